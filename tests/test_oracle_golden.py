@@ -1,0 +1,130 @@
+"""Pin the CPU oracle (oracle/disco_ref.py) against golden vectors captured from the real
+reference by oracle/make_golden.py.  CPU only; a few forwards of the oracle."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import disco_ref as R
+
+TOL = 2e-5  # fp32 CPU vs fp32 CPU, different op order
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _close(a, b, tol=TOL):
+    a = torch.as_tensor(np.asarray(a)); b = torch.as_tensor(np.asarray(b))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a.double() - b.double()).abs().max().item()
+    assert err <= tol, f"max abs err {err:.3e} > {tol}"
+
+
+# ---------------------------------------------------------------- components ------------
+
+
+def test_gamut_table(golden_dir, q_to_ab):
+    g = _load(golden_dir, "components")
+    assert np.array_equal(g["q_to_ab"], q_to_ab)
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (32, 32), (32, 48), (48, 32), (8, 12)])
+def test_position_encoding(golden_dir, hw):
+    g = _load(golden_dir, "components")
+    _close(R.position_encoding(*hw), g["pos_%dx%d" % hw], 1e-6)
+
+
+def test_pool_unpool_sizes(golden_dir):
+    g = _load(golden_dir, "components")
+    prob, feat, tok = (torch.from_numpy(g[k]) for k in ("pool_prob", "pool_feat", "up_tok"))
+    pooled, conf = R.poolfeat(feat, prob, 16)
+    _close(pooled, g["pool_out"], 1e-5)
+    _close(conf, g["pool_conf"], 1e-6)
+    assert torch.equal(R.spixel_size(prob, 16), torch.from_numpy(g["spix_size"]))  # multiples of 1/256: exact
+    _close(R.upfeat(tok, prob, 16), g["up_out"], 1e-6)
+
+
+@pytest.mark.parametrize("t", [0, 1, 2])
+def test_sample_anchor_colors(golden_dir, q_to_ab, t):
+    g = _load(golden_dir, "components")
+    out = R.sample_anchor_colors(torch.from_numpy(g["samp_prob"]), torch.from_numpy(q_to_ab), t)
+    assert torch.equal(out, torch.from_numpy(g["samp_T%d" % t]))  # bin centres / 110: exact
+
+
+def test_labels_and_decode(golden_dir, q_to_ab):
+    g = _load(golden_dir, "components")
+    q = torch.from_numpy(q_to_ab)
+    ab = torch.from_numpy(g["enc_ab"])
+    assert torch.equal(R.color_labels(ab, q), torch.from_numpy(g["enc_label"]))
+    _close(R.encode_ab2ind(ab, q)[:, ::7], g["enc_soft_sub"], 1e-6)
+    assert torch.equal(R.decode_ind2ab(torch.from_numpy(g["dec_logit"]), q, 0), torch.from_numpy(g["dec_ab_T0"]))
+
+
+def test_kmeans_matches_reference(golden_dir):
+    g = _load(golden_dir, "components")
+    torch.set_rng_state(torch.from_numpy(g["km_torch_rng"]))  # the reference's fallback draws
+    for x, init, ids in zip(g["km_x"], g["km_init"], g["km_ids"]):
+        a, passes, events = R.kmeans_one(torch.from_numpy(x), init, 8)
+        assert np.array_equal(a.numpy(), ids.astype(np.int64))
+    assert events > 0  # the last case has duplicated rows: the empty-cluster fallback ran
+
+
+def test_kmeans_init_stream(golden_dir):
+    g = _load(golden_dir, "components")
+    np.random.seed(130)
+    assert np.array_equal(R.kmeans_init_indices(4, 256, 8), g["km_init"])
+
+
+# ---------------------------------------------------------------- full forwards ---------
+
+
+def _run(golden_dir, synth_sd, q_to_ab, name):
+    from disentangledcolorization_amd import synth
+
+    g = _load(golden_dir, name)
+    n, h, w, k, T, rh, iseed, seed = (int(v) for v in g["recipe"])
+    gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
+    oracle = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=k, random_hint=bool(rh))
+    np.random.seed(seed); torch.manual_seed(seed); random.seed(seed)
+    out, info = oracle.forward(gray, ab, sampled_T=T, return_info=True)
+    return g, out, info
+
+
+def _check_forward(g, out, info):
+    pal, ref, pred, aff, spix, mask = out
+    fs, as_ = (int(v) for v in g["strides"])
+    sub = int(g["sub"])
+    _close(info["feats"][:, :, ::fs, ::fs], g["feats_sub"], 1e-4)   # features are O(10)
+    _close(aff[: g["aff_sub"].shape[0], :, ::as_, ::as_], g["aff_sub"], 1e-5)
+    _close(info["enc"], g["enc"], 1e-4)
+    if "cluster_ids" in g.files:
+        assert np.array_equal(info["assign"].numpy(), g["cluster_ids"].astype(np.int64))
+    assert torch.equal(mask, torch.from_numpy(g["hint_mask"]))      # anchors bit-exact
+    assert torch.equal(spix, torch.from_numpy(g["spix_colors"]))
+    _close(info["dec"], g["dec"], 1e-4)
+    if sub == 1:
+        _close(info["hint"] if "hint" in info else g["hint"], g["hint"], 1e-4)
+        _close(pal, g["pal_logit"], 1e-4); _close(ref, g["ref_logit"], 1e-4)
+        _close(pred, g["pred_colors"], TOL)
+    else:
+        _close(pal[:, ::sub], g["pal_logit"], 1e-4); _close(ref[:, ::sub], g["ref_logit"], 1e-4)
+        _close(pred[:, :, ::sub, ::sub], g["pred_colors"], TOL)
+    assert abs(float(pred.abs().max()) - float(g["pred_absmax"])) < TOL
+
+
+@pytest.mark.parametrize("name", ["fwd_n2_256_k8", "fwd_diverse_256_k16", "fwd_n1_128x192_k8",
+                                  "fwd_randhint_128_k16", "fwd_gt_128_k8", "fwd_n1_512x768_k8"])
+def test_forward_matches_reference(golden_dir, synth_sd, q_to_ab, name):
+    g, out, info = _run(golden_dir, synth_sd, q_to_ab, name)
+    _check_forward(g, out, info)
+
+
+def test_diverse_requires_single_image(synth_sd, q_to_ab):
+    from disentangledcolorization_amd import synth
+
+    gray, ab = synth.synth_inputs(2, 32, 32)
+    with pytest.raises(RuntimeError):
+        R.DiscoOracle(synth_sd, q_to_ab, n_clusters=2).forward(gray, ab, sampled_T=2)
