@@ -1,0 +1,147 @@
+// common.h — internal declarations shared by the HIP translation units of libdisco_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/disco_hip.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace disco {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define DISCO_HIP_CHECK(expr)                                  \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) return ::disco::hip_fail(_e, #expr); \
+    } while (0)
+
+#define DISCO_LAUNCH_CHECK(what)                                  \
+    do {                                                          \
+        hipError_t _e = hipGetLastError();                        \
+        if (_e != hipSuccess) return ::disco::hip_fail(_e, what); \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---- activation tensor: NHWC fp16, hi plane followed by lo plane -----------------------------
+struct Act {
+    f16* p = nullptr;  // hi plane; lo plane at p + plane
+    int n = 0, h = 0, w = 0, c = 0;
+    size_t plane = 0;  // elements per plane = n*h*w*c
+    size_t bytes() const { return plane * 2 * sizeof(f16); }
+};
+
+// ---- conv3x3 (MFMA implicit GEMM) ---------------------------------------------------------------
+constexpr int CONV_CK = 16;  // input-channel chunk (one MFMA k-block)
+
+struct ConvSrc {
+    const f16* p;    // hi plane
+    long plane;      // elements between hi and lo plane
+    int c;           // channels of this source (multiple of 16)
+    int h, w;        // stored size (half of logical when up)
+    int up;          // nearest x2 upsample on read
+};
+
+struct ConvArgs {
+    ConvSrc src[2];
+    int nsrc;
+    int n, h_in, w_in;  // logical input size
+    int c_in;           // padded total input channels (multiple of 16)
+    int h_out, w_out, stride;
+    const f16* w;       // packed weights
+    int c_out;          // real output channels
+    int c_out_pad;      // channel stride of the output tensor
+    const float* bias;
+    const float* bn_scale;
+    const float* bn_shift;
+    const f16* res;     // residual (same layout as out) or null
+    long res_plane;
+    f16* out;
+    long out_plane;
+    int act;
+    float slope;
+    int precision;
+};
+
+size_t conv3x3_packed_bytes(int c_out, int c_in_pad);
+// h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map[i] = source channel index for packed channel i or -1 (zero)
+void conv3x3_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed);
+int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+
+// ---- direct (VALU) convs ------------------------------------------------------------------------
+// first layers: Cin = 1, fp32 NCHW gray input -> act output
+int launch_conv_c1(const float* d_gray, const float* d_w /*(cout,9)*/, const float* d_bias, const float* d_bn_scale,
+                   const float* d_bn_shift, f16* out, long out_plane, int n, int h, int w, int c_out, int act,
+                   float slope, hipStream_t s);
+// last layers: small Cout, act input -> fp32 NCHW output; mode 0 = softmax over channels, 1 = tanh, 2 = none
+int launch_conv_small_out(const f16* in, long in_plane, int c_in, const float* d_w /*(9,c_in,cout)*/,
+                          const float* d_bias, float* d_out_nchw, int n, int h, int w, int c_out, int mode,
+                          hipStream_t s);
+size_t deconv4x4_packed_bytes(int c_in, int c_out);
+void deconv4x4_pack_host(const float* h_w_iohw, int c_in, int c_out, void* h_packed);
+int launch_deconv4x4(const f16* in, long in_plane, const void* d_packed, const float* d_bias, f16* out,
+                     long out_plane, int n, int h_in, int w_in, int c_in, int c_out, float slope, int precision,
+                     hipStream_t s);
+
+// ---- layout conversion --------------------------------------------------------------------------
+int launch_nchw_to_act(const float* src, f16* dst, long plane, int n, int c, int h, int w, int c_pad, hipStream_t s);
+int launch_act_to_nchw(const f16* src, long plane, float* dst, int n, int c, int h, int w, int c_pad, hipStream_t s);
+
+// ---- superpixel ops -----------------------------------------------------------------------------
+// feature source for pooling: either act planes (c_act channels) and/or extra fp32 NCHW channels
+struct PoolArgs {
+    const f16* feat_act; long feat_plane; int c_act;   // NHWC act features, channels [0,c_act)   (may be null)
+    const float* feat_nchw; int c_nchw;                 // fp32 NCHW features, channels [c_act, C)  (may be null)
+    const float* prob;                                  // (n,9,H,W) fp32
+    float* partial;                                     // workspace (cells,9,C+1)
+    float* cnt;                                         // workspace (cells,9)
+    float* tok_out; int c_tok;                          // channels [0,c_tok) as tokens (n,L,c_tok)  (may be null)
+    float* nchw_out; int c_from;                        // channels [c_from,C) as NCHW (n,C-c_from,h,w) (may be null)
+    float* conf;                                        // (n,1,h,w) or null
+    float* sizes;                                       // (n,h*w) or null
+    int n, H, W, sp;
+};
+size_t poolfeat_ws_bytes(int n, int c, int H, int W, int sp);
+int launch_poolfeat(const PoolArgs& a, hipStream_t s);
+// upfeat: tokens (n,L,C) [tok_layout] or NCHW -> act planes (c_pad) and/or fp32 NCHW
+int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_rep, f16* out_act, long out_plane,
+                  float* out_nchw, int n, int c, int h, int w, int sp, hipStream_t s);
+// gray (n,1,H,W) -> 16-channel act with gray in channel 0 (rep: output image i reads gray image i/rep)
+int launch_gray16(const float* gray, int rep, f16* out, long out_plane, int n, int H, int W, hipStream_t s);
+
+// ---- token path ---------------------------------------------------------------------------------
+constexpr int D_MODEL = 64;
+constexpr int D_FF = 256;
+constexpr int N_HEAD = 8;
+constexpr int N_VOCAB = 313;
+constexpr int ENC_LAYERS = 6;
+// per layer, state_dict order: in_proj_w(192x64) in_proj_b(192) out_w(64x64) out_b(64) l1_w(256x64) l1_b(256)
+//                              l2_w(64x256) l2_b(64) n1_w n1_b n2_w n2_b (64 each)
+constexpr size_t ENC_LAYER_FLOATS = 192 * 64 + 192 + 64 * 64 + 64 + 256 * 64 + 256 + 64 * 256 + 64 + 4 * 64;
+size_t encoder_ws_bytes(int n, int l);
+int launch_encoder_stack(const float* x, const float* pos, const float* weights, float* out, int n, int l, void* ws,
+                         hipStream_t s);
+void position_encoding_host(float* h_pos /*(h*w,64)*/, int h, int w);
+// logits: (n,L,64) x (313,64)^T -> NCHW (n,313,L)
+int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s);
+int launch_select_colors(const float* logit_nchw, const float* q_to_ab, float* colors, int32_t* labels, int n, int l,
+                         int t_first, int t_count, hipStream_t s);
+int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labels, int n, int l, hipStream_t s);
+int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
+                          int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,
+                          int l, int k, hipStream_t s);
+int launch_hint_mask_from_pos(const int32_t* pos, float* hint_mask, int n, int l, int k, hipStream_t s);
+// hint[t] = W[:, :64] src + m W[:, 64+label] + m W[:, 377]
+int launch_hint_embed(const float* src, int src_rep, const int32_t* labels, const float* mask, int mask_rep,
+                      const float* w_emb, float* out, int n, int l, hipStream_t s);
+
+}  // namespace disco

@@ -1,0 +1,265 @@
+// spixel.hip — superpixel pooling / sizes / un-pooling (K4, K5, K15 of SURVEY §2b).
+//
+// Reference: models/basic.py:274-324 (poolfeat), :327-335 (get_spixel_size), :338-376 (upfeat).
+// Slot c = (dy+1)*3 + (dx+1): a pixel of cell (a,b) with probability P_c belongs to superpixel
+// (a+dy, b+dx).  The reference evaluates nine avg_pool2d + pad/shift/accumulate passes over the
+// full-resolution tensor; here every cell is read ONCE:
+//   pass 1 (one workgroup per cell): partial[cell][c][ch] = mean_{p in cell} feat(p,ch) P_c(p),
+//           ch == C is the all-ones channel (-> probability mass); cnt[cell][c] = #{p: P_c(p) == max_c' P_c'(p)}
+//   pass 2 (one thread per (superpixel, ch)): num = sum_{c=0..8} partial[cell(i-dy,j-dx)][c][ch]
+//           accumulated in slot order 0..8 like the reference; pooled = num / (den + 1e-8);
+//           size = (sum_c cnt) / sp^2  (exact: multiples of 1/sp^2)
+#include "common.h"
+
+namespace disco {
+
+namespace {
+
+// blockDim = 256; grid = n*h*w cells
+__global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
+    const int C = a.c_act + a.c_nchw;  // feature channels (ones channel is index C)
+    const int hs = a.H / a.sp, ws = a.W / a.sp;
+    const int cell = blockIdx.x;
+    const int cx = cell % ws, cy = (cell / ws) % hs, n = cell / (ws * hs);
+    const int npix = a.sp * a.sp;
+    const long HW = (long)a.H * a.W;
+    const float* prob = a.prob + (long)n * 9 * HW;
+    extern __shared__ float sm[];      // [npix][9] probabilities, then reduction scratch
+    float* sp_prob = sm;
+    float* red = sm + npix * 9;       // [4 pixel groups][9 slots][64 channels] partial sums
+    __shared__ int s_cnt[9];
+    if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // load probabilities of the cell and count hard assignments (ties count for every maximal slot)
+    for (int p = threadIdx.x; p < npix; p += blockDim.x) {
+        const int py = p / a.sp, px = p % a.sp;
+        const long off = (long)(cy * a.sp + py) * a.W + cx * a.sp + px;
+        float v[9], m = -1.f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { v[c] = prob[c * HW + off]; m = fmaxf(m, v[c]); sp_prob[p * 9 + c] = v[c]; }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) if (v[c] == m) atomicAdd(&s_cnt[c], 1);
+    }
+    __syncthreads();
+    // thread = (channel ch = tid & 63 (+64 second round), pixel group g = tid >> 6)
+    const int g = threadIdx.x >> 6, lanech = threadIdx.x & 63;
+    const float inv = 1.f / (float)npix;
+    for (int ch0 = 0; ch0 <= C; ch0 += 64) {
+        const int ch = ch0 + lanech;
+        float acc[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+        if (ch <= C) {
+            for (int p = g; p < npix; p += 4) {
+                const int py = p / a.sp, px = p % a.sp;
+                const long pix = (long)(cy * a.sp + py) * a.W + cx * a.sp + px;
+                float f;
+                if (ch == C) f = 1.f;
+                else if (ch < a.c_act) {
+                    const long idx = ((long)n * HW + pix) * a.c_act + ch;
+                    f = (float)a.feat_act[idx] + (float)a.feat_act[idx + a.feat_plane];
+                } else f = a.feat_nchw[((long)n * a.c_nchw + (ch - a.c_act)) * HW + pix];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) acc[c] = fmaf(f, sp_prob[p * 9 + c], acc[c]);
+            }
+        }
+        // reduce the 4 pixel groups
+#pragma unroll
+        for (int c = 0; c < 9; ++c) red[(g * 9 + c) * 64 + lanech] = acc[c];
+        __syncthreads();
+        if (g == 0 && ch <= C) {
+            float* dst = a.partial + ((long)cell * 9) * (C + 1) + ch;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const float s = (red[(0 * 9 + c) * 64 + lanech] + red[(1 * 9 + c) * 64 + lanech]) +
+                                (red[(2 * 9 + c) * 64 + lanech] + red[(3 * 9 + c) * 64 + lanech]);
+                dst[(long)c * (C + 1)] = s * inv;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) a.cnt[(long)cell * 9 + threadIdx.x] = (float)s_cnt[threadIdx.x];
+}
+
+__global__ void pool_gather_kernel(PoolArgs a) {
+    const int C = a.c_act + a.c_nchw;
+    const int hs = a.H / a.sp, ws = a.W / a.sp, L = hs * ws;
+    const long total = (long)a.n * L * (C + 1);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % (C + 1));
+        const long sp_i = t / (C + 1);
+        const int j = (int)(sp_i % ws), i = (int)((sp_i / ws) % hs);
+        const int n = (int)(sp_i / L);
+        float num = 0.f, den = 0.f, cn = 0.f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int dy = c / 3 - 1, dx = c % 3 - 1;
+            const int si = i - dy, sj = j - dx;
+            if (si < 0 || si >= hs || sj < 0 || sj >= ws) continue;
+            const long cell = ((long)n * hs + si) * ws + sj;
+            const float* pp = a.partial + (cell * 9 + c) * (C + 1);
+            num = __fadd_rn(num, pp[ch]);
+            den = __fadd_rn(den, pp[C]);
+            cn += a.cnt[cell * 9 + c];
+        }
+        const int tok = i * ws + j;
+        if (ch == C) {
+            if (a.conf) a.conf[(long)n * L + tok] = den;
+            if (a.sizes) a.sizes[(long)n * L + tok] = cn / (float)(a.sp * a.sp);
+        } else {
+            const float v = num / (den + 1e-8f);
+            if (a.tok_out && ch < a.c_tok) a.tok_out[((long)n * L + tok) * a.c_tok + ch] = v;
+            if (a.nchw_out && ch >= a.c_from) a.nchw_out[((long)n * (C - a.c_from) + (ch - a.c_from)) * L + tok] = v;
+        }
+    }
+}
+
+// upfeat: out(p) = sum_c P_c(p) tok[cell(p) + (dy,dx)]; thread = (pixel, 8 channels)
+__global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ tok, int tok_layout,
+                                                     const float* __restrict__ prob, int prob_rep, f16* out_act,
+                                                     long out_plane, float* out_nchw, int n, int c, int hs, int ws,
+                                                     int sp) {
+    const int H = hs * sp, W = ws * sp, L = hs * ws;
+    const long HW = (long)H * W;
+    const int groups = c >> 3;
+    const long total = (long)n * HW * groups;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        const long pix = t / groups;
+        const long p = pix % HW;
+        const int img = (int)(pix / HW);
+        const int y = (int)(p / W), x = (int)(p % W);
+        const int cy = y / sp, cx = x / sp;
+        const float* pr = prob + (long)(img / prob_rep) * 9 * HW + p;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int dy = s / 3 - 1, dx = s % 3 - 1;
+            const int ty = cy + dy, tx = cx + dx;
+            const float pw = pr[s * HW];
+            float tv[8];
+            if (ty < 0 || ty >= hs || tx < 0 || tx >= ws) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tv[j] = 0.f;
+            } else if (tok_layout) {
+                const float* tp = tok + ((long)img * L + ty * ws + tx) * c + g * 8;
+                const float4 a0 = *reinterpret_cast<const float4*>(tp), a1 = *reinterpret_cast<const float4*>(tp + 4);
+                tv[0] = a0.x; tv[1] = a0.y; tv[2] = a0.z; tv[3] = a0.w;
+                tv[4] = a1.x; tv[5] = a1.y; tv[6] = a1.z; tv[7] = a1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tv[j] = tok[((long)img * c + g * 8 + j) * L + ty * ws + tx];
+            }
+            // the reference multiplies then accumulates in slot order (no fused multiply-add)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = s == 0 ? __fmul_rn(tv[j], pw) : __fadd_rn(acc[j], __fmul_rn(tv[j], pw));
+        }
+        if (out_act) {
+            f16x8 hv, lv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hv[j] = (f16)acc[j]; lv[j] = (f16)(acc[j] - (float)hv[j]); }
+            f16* o = out_act + pix * c + g * 8;
+            *reinterpret_cast<f16x8*>(o) = hv;
+            *reinterpret_cast<f16x8*>(o + out_plane) = lv;
+        }
+        if (out_nchw) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out_nchw[((long)img * c + g * 8 + j) * HW + p] = acc[j];
+        }
+    }
+}
+
+// generic (c not a multiple of 8) NCHW-only variant: thread = (pixel, channel)
+__global__ void upfeat_scalar_kernel(const float* __restrict__ tok, const float* __restrict__ prob, float* out_nchw,
+                                     int n, int c, int hs, int ws, int sp) {
+    const int H = hs * sp, W = ws * sp, L = hs * ws;
+    const long HW = (long)H * W;
+    const long total = (long)n * c * HW;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long p = t % HW;
+        const int ch = (int)((t / HW) % c);
+        const int img = (int)(t / (HW * c));
+        const int y = (int)(p / W), x = (int)(p % W);
+        const int cy = y / sp, cx = x / sp;
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int ty = cy + s / 3 - 1, tx = cx + s % 3 - 1;
+            const float tv = (ty < 0 || ty >= hs || tx < 0 || tx >= ws) ? 0.f : tok[((long)img * c + ch) * L + ty * ws + tx];
+            const float term = __fmul_rn(tv, prob[((long)img * 9 + s) * HW + p]);
+            acc = s == 0 ? term : __fadd_rn(acc, term);
+        }
+        out_nchw[t] = acc;
+    }
+}
+
+__global__ void gray16_kernel(const float* __restrict__ gray, int rep, f16* out, long out_plane, long npix_total,
+                              long HW) {
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix_total; pix += (long)gridDim.x * blockDim.x) {
+        const long img = pix / HW, p = pix % HW;
+        const float v = gray[(img / rep) * HW + p];
+        f16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (f16)0.f;
+        f16x8 h = z, l = z;
+        h[0] = (f16)v;
+        l[0] = (f16)(v - (float)h[0]);
+        f16* o = out + pix * 16;
+        *reinterpret_cast<f16x8*>(o) = h;
+        *reinterpret_cast<f16x8*>(o + 8) = z;
+        *reinterpret_cast<f16x8*>(o + out_plane) = l;
+        *reinterpret_cast<f16x8*>(o + out_plane + 8) = z;
+    }
+}
+
+inline int grid_for(long total, int block = 256) {
+    long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace
+
+size_t poolfeat_ws_bytes(int n, int c, int H, int W, int sp) {
+    const size_t cells = (size_t)n * (H / sp) * (W / sp);
+    return cells * 9 * (c + 1) * sizeof(float) + cells * 9 * sizeof(float);
+}
+
+int launch_poolfeat(const PoolArgs& a, hipStream_t s) {
+    const int C = a.c_act + a.c_nchw;
+    if (a.H % a.sp || a.W % a.sp) { set_error("poolfeat: %dx%d not a multiple of sp=%d", a.H, a.W, a.sp); return DISCO_ESHAPE; }
+    const int cells = a.n * (a.H / a.sp) * (a.W / a.sp);
+    const size_t smem = ((size_t)a.sp * a.sp * 9 + 4 * 9 * 64) * sizeof(float);
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(cells), dim3(256), smem, s, a);
+    DISCO_LAUNCH_CHECK("pool_partial_kernel");
+    const long total = (long)cells * (C + 1);
+    hipLaunchKernelGGL(pool_gather_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    DISCO_LAUNCH_CHECK("pool_gather_kernel");
+    return DISCO_OK;
+}
+
+int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_rep, f16* out_act, long out_plane,
+                  float* out_nchw, int n, int c, int h, int w, int sp, hipStream_t s) {
+    if (c % 8 == 0) {
+        const long total = (long)n * h * sp * w * sp * (c / 8);
+        hipLaunchKernelGGL(upfeat_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, tok_layout, prob, prob_rep,
+                           out_act, out_plane, out_nchw, n, c, h, w, sp);
+        DISCO_LAUNCH_CHECK("upfeat_kernel");
+        return DISCO_OK;
+    }
+    if (tok_layout || out_act || prob_rep != 1) { set_error("upfeat: c=%d needs the NCHW path", c); return DISCO_ESHAPE; }
+    const long total = (long)n * c * h * sp * w * sp;
+    hipLaunchKernelGGL(upfeat_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, prob, out_nchw, n, c, h, w, sp);
+    DISCO_LAUNCH_CHECK("upfeat_scalar_kernel");
+    return DISCO_OK;
+}
+
+int launch_gray16(const float* gray, int rep, f16* out, long out_plane, int n, int H, int W, hipStream_t s) {
+    const long HW = (long)H * W, total = (long)n * HW;
+    hipLaunchKernelGGL(gray16_kernel, dim3(grid_for(total)), dim3(256), 0, s, gray, rep, out, out_plane, total, HW);
+    DISCO_LAUNCH_CHECK("gray16_kernel");
+    return DISCO_OK;
+}
+
+}  // namespace disco

@@ -1,0 +1,542 @@
+// tokens.hip — the superpixel-token path in exact fp32 (K6-K14 of SURVEY §2b).
+//
+//   token_gemm        every nn.Linear on the path as C[T,O] = A[T,K] W[O,K]^T on the fp32 matrix pipe
+//                     (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, exact f32) with fused epilogues:
+//                       QKV   packed in-projection of nn.MultiheadAttention, q=k=src+pos, v=src, q scaled
+//                             (transformer2d.py:52-54)
+//                       RELU  linear1 + ReLU (:56)            RES_LN  out_proj/linear2 + residual + LayerNorm (:55-59)
+//                       LOGIT mid_word_prj / trg_word_prj -> NCHW logits (model.py:134-135,187-189)
+//                       HINT  trg_word_emb on [src ; m*onehot313(label) ; m] (model.py:183-185)
+//   attention_kernel  softmax(Q K^T) V per (image, head), d_head = 8, thread per query, keys/values in LDS
+//   kmeans_anchor_kernel  Lloyd k-means (clusterkit.py:112-208) + per-cluster anchor argmax (anchor_gen.py:96-101)
+//   select_colors_kernel  softmax(313) -> stable top-10 -> T-th distinct colour (anchor_gen.py:54-90) + label
+//   nearest_bin_kernel    argmax of encode_ab2ind = nearest gamut bin (basic.py:177-194, model.py:166)
+#include <cmath>
+#include <vector>
+#include "common.h"
+
+namespace disco {
+
+namespace {
+
+enum { EPI_QKV = 0, EPI_RELU = 1, EPI_RES_LN = 2, EPI_LOGIT = 3, EPI_HINT = 4 };
+
+struct GemmArgs {
+    const float* A;      // (rows_a, K)
+    int a_rep;           // virtual image i reads A image i / a_rep
+    const float* pos;    // (L,64) added to A for EPI_QKV q,k tiles
+    const float* W;      // (O, ldw) row-major; the first K columns are contracted
+    int ldw;
+    const float* bias;   // (O) or null
+    int T, L, K, O;      // T = virtual rows = n_virtual * L
+    float* out;          // QKV: q|k|v each (T,64); RELU: (T,O); RES_LN: (T,64); LOGIT: (n,O,L); HINT: (T,64)
+    const float* res;    // RES_LN residual (T,64)
+    const float* ln_w;
+    const float* ln_b;
+    float q_scale;
+    const int32_t* labels;  // HINT: (T)
+    const float* mask;      // HINT: (T / mask_rep ...) indexed like A with mask_rep
+    int mask_rep;
+};
+
+constexpr int GP = 65;  // padded LDS row (floats)
+
+template <int EPI>
+__global__ __launch_bounds__(256) void token_gemm_kernel(const GemmArgs g) {
+    __shared__ float sA[64 * GP];
+    __shared__ float sB[64 * GP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0 = blockIdx.x * 64, col0 = blockIdx.y * 64;
+    const bool add_pos = EPI == EPI_QKV && blockIdx.y < 2;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    for (int k0 = 0; k0 < g.K; k0 += 64) {
+        if (k0) __syncthreads();
+        // stage A rows [row0,row0+64) x [k0,k0+64) and W rows [col0,col0+64) x [k0,k0+64)
+        for (int u = tid; u < 64 * 16; u += 256) {
+            const int r = u >> 4, c4 = (u & 15) * 4;
+            const int row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < g.T) {
+                const int img = row / g.L, t = row - img * g.L;
+                const float* ap = g.A + ((size_t)(img / g.a_rep) * g.L + t) * g.K + k0 + c4;
+                v = *reinterpret_cast<const float4*>(ap);
+                if (add_pos) {
+                    const float4 p = *reinterpret_cast<const float4*>(g.pos + (size_t)t * 64 + c4);
+                    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+                }
+            }
+            float* d = sA + r * GP + c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            const int col = col0 + r;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < g.O) w = *reinterpret_cast<const float4*>(g.W + (size_t)col * g.ldw + k0 + c4);
+            float* e = sB + r * GP + c4;
+            e[0] = w.x; e[1] = w.y; e[2] = w.z; e[3] = w.w;
+        }
+        __syncthreads();
+        const float* pa = sA + (wm * 32 + (lane & 31)) * GP + (lane >> 5);
+        const float* pb = sB + (wn * 32 + (lane & 31)) * GP + (lane >> 5);
+#pragma unroll 8
+        for (int k = 0; k < 64; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    // C tile -> LDS (reuse sA): row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane & 31
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        sA[r * GP + wn * 32 + (lane & 31)] = acc[e];
+    }
+    __syncthreads();
+    // thread = (row = tid/4, 16 columns)
+    const int r = tid >> 2, cq = (tid & 3) * 16;
+    const int row = row0 + r;
+    const bool rok = row < g.T;
+    const int img = rok ? row / g.L : 0, t = rok ? row - img * g.L : 0;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int col = col0 + cq + j;
+        v[j] = sA[r * GP + cq + j] + ((g.bias && col < g.O) ? g.bias[col] : 0.f);
+    }
+    if (EPI == EPI_QKV) {
+        if (rok) {
+            float* o = g.out + (size_t)blockIdx.y * g.T * 64 + (size_t)row * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = blockIdx.y == 0 ? v[j] * g.q_scale : v[j];
+        }
+    } else if (EPI == EPI_RELU) {
+        if (rok) {
+            float* o = g.out + (size_t)row * g.O + col0 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = fmaxf(v[j], 0.f);
+        }
+    } else if (EPI == EPI_LOGIT) {
+        if (rok) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int col = col0 + cq + j;
+                if (col < g.O) g.out[((size_t)img * g.O + col) * g.L + t] = v[j];
+            }
+        }
+    } else if (EPI == EPI_HINT) {
+        if (rok) {
+            const float m = g.mask[(size_t)(img / g.mask_rep) * g.L + t];
+            const int lab = g.labels[row];
+            float* o = g.out + (size_t)row * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float* wr = g.W + (size_t)(cq + j) * g.ldw;
+                o[j] = v[j] + m * wr[64 + lab] + m * wr[64 + N_VOCAB];
+            }
+        }
+    } else {  // EPI_RES_LN: y = LayerNorm(res + v), biased variance, eps 1e-5
+        float s = 0.f;
+        if (rok) {
+            const float* rp = g.res + (size_t)row * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { v[j] += rp[j]; s += v[j]; }
+        }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        const float mean = s * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const float d = v[j] - mean; q += d * d; }
+        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+        const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + 1e-5f);
+        if (rok) {
+            float* o = g.out + (size_t)row * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = (v[j] - mean) * rstd * g.ln_w[cq + j] + g.ln_b[cq + j];
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs& g, hipStream_t s) {
+    dim3 grid(cdiv(g.T, 64), cdiv(g.O, 64));
+    hipLaunchKernelGGL(token_gemm_kernel<EPI>, grid, dim3(256), 0, s, g);
+    DISCO_LAUNCH_CHECK("token_gemm_kernel");
+    return DISCO_OK;
+}
+
+// ---- attention: block = 256 queries of one (image, head); keys/values streamed through LDS in chunks ----
+constexpr int KCH = 256;
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, float* out, int L) {
+    __shared__ float4 sk[KCH * 2];
+    __shared__ float4 sv[KCH * 2];
+    const int qb = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
+    const int qi = qb * 256 + threadIdx.x;
+    const bool ok = qi < L;
+    const size_t base = (size_t)img * L * 64 + head * 8;
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0;
+    if (ok) {
+        q0 = *reinterpret_cast<const float4*>(q + base + (size_t)qi * 64);
+        q1 = *reinterpret_cast<const float4*>(q + base + (size_t)qi * 64 + 4);
+    }
+    float m = -INFINITY, l = 0.f;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int c0 = 0; c0 < L; c0 += KCH) {
+        const int nk = min(KCH, L - c0);
+        __syncthreads();
+        for (int u = threadIdx.x; u < nk * 2; u += 256) {
+            const int key = u >> 1, part = u & 1;
+            sk[u] = *reinterpret_cast<const float4*>(k + base + (size_t)(c0 + key) * 64 + part * 4);
+            sv[u] = *reinterpret_cast<const float4*>(v + base + (size_t)(c0 + key) * 64 + part * 4);
+        }
+        __syncthreads();
+        // pass 1: chunk maximum
+        float cm = -INFINITY;
+        for (int j = 0; j < nk; ++j) {
+            const float4 a = sk[2 * j], b = sk[2 * j + 1];
+            const float sc = q0.x * a.x + q0.y * a.y + q0.z * a.z + q0.w * a.w + q1.x * b.x + q1.y * b.y + q1.z * b.z + q1.w * b.w;
+            cm = fmaxf(cm, sc);
+        }
+        const float mn = fmaxf(m, cm);
+        const float alpha = expf(m - mn);   // 0 on the first chunk (m = -inf)
+        l *= alpha;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= alpha;
+        m = mn;
+        // pass 2: exponentials, sum and weighted values
+        for (int j = 0; j < nk; ++j) {
+            const float4 a = sk[2 * j], b = sk[2 * j + 1];
+            const float sc = q0.x * a.x + q0.y * a.y + q0.z * a.z + q0.w * a.w + q1.x * b.x + q1.y * b.y + q1.z * b.z + q1.w * b.w;
+            const float p = expf(sc - m);
+            l += p;
+            const float4 c = sv[2 * j], d = sv[2 * j + 1];
+            o[0] = fmaf(p, c.x, o[0]); o[1] = fmaf(p, c.y, o[1]); o[2] = fmaf(p, c.z, o[2]); o[3] = fmaf(p, c.w, o[3]);
+            o[4] = fmaf(p, d.x, o[4]); o[5] = fmaf(p, d.y, o[5]); o[6] = fmaf(p, d.z, o[6]); o[7] = fmaf(p, d.w, o[7]);
+        }
+    }
+    if (ok) {
+        const float inv = 1.f / l;
+        float* op = out + base + (size_t)qi * 64;
+        *reinterpret_cast<float4*>(op) = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+    }
+}
+
+// ---- k-means + anchors: one workgroup (256 threads) per image ---------------------------------------------------
+constexpr int KMAX = 32;
+__global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
+                                                            const int32_t* __restrict__ init_idx,
+                                                            const int32_t* __restrict__ fallback, int max_fallback,
+                                                            int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
+                                                            int32_t* info, int L, int K) {
+    __shared__ float cen[KMAX * 64];
+    __shared__ float cnew[KMAX * 64];
+    __shared__ int cnt[KMAX];
+    __shared__ float shift_part[KMAX];
+    __shared__ int s_events, s_stop;
+    __shared__ float red_v[256];
+    __shared__ int red_i[256];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const float* X = x + (size_t)img * L * 64;
+    int32_t* assign = assign_out + (size_t)img * L;
+    for (int u = tid; u < K * 64; u += 256) cen[u] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
+    if (tid == 0) { s_events = 0; s_stop = 0; }
+    __syncthreads();
+    int passes = 0;
+    while (true) {
+        // assignment: first minimum of sum_c (x - c)^2
+        for (int t = tid; t < L; t += 256) {
+            const float* xp = X + (size_t)t * 64;
+            float best = INFINITY; int bi = 0;
+            for (int j = 0; j < K; ++j) {
+                float d = 0.f;
+#pragma unroll 16
+                for (int c = 0; c < 64; ++c) { const float df = xp[c] - cen[j * 64 + c]; d = fmaf(df, df, d); }
+                if (d < best) { best = d; bi = j; }
+            }
+            assign[t] = bi;
+        }
+        if (tid < K) cnt[tid] = 0;
+        __syncthreads();
+        for (int t = tid; t < L; t += 256) atomicAdd(&cnt[assign[t]], 1);
+        __syncthreads();
+        // empty clusters take a fallback row, in cluster order (sequential bookkeeping by one thread)
+        if (tid == 0) {
+            for (int j = 0; j < K; ++j)
+                if (cnt[j] == 0) {
+                    const int e = s_events++;
+                    const int row = (fallback && e < max_fallback) ? fallback[(size_t)img * max_fallback + e] : 0;
+                    cnt[j] = -(row + 1);   // marker: negative = use row
+                }
+        }
+        __syncthreads();
+        // update: thread = (cluster, channel) pairs
+        for (int u = tid; u < K * 64; u += 256) {
+            const int j = u >> 6, c = u & 63;
+            float s;
+            if (cnt[j] < 0) s = X[(size_t)(-cnt[j] - 1) * 64 + c];
+            else {
+                s = 0.f;
+                for (int t = 0; t < L; ++t) if (assign[t] == j) s += X[(size_t)t * 64 + c];
+                s = s / (float)cnt[j];
+            }
+            cnew[u] = s;
+        }
+        __syncthreads();
+        // centre shift = sum_j sqrt(sum_c (new-old)^2)
+        if (tid < K) {
+            float q = 0.f;
+            for (int c = 0; c < 64; ++c) { const float d = cnew[tid * 64 + c] - cen[tid * 64 + c]; q += d * d; }
+            shift_part[tid] = sqrtf(q);
+        }
+        __syncthreads();
+        ++passes;
+        if (tid == 0) {
+            float sh = 0.f;
+            for (int j = 0; j < K; ++j) sh += shift_part[j];
+            s_stop = (sh * sh < 1e-4f) || passes >= 20;
+        }
+        for (int u = tid; u < K * 64; u += 256) cen[u] = cnew[u];
+        __syncthreads();
+        if (s_stop) break;
+    }
+    // anchors: per cluster the first argmax of [assign==j] + sizes*0.01 (exact fp32 ops, no fma)
+    const float* sz = sizes + (size_t)img * L;
+    float* hm = hint_mask + (size_t)img * L;
+    for (int t = tid; t < L; t += 256) hm[t] = 0.f;
+    __syncthreads();
+    for (int j = 0; j < K; ++j) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int t = tid; t < L; t += 256) {
+            const float sc = __fadd_rn(assign[t] == j ? 1.f : 0.f, __fmul_rn(sz[t], 0.01f));
+            if (sc > bv) { bv = sc; bi = t; }   // ascending t: keeps the first maximum
+        }
+        red_v[tid] = bv; red_i[tid] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                const float ov = red_v[tid + s]; const int oi = red_i[tid + s];
+                if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) { red_v[tid] = ov; red_i[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { anchor_out[img * K + j] = red_i[0]; hm[red_i[0]] += 1.f; }
+        __syncthreads();
+    }
+    if (tid == 0 && info) { info[img * 2] = passes; info[img * 2 + 1] = s_events; }
+}
+
+__global__ void hint_mask_from_pos_kernel(const int32_t* pos, float* hint_mask, int n, int L, int K) {
+    const int img = blockIdx.x;
+    for (int t = threadIdx.x; t < L; t += blockDim.x) hint_mask[(size_t)img * L + t] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int j = 0; j < K; ++j) hint_mask[(size_t)img * L + pos[img * K + j]] = 1.f;
+}
+
+// ---- colour selection: one wave per token ---------------------------------------------------------------------
+// probabilities exactly as softmax: exp(x-max)/sum; order = (p desc, bin asc) = stable descending sort.
+__global__ __launch_bounds__(256) void select_colors_kernel(const float* __restrict__ logit, const float* __restrict__ q_to_ab,
+                                                            float* colors, int32_t* labels, int n, int L, int t_first,
+                                                            int t_count) {
+    const int lane = threadIdx.x & 63;
+    const int tokg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tokg >= n * L) return;
+    const int img = tokg / L, t = tokg - img * L;
+    const float* lp = logit + (size_t)img * N_VOCAB * L + t;
+    float p[5];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int b = lane + 64 * i;
+        p[i] = b < N_VOCAB ? lp[(size_t)b * L] : -INFINITY;
+        mx = fmaxf(mx, p[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { p[i] = (lane + 64 * i) < N_VOCAB ? expf(p[i] - mx) : 0.f; s += p[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) p[i] = (lane + 64 * i) < N_VOCAB ? p[i] / s : -1.f;
+    // top-10 by repeated wave arg-max (value desc, bin asc)
+    int top[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        float bv = -2.f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (p[i] > bv) { bv = p[i]; bi = lane + 64 * i; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        top[r] = bi;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (lane + 64 * i == bi) p[i] = -3.f;
+    }
+    if (lane != 0) return;
+    float ca[10], cb[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { ca[r] = q_to_ab[top[r] * 2] / 110.0f; cb[r] = q_to_ab[top[r] * 2 + 1] / 110.0f; }
+    // T=1: first candidate farthest from top-1; T=2: first candidate maximising d1 + dist to the T=1 pick
+    float d1[10]; int j1 = 0; float b1 = -1.f;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const float da = __fsub_rn(ca[r], ca[0]), db = __fsub_rn(cb[r], cb[0]);
+        d1[r] = sqrtf(__fadd_rn(__fmul_rn(da, da), __fmul_rn(db, db)));
+        if (d1[r] > b1) { b1 = d1[r]; j1 = r; }
+    }
+    int j2 = 0; float b2 = -1.f;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const float da = __fsub_rn(ca[r], ca[j1]), db = __fsub_rn(cb[r], cb[j1]);
+        const float d2 = __fadd_rn(d1[r], sqrtf(__fadd_rn(__fmul_rn(da, da), __fmul_rn(db, db))));
+        if (d2 > b2) { b2 = d2; j2 = r; }
+    }
+    const int pick[3] = {0, j1, j2};
+    for (int tt = 0; tt < t_count; ++tt) {
+        const int r = pick[t_first + tt];
+        // output image index: image-major [img][tt]
+        const size_t oi = (size_t)img * t_count + tt;
+        colors[(oi * 2 + 0) * L + t] = ca[r];
+        colors[(oi * 2 + 1) * L + t] = cb[r];
+        if (labels) labels[oi * L + t] = top[r];   // bin centres are their own nearest bin
+    }
+}
+
+__global__ void nearest_bin_kernel(const float* __restrict__ ab, const float* __restrict__ q_to_ab, int32_t* labels,
+                                   int n, int L) {
+    const long total = (long)n * L;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long img = i / L, t = i % L;
+        const float a = __fmul_rn(ab[(img * 2 + 0) * L + t], 110.f), b = __fmul_rn(ab[(img * 2 + 1) * L + t], 110.f);
+        float best = INFINITY; int bi = 0;
+        for (int q = 0; q < N_VOCAB; ++q) {
+            const float da = __fsub_rn(q_to_ab[q * 2], a), db = __fsub_rn(q_to_ab[q * 2 + 1], b);
+            const float d = __fadd_rn(__fmul_rn(da, da), __fmul_rn(db, db));
+            if (d < best) { best = d; bi = q; }
+        }
+        labels[i] = bi;
+    }
+}
+
+}  // namespace
+
+// workspace of one encoder stack: q,k,v (3 T 64), attn, LN1 out, two ping-pong layer outputs (4 T 64), ffn (T 256)
+size_t encoder_ws_bytes(int n, int l) { return (size_t)n * l * (3 * 64 + 4 * 64 + 256) * sizeof(float); }
+
+int launch_encoder_stack(const float* x, const float* pos, const float* weights, float* out, int n, int l, void* ws,
+                         hipStream_t s) {
+    const int T = n * l;
+    float* qkv = reinterpret_cast<float*>(ws);
+    float* att = qkv + (size_t)3 * T * 64;
+    float* xa = att + (size_t)T * 64;
+    float* pp[2] = {xa + (size_t)T * 64, xa + (size_t)2 * T * 64};
+    float* ffn = xa + (size_t)3 * T * 64;
+    const float* cur = x;
+    for (int layer = 0; layer < ENC_LAYERS; ++layer) {
+        const float* w = weights + (size_t)layer * ENC_LAYER_FLOATS;
+        const float* in_w = w;                 const float* in_b = in_w + 192 * 64;
+        const float* out_w = in_b + 192;       const float* out_b = out_w + 64 * 64;
+        const float* l1_w = out_b + 64;        const float* l1_b = l1_w + 256 * 64;
+        const float* l2_w = l1_b + 256;        const float* l2_b = l2_w + 64 * 256;
+        const float* n1_w = l2_b + 64;         const float* n1_b = n1_w + 64;
+        const float* n2_w = n1_b + 64;         const float* n2_b = n2_w + 64;
+        GemmArgs g{};
+        g.a_rep = 1; g.T = T; g.L = l; g.mask_rep = 1;
+        // q,k,v
+        g.A = cur; g.pos = pos; g.W = in_w; g.ldw = 64; g.bias = in_b; g.K = 64; g.O = 192; g.out = qkv;
+        g.q_scale = (float)std::sqrt(1.0 / 8.0);
+        int rc = launch_gemm<EPI_QKV>(g, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(attention_kernel, dim3(cdiv(l, 256), N_HEAD, n), dim3(256), 0, s, qkv, qkv + (size_t)T * 64,
+                           qkv + (size_t)2 * T * 64, att, l);
+        DISCO_LAUNCH_CHECK("attention_kernel");
+        // x1 = LN1(x + att Wo^T + bo)
+        g.A = att; g.pos = nullptr; g.W = out_w; g.ldw = 64; g.bias = out_b; g.K = 64; g.O = 64; g.out = xa;
+        g.res = cur; g.ln_w = n1_w; g.ln_b = n1_b;
+        if ((rc = launch_gemm<EPI_RES_LN>(g, s))) return rc;
+        // f = relu(x1 W1^T + b1)
+        g.A = xa; g.W = l1_w; g.ldw = 64; g.bias = l1_b; g.K = 64; g.O = 256; g.out = ffn; g.res = nullptr;
+        if ((rc = launch_gemm<EPI_RELU>(g, s))) return rc;
+        // x2 = LN2(x1 + f W2^T + b2)
+        float* dst = layer == ENC_LAYERS - 1 ? out : pp[layer & 1];
+        g.A = ffn; g.W = l2_w; g.ldw = 256; g.bias = l2_b; g.K = 256; g.O = 64; g.out = dst; g.res = xa;
+        g.ln_w = n2_w; g.ln_b = n2_b;
+        if ((rc = launch_gemm<EPI_RES_LN>(g, s))) return rc;
+        cur = dst;
+    }
+    return DISCO_OK;
+}
+
+void position_encoding_host(float* h_pos, int h, int w) {
+    // position_encoding.py:26-47 with num_pos_feats=32, normalize=True, scale=2*pi, temperature 1e4 (fp32 ops)
+    const float scale = (float)(2.0 * M_PI);
+    float dim_t[32];
+    for (int i = 0; i < 32; ++i) dim_t[i] = powf(10000.f, (2.f * (float)(i / 2)) / 32.f);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float* p = h_pos + ((size_t)y * w + x) * 64;
+            const float ye = (float)(y + 1) / ((float)h + 1e-6f) * scale;
+            const float xe = (float)(x + 1) / ((float)w + 1e-6f) * scale;
+            for (int i = 0; i < 32; ++i) {
+                const float ay = ye / dim_t[i], ax = xe / dim_t[i];
+                p[i] = (i & 1) ? cosf(ay) : sinf(ay);
+                p[32 + i] = (i & 1) ? cosf(ax) : sinf(ax);
+            }
+        }
+}
+
+int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s) {
+    GemmArgs g{};
+    g.A = x; g.a_rep = 1; g.W = w; g.ldw = 64; g.bias = nullptr; g.T = n * l; g.L = l; g.K = 64; g.O = N_VOCAB;
+    g.out = out_nchw; g.mask_rep = 1;
+    return launch_gemm<EPI_LOGIT>(g, s);
+}
+
+int launch_hint_embed(const float* src, int src_rep, const int32_t* labels, const float* mask, int mask_rep,
+                      const float* w_emb, float* out, int n, int l, hipStream_t s) {
+    GemmArgs g{};
+    g.A = src; g.a_rep = src_rep; g.W = w_emb; g.ldw = 64 + N_VOCAB + 1; g.bias = nullptr; g.T = n * l; g.L = l;
+    g.K = 64; g.O = 64; g.out = out; g.labels = labels; g.mask = mask; g.mask_rep = mask_rep;
+    return launch_gemm<EPI_HINT>(g, s);
+}
+
+int launch_select_colors(const float* logit_nchw, const float* q_to_ab, float* colors, int32_t* labels, int n, int l,
+                         int t_first, int t_count, hipStream_t s) {
+    if (t_first < 0 || t_first + t_count > 3) { set_error("select_colors: T range"); return DISCO_EINVAL; }
+    hipLaunchKernelGGL(select_colors_kernel, dim3(cdiv(n * l, 4)), dim3(256), 0, s, logit_nchw, q_to_ab, colors, labels,
+                       n, l, t_first, t_count);
+    DISCO_LAUNCH_CHECK("select_colors_kernel");
+    return DISCO_OK;
+}
+
+int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labels, int n, int l, hipStream_t s) {
+    hipLaunchKernelGGL(nearest_bin_kernel, dim3(cdiv(n * l, 256)), dim3(256), 0, s, ab_nchw, q_to_ab, labels, n, l);
+    DISCO_LAUNCH_CHECK("nearest_bin_kernel");
+    return DISCO_OK;
+}
+
+int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
+                          int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,
+                          int l, int k, hipStream_t s) {
+    if (k < 1 || k > KMAX) { set_error("kmeans: K=%d outside [1,%d]", k, KMAX); return DISCO_ESHAPE; }
+    if (k > l) { set_error("kmeans: K=%d larger than %d tokens", k, l); return DISCO_ESHAPE; }
+    hipLaunchKernelGGL(kmeans_anchor_kernel, dim3(n), dim3(256), 0, s, x, sizes, init_idx, fallback_rows, max_fallback,
+                       assign, anchor, hint_mask, info, l, k);
+    DISCO_LAUNCH_CHECK("kmeans_anchor_kernel");
+    return DISCO_OK;
+}
+
+int launch_hint_mask_from_pos(const int32_t* pos, float* hint_mask, int n, int l, int k, hipStream_t s) {
+    hipLaunchKernelGGL(hint_mask_from_pos_kernel, dim3(n), dim3(256), 0, s, pos, hint_mask, n, l, k);
+    DISCO_LAUNCH_CHECK("hint_mask_from_pos_kernel");
+    return DISCO_OK;
+}
+
+}  // namespace disco

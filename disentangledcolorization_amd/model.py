@@ -1,0 +1,244 @@
+"""Drop-in for the reference's `models/model.py::AnchorColorProb` backed by libdisco_hip.so.
+
+Same constructor, `forward(input_grays, input_colors, test_mode, sampled_T)` signature / 6-tuple of
+fp32 NCHW outputs and the same 461-tensor `state_dict` (strict `load_state_dict`), so it slots in
+under main/colorizer/inference.py:71-74,81,85,89,108-109.  Host code here is
+plumbing only: tensor allocation, checkpoint hand-over to the C ABI and the host-side random draws
+the reference makes (NumPy k-means initialisation, Python `random` hints, torch CPU fallback rows).
+All arithmetic runs in hand-written HIP kernels; without the library this module raises.
+
+Supported configuration = the only one inference.py can produce (inference.py:71-74,165):
+test_mode=True, enhanced=True, use_dense_pos=True, hint2regress=False, spix_pos=False,
+use_mask=False, sp_size=16, d_model=64.  Anything else raises NotImplementedError.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _ffi
+from .layout import state_dict_spec
+
+_PARAM_KINDS = {"conv_w", "sn_w", "deconv_w", "bias", "bn_w", "bn_b", "lin_w", "lin_b", "ln_w", "ln_b"}
+MAX_FALLBACK = 16  # empty-cluster draws handed to the kernel per image and call
+
+
+class _Node(nn.Module):
+    """Bare container so that dotted checkpoint keys map onto a module tree."""
+
+
+class AnchorColorProb(nn.Module):
+    def __init__(self, inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=False,
+                 learning_pos=False, n_clusters=8, random_hint=False, hint2regress=False, enhanced=False,
+                 use_mask=False, rank=0, precision="f16x3", init_weights=True):
+        super().__init__()
+        unsupported = []
+        if inChannel != 1: unsupported.append("inChannel=%r" % inChannel)
+        if outChannel != 313: unsupported.append("outChannel=%r" % outChannel)
+        if sp_size != 16: unsupported.append("sp_size=%r" % sp_size)
+        if d_model != 64: unsupported.append("d_model=%r" % d_model)
+        if not use_dense_pos: unsupported.append("use_dense_pos=False")
+        if spix_pos: unsupported.append("spix_pos=True")
+        if hint2regress: unsupported.append("hint2regress=True")
+        if not enhanced: unsupported.append("enhanced=False")
+        if use_mask: unsupported.append("use_mask=True")
+        if unsupported:
+            raise NotImplementedError("outside the MI355X hot path (SURVEY §8b): " + ", ".join(unsupported))
+        # learning_pos is accepted and ignored exactly like the reference (model.py:59 hard-codes is_learned=False)
+        self.sp_size, self.hint_num, self.random_hint = sp_size, int(n_clusters), bool(random_hint)
+        self.enhanced, self.hint2regress, self.spix_pos, self.use_token_mask = True, False, False, False
+        self.n_vocab = 313
+        self.rank = rank
+        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1}[precision]
+        self.sync_kmeans_events = True   # emulate the reference's torch.randint fallback draws (one sync per forward)
+        self._build_tree()
+        self._ctx = None
+        self._ctx_device = None
+        self._workspace = None
+        self._keep = None
+        if init_weights:
+            from .synth import synth_state_dict
+            super().load_state_dict(synth_state_dict(130), strict=True)
+
+    # ---- checkpoint layout ------------------------------------------------------------------------
+    def _build_tree(self):
+        for key, shape, dt, kind in state_dict_spec():
+            parts = key.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            t = torch.zeros(shape, dtype=getattr(torch, dt))
+            if kind in _PARAM_KINDS:
+                node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+            else:
+                node.register_buffer(parts[-1], t)
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        self._drop_ctx()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._drop_ctx()
+        return out
+
+    def _drop_ctx(self):
+        if getattr(self, "_ctx", None) is not None:
+            _ffi.lib().disco_destroy(self._ctx)
+        self._ctx = None
+
+    def __del__(self):
+        try:
+            self._drop_ctx()
+        except Exception:
+            pass
+
+    def set_train(self):
+        raise NotImplementedError("training is outside the MI355X hot path")
+
+    # ---- native context ---------------------------------------------------------------------------
+    def _context(self, device):
+        if self._ctx is not None and self._ctx_device == device:
+            return self._ctx
+        self._drop_ctx()
+        L = _ffi.lib()
+        opt = _ffi.Options(self.sp_size, self.hint_num, int(self.random_hint), self.precision)
+        ctx = C.c_void_p()
+        _ffi.check(L.disco_create(device.index if device.index is not None else torch.cuda.current_device(),
+                                  C.byref(opt), C.byref(ctx)))
+        try:
+            for key, t in self.state_dict().items():
+                shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                if t.dtype == torch.float32:
+                    h = t.detach().to("cpu").contiguous()
+                    _ffi.check(L.disco_load_tensor(ctx, key.encode(), C.c_void_p(h.data_ptr()), shape, t.dim()))
+                else:  # num_batches_tracked: shape only
+                    _ffi.check(L.disco_load_tensor(ctx, key.encode(), None, shape, t.dim()))
+            _ffi.check(L.disco_finalize(ctx))
+        except Exception:
+            L.disco_destroy(ctx)
+            raise
+        self._ctx, self._ctx_device = ctx, device
+        return ctx
+
+    def set_profiling(self, enabled=True):
+        self._profiling = bool(enabled)
+        if self._ctx is not None:
+            _ffi.lib().disco_set_profiling(self._ctx, int(enabled))
+
+    def profile(self):
+        """[(stage, ms, algorithmic flops)] of the last forward (after a device sync)."""
+        L = _ffi.lib()
+        out = []
+        for i in range(L.disco_profile_count(self._ctx)):
+            name, ms, fl = C.c_char_p(), C.c_float(), C.c_double()
+            _ffi.check(L.disco_profile_entry(self._ctx, i, C.byref(name), C.byref(ms), C.byref(fl)))
+            out.append((name.value.decode(), ms.value, fl.value))
+        return out
+
+    # ---- host-side random draws (same generators the reference consumes) ---------------------------
+    def _kmeans_init(self, n, l):
+        # clusterkit.py:107 — np.random.choice per image, legacy global RandomState, image order
+        return np.ascontiguousarray(
+            np.stack([np.random.choice(l, self.hint_num, replace=False) for _ in range(n)]).astype(np.int32))
+
+    def _random_hints(self, n, l):
+        # basic.py:42-47 — Python's global `random`
+        k = self.hint_num
+        return np.ascontiguousarray(
+            np.stack([np.asarray(random.sample(range(0, l), random.randint(k, k))) for _ in range(n)]).astype(np.int32))
+
+    @staticmethod
+    def _peek_randint(l, count):
+        """The next `count` values torch.randint(l,(1,)) would return, without consuming them."""
+        g = torch.Generator()
+        g.set_state(torch.get_rng_state())
+        return [int(torch.randint(l, (1,), generator=g)) for _ in range(count)]
+
+    # ---- forward ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_grays, input_colors, test_mode=False, sampled_T=0):
+        if not test_mode:
+            raise NotImplementedError("test_mode=False (training forward) is outside the MI355X hot path")
+        if not input_grays.is_cuda:
+            raise _ffi.DiscoError("AnchorColorProb needs CUDA/HIP tensors: the HIP path has no CPU fallback")
+        dev = input_grays.device
+        gray = input_grays.contiguous().float()
+        ab = input_colors.to(dev).contiguous().float()
+        n, _, H, W = gray.shape
+        if gray.shape[1] != 1 or ab.shape != (n, 2, H, W):
+            raise ValueError("expected gray (N,1,H,W) and ab (N,2,H,W)")
+        sp = self.sp_size
+        if H % sp or W % sp:
+            raise ValueError("H and W must be multiples of %d" % sp)
+        h, w = H // sp, W // sp
+        l = h * w
+        T = int(sampled_T)
+        rep = 3 if T > 0 else 1
+        n2 = n * rep
+        L = _ffi.lib()
+        with torch.cuda.device(dev):
+            ctx = self._context(dev)
+            L.disco_set_profiling(ctx, int(getattr(self, "_profiling", False)))
+            f32 = dict(device=dev, dtype=torch.float32)
+            pal = torch.empty(n, 313, h, w, **f32)
+            ref = torch.empty(n2, 313, h, w, **f32)
+            pred = torch.empty(n2, 2, H, W, **f32)
+            aff = torch.empty(n, 9, H, W, **f32)
+            spix = torch.empty(n2, 2, h, w, **f32)
+            mask = torch.empty(n, 1, h, w, **f32)
+            need = C.c_size_t()
+            _ffi.check(L.disco_workspace_bytes(ctx, n, H, W, T, C.byref(need)))
+            if self._workspace is None or self._workspace.numel() < need.value or self._workspace.device != dev:
+                self._workspace = None
+                self._workspace = torch.empty(need.value, device=dev, dtype=torch.uint8)
+            a = _ffi.ForwardArgs()
+            a.n, a.h, a.w, a.sampled_T = n, H, W, T
+            a.d_gray, a.d_ab = gray.data_ptr(), ab.data_ptr()
+            a.d_pal_logit, a.d_ref_logit, a.d_pred_colors = pal.data_ptr(), ref.data_ptr(), pred.data_ptr()
+            a.d_affinity, a.d_spix_colors, a.d_hint_mask = aff.data_ptr(), spix.data_ptr(), mask.data_ptr()
+            a.d_workspace, a.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
+            a.stream = torch.cuda.current_stream().cuda_stream
+            if self.random_hint:
+                hint_pos = self._random_hints(n, l)
+                a.h_hint_pos = hint_pos.ctypes.data
+                _ffi.check(L.disco_forward(ctx, C.byref(a)))
+                self._keep = (hint_pos,)
+            else:
+                init_idx = self._kmeans_init(n, l)
+                a.h_init_idx = init_idx.ctypes.data
+                a.max_fallback = MAX_FALLBACK
+                draws = self._peek_randint(l, MAX_FALLBACK * 2)
+                bases = [0] * n
+                events = np.zeros(n, np.int32)
+                for _ in range(n + 1):
+                    while len(draws) < max(bases) + MAX_FALLBACK:
+                        draws = self._peek_randint(l, len(draws) * 2)
+                    rows = np.ascontiguousarray(
+                        np.asarray([draws[b:b + MAX_FALLBACK] for b in bases], dtype=np.int32))
+                    a.h_fallback_rows = rows.ctypes.data
+                    a.h_kmeans_events = events.ctypes.data if self.sync_kmeans_events else None
+                    _ffi.check(L.disco_forward(ctx, C.byref(a)))
+                    if not self.sync_kmeans_events:
+                        break
+                    if int(events.max()) > MAX_FALLBACK:
+                        raise _ffi.DiscoError("k-means used more than %d empty-cluster draws" % MAX_FALLBACK)
+                    new_bases = [0] + list(np.cumsum(events)[:-1])
+                    if new_bases == bases:
+                        break
+                    bases = [int(b) for b in new_bases]   # an earlier image consumed draws: shift and redo
+                if self.sync_kmeans_events:
+                    for _ in range(int(events.sum())):      # consume what the reference would have consumed
+                        torch.randint(l, (1,))
+                self._keep = (init_idx, rows, events)
+        if rep > 1:
+            aff_out = aff.expand(rep, -1, -1, -1) if n == 1 else aff.repeat_interleave(rep, 0)
+            mask_out = mask.expand(rep, -1, -1, -1) if n == 1 else mask.repeat_interleave(rep, 0)
+        else:
+            aff_out, mask_out = aff, mask
+        return pal, ref, pred, aff_out, spix, mask_out

@@ -1,0 +1,183 @@
+/* disco_hip.h — C ABI of the MI355X-native DISCO colorization hot path (libdisco_hip.so).
+ *
+ * This is the boundary a native replacement of the reference's per-image forward exports
+ * (SURVEY §8b).  Entry points and the reference interface each one replaces (paths relative
+ * to the reference root):
+ *
+ *   disco_create / disco_destroy      model.AnchorColorProb(...) ctor        models/model.py:33-76
+ *                                     (main/colorizer/inference.py:71-74, .cuda() :81)
+ *   disco_load_tensor / disco_finalize  load_checkpoint -> load_state_dict(strict)
+ *                                     main/utils_train.py:140-151, inference.py:85
+ *   disco_forward                     AnchorColorProb.forward(gray, ab, True, sampled_T)
+ *                                     models/model.py:103-199, inference.py:108-109
+ *   disco_workspace_bytes             (allocation the reference leaves to torch's caching allocator)
+ *   disco_op_*                        the individual stock-PyTorch operators of SURVEY §2b
+ *                                     (K1..K16), exposed so each kernel can be parity-tested
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  `d_` arguments are DEVICE pointers on the
+ *     context's device, `h_` arguments are HOST pointers.
+ *   - ownership: the caller owns every input, output and workspace buffer.  The context owns
+ *     only the packed weights it allocated in disco_finalize.  Nothing is returned by
+ *     pointer-to-new-memory.
+ *   - errors: 0 on success, negative DISCO_E* otherwise; never exit()/throw across the ABI.
+ *     disco_last_error() gives a thread-local message for the last failing call.
+ *   - threading: launchers are asynchronous on the given hipStream_t (passed as void*), hold no
+ *     global mutable state and are re-entrant across streams/devices.  One context per device.
+ *     No hidden host synchronisation except in disco_forward's k-means fallback bookkeeping
+ *     (documented there) and disco_sync.
+ *   - host-side randomness (k-means initial rows, empty-cluster fallback rows, random hints) is
+ *     passed in as int32 index arrays so the native side is deterministic.
+ */
+#ifndef DISCO_HIP_H
+#define DISCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISCO_ABI_VERSION 1
+
+#define DISCO_OK 0
+#define DISCO_EINVAL (-1)       /* bad argument / null pointer */
+#define DISCO_ESHAPE (-2)       /* unsupported or inconsistent shape */
+#define DISCO_EUNSUPPORTED (-3) /* flag combination outside the hot path */
+#define DISCO_EHIP (-4)         /* HIP runtime error (message has hipGetErrorString) */
+#define DISCO_ESTATE (-5)       /* call order (e.g. forward before finalize, missing tensor) */
+#define DISCO_ENOMEM (-6)
+
+typedef struct disco_ctx disco_ctx;
+
+/* activation codes of the fused conv epilogue */
+#define DISCO_ACT_NONE 0
+#define DISCO_ACT_RELU 1
+#define DISCO_ACT_LRELU 2 /* LeakyReLU(slope) */
+#define DISCO_ACT_TANH 3
+
+/* conv precision modes */
+#define DISCO_PREC_F16X3 0 /* fp16 hi/lo split operands, 3 MFMA products, fp32 accumulate */
+#define DISCO_PREC_F16X1 1 /* fp16 hi operands only */
+
+int disco_abi_version(void);
+const char *disco_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------- */
+
+typedef struct disco_options {
+    int32_t sp_size;     /* superpixel size, 16 (inference.py:146) */
+    int32_t n_clusters;  /* K anchors (inference.py:156) */
+    int32_t random_hint; /* 1: anchors come from h_hint_pos instead of k-means (model.py:69) */
+    int32_t precision;   /* DISCO_PREC_* for the conv stacks */
+} disco_options;
+
+int disco_create(int device, const disco_options *opt, disco_ctx **out);
+int disco_destroy(disco_ctx *ctx);
+
+/* Hand one checkpoint tensor (state_dict entry `key`) to the context.
+ * h_data: host fp32 (int64 `num_batches_tracked` entries may be passed as NULL, they are unused). */
+int disco_load_tensor(disco_ctx *ctx, const char *key, const float *h_data, const int64_t *shape, int ndim);
+
+/* Strict check (every expected key present with the expected shape, no extras), then fold
+ * spectral-norm / batch-norm, split to fp16 hi/lo, pack into MFMA fragment order and upload. */
+int disco_finalize(disco_ctx *ctx);
+
+/* Number of state_dict entries the context expects and the i-th expected key/shape. */
+int disco_expected_tensors(void);
+int disco_expected_tensor(int i, const char **key, int64_t shape[4], int *ndim);
+
+/* ---- forward ------------------------------------------------------------------------- */
+
+typedef struct disco_forward_args {
+    int32_t n, h, w;          /* input batch; h, w multiples of sp_size */
+    int32_t sampled_T;        /* 0: top-1 anchors; >0: diverse (3 outputs per image); <0: GT anchor colours */
+    const float *d_gray;      /* (n,1,h,w) fp32 NCHW, L in [-1,1] */
+    const float *d_ab;        /* (n,2,h,w) fp32 NCHW, ab/110 */
+    const int32_t *h_init_idx;      /* (n,K) k-means initial rows (np.random.choice per image, clusterkit.py:107) */
+    const int32_t *h_fallback_rows; /* (n,max_fallback) rows for empty clusters (clusterkit.py:181-182); may be NULL */
+    int32_t max_fallback;
+    const int32_t *h_hint_pos;      /* (n,K) anchor tokens when random_hint (basic.py:42-47); else NULL */
+    /* outputs, fp32 NCHW, n' = n (or 3n when sampled_T>0, image-major [n][t]) */
+    float *d_pal_logit;   /* (n ,313,h/sp,w/sp) */
+    float *d_ref_logit;   /* (n',313,h/sp,w/sp) */
+    float *d_pred_colors; /* (n',2,h,w) */
+    float *d_affinity;    /* (n ,9,h,w)  (the reference returns the expanded n' copies; rows repeat) */
+    float *d_spix_colors; /* (n',2,h/sp,w/sp) */
+    float *d_hint_mask;   /* (n ,1,h/sp,w/sp) */
+    int32_t *h_kmeans_events; /* (n) out: empty-cluster events consumed per image; may be NULL */
+    void *d_workspace;
+    size_t workspace_bytes;
+    void *stream; /* hipStream_t */
+} disco_forward_args;
+
+int disco_workspace_bytes(disco_ctx *ctx, int n, int h, int w, int sampled_T, size_t *bytes);
+int disco_forward(disco_ctx *ctx, const disco_forward_args *a);
+int disco_sync(void *stream);
+
+/* Per-stage timing hooks used by bench.py: after a forward with profiling enabled the context
+ * holds hipEvent timings of named stages on the forward's stream. */
+int disco_set_profiling(disco_ctx *ctx, int enabled);
+int disco_profile_count(disco_ctx *ctx);
+int disco_profile_entry(disco_ctx *ctx, int i, const char **name, float *ms, double *flops);
+
+/* ---- operator-level entry points (parity tests, micro-benchmarks) ------------------- */
+
+/* Activation tensors are NHWC fp16 in two planes: hi at d_x, lo at d_x + plane_elems
+ * (x ~= hi + lo, |lo| <= ulp(hi)/2).  Convert from / to the reference's fp32 NCHW: */
+int disco_op_nchw_to_act(const float *d_src, void *d_dst, int n, int c, int h, int w, int c_pad, void *stream);
+int disco_op_act_to_nchw(const void *d_src, float *d_dst, int n, int c, int h, int w, int c_pad, void *stream);
+
+typedef struct disco_conv_desc {
+    int32_t n, h_in, w_in;     /* logical input size (after the optional x2 upsample-on-read) */
+    int32_t c_in0, c_in1;      /* channels of source 0 / source 1 (concat-on-read; c_in1 = 0 if unused) */
+    int32_t up0, up1;          /* 1: source is stored at half resolution, nearest-upsampled on read */
+    int32_t c_out, stride;     /* 3x3, pad 1, stride 1 or 2 */
+    int32_t act;               /* DISCO_ACT_* applied after bias (+residual) */
+    float slope;
+    int32_t precision;         /* DISCO_PREC_* */
+} disco_conv_desc;
+
+/* Pack an effective fp32 OIHW 3x3 weight (host) for the MFMA kernel; returns bytes needed when
+ * d_packed == NULL.  c_in = c_in0 + c_in1 (each a multiple of 16, or c_in0 arbitrary when c_in1 = 0). */
+int disco_op_conv3x3_pack(const float *h_w_oihw, int c_out, int c_in, void *d_packed, size_t *bytes);
+
+/* out = bn(act(conv3x3(cat(src0,src1)) + bias [+ res]));  bias/bn_scale/bn_shift: device fp32 (c_out) or NULL */
+int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d_src1, const void *d_packed_w,
+                     const float *d_bias, const float *d_bn_scale, const float *d_bn_shift, const void *d_res,
+                     void *d_out, void *stream);
+
+/* ConvTranspose2d 4x4 s2 p1 + bias + LeakyReLU(slope): h_w_iohw is the (c_in,c_out,4,4) fp32 weight */
+int disco_op_deconv4x4_pack(const float *h_w_iohw, int c_in, int c_out, void *d_packed, size_t *bytes);
+int disco_op_deconv4x4(const void *d_src, const void *d_packed_w, const float *d_bias, void *d_out, int n,
+                       int h_in, int w_in, int c_in, int c_out, float slope, int precision, void *stream);
+
+/* superpixel ops on fp32 NCHW tensors (basic.py:274-376) */
+int disco_op_poolfeat(const float *d_feat, const float *d_prob, float *d_pooled, float *d_conf, float *d_sizes,
+                      int n, int c, int h, int w, int sp, void *d_ws, size_t ws_bytes, void *stream);
+int disco_op_upfeat(const float *d_tok, const float *d_prob, float *d_out, int n, int c, int h, int w, int sp,
+                    void *stream);
+
+/* 6-layer encoder stack on (n,L,64) fp32 tokens; weights: the 12 tensors per layer concatenated
+ * in state_dict order (h_weights host fp32), pos (L,64) device */
+size_t disco_op_encoder_weight_floats(void);
+int disco_op_encoder_stack(const float *d_x, const float *d_pos, const float *d_weights, float *d_out, int n,
+                           int l, void *d_ws, size_t ws_bytes, void *stream);
+
+/* k-means (clusterkit.py:112-208) + anchors (anchor_gen.py:96-101) on (n,L,64) tokens */
+int disco_op_kmeans_anchors(const float *d_x, const float *d_sizes, const int32_t *d_init_idx,
+                            const int32_t *d_fallback_rows, int max_fallback, int32_t *d_assign,
+                            int32_t *d_anchor, float *d_hint_mask, int32_t *d_info, int n, int l, int k,
+                            void *stream);
+
+/* softmax(313) -> stable top-10 -> colour pick (anchor_gen.py:54-90) and nearest-bin label (basic.py:177-194) */
+int disco_op_select_colors(const float *d_logit_nchw, float *d_colors, int32_t *d_labels, int n, int hw, int t,
+                           void *stream);
+int disco_op_nearest_bin(const float *d_ab_nchw, int32_t *d_labels, int n, int hw, void *stream);
+int disco_op_position_encoding(float *d_pos, int h, int w, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCO_HIP_H */

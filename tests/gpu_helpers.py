@@ -1,0 +1,69 @@
+"""Helpers for the -m gpu parity tests: thin wrappers over the C ABI (through ctypes) so that the
+tests read like calls of the reference's operators."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from disentangledcolorization_amd import _ffi
+
+DEV = "cuda:0"
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_act(x, c_pad=None):
+    """fp32 NCHW (cpu or cuda) -> act tensor (2,N,H,W,c_pad) fp16 on the GPU (hi plane, lo plane)."""
+    x = x.to(DEV).float().contiguous()
+    n, c, h, w = x.shape
+    c_pad = c_pad or c
+    out = torch.empty(2, n, h, w, c_pad, device=DEV, dtype=torch.float16)
+    _ffi.check(_ffi.lib().disco_op_nchw_to_act(_ffi.ptr(x), _ffi.ptr(out), n, c, h, w, c_pad, stream()))
+    return out
+
+
+def from_act(a, c=None):
+    """act tensor (2,N,H,W,c_pad) -> fp32 NCHW on the GPU."""
+    _, n, h, w, c_pad = a.shape
+    c = c or c_pad
+    out = torch.empty(n, c, h, w, device=DEV, dtype=torch.float32)
+    _ffi.check(_ffi.lib().disco_op_act_to_nchw(_ffi.ptr(a), _ffi.ptr(out), n, c, h, w, c_pad, stream()))
+    return out
+
+
+def pack_conv(w):
+    """(Cout,Cin,3,3) fp32 cpu -> packed device buffer."""
+    w = w.detach().cpu().float().contiguous()
+    co, ci = w.shape[:2]
+    nbytes = C.c_size_t()
+    _ffi.check(_ffi.lib().disco_op_conv3x3_pack(None, co, ci, None, C.byref(nbytes)))
+    buf = torch.empty(nbytes.value, device=DEV, dtype=torch.uint8)
+    _ffi.check(_ffi.lib().disco_op_conv3x3_pack(_ffi.ptr(w), co, ci, _ffi.ptr(buf), C.byref(nbytes)))
+    return buf
+
+
+def conv3x3(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, act=_ffi.ACT_NONE, slope=0.0,
+            bn_scale=None, bn_shift=None, res=None, precision=_ffi.PREC_F16X3):
+    """HIP conv on act tensors; returns the act output.  src*: (2,N,h,w,C) fp16."""
+    n = src0.shape[1]
+    h_in = src0.shape[2] * (2 if up0 else 1)
+    w_in = src0.shape[3] * (2 if up0 else 1)
+    c0 = src0.shape[4]
+    c1 = src1.shape[4] if src1 is not None else 0
+    co = w.shape[0]
+    packed = pack_conv(w)
+    d = _ffi.ConvDesc(n, h_in, w_in, c0, c1, int(up0), int(up1), co, stride, act, slope, precision)
+    ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
+    out = torch.empty(2, n, ho, wo, co, device=DEV, dtype=torch.float16)
+    dv = lambda t: None if t is None else t.to(DEV).float().contiguous()
+    bias, bn_scale, bn_shift = dv(bias), dv(bn_scale), dv(bn_shift)
+    _ffi.check(_ffi.lib().disco_op_conv3x3(C.byref(d), _ffi.ptr(src0), _ffi.ptr(src1), _ffi.ptr(packed), _ffi.ptr(bias),
+                                          _ffi.ptr(bn_scale), _ffi.ptr(bn_shift), _ffi.ptr(res), _ffi.ptr(out), stream()))
+    torch.cuda.synchronize()
+    return out
+
+
+def max_err(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()

@@ -1,0 +1,93 @@
+"""CPU-side checks of the C-ABI library and the host mirror: the .so loads, exports every symbol
+include/disco_hip.h declares, agrees with layout.py on the checkpoint layout, and the drop-in
+class keeps the reference's state_dict contract.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from disentangledcolorization_amd import _ffi
+from disentangledcolorization_amd.layout import state_dict_spec
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from disentangledcolorization_amd.build import build
+    build(verbose=False)
+    return _ffi.lib()
+
+
+def test_header_symbols_exported(lib):
+    text = open(os.path.join(REPO, "include", "disco_hip.h")).read()
+    declared = set(re.findall(r"\b(disco_[a-z0-9_]+)\s*\(", text))
+    declared -= {"disco_ctx"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.disco_abi_version() == 1
+
+
+def test_native_layout_matches_python_spec(lib):
+    spec = state_dict_spec()
+    assert lib.disco_expected_tensors() == len(spec) == 461
+    for i, (key, shape, dt, kind) in enumerate(spec):
+        k, shp, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        assert lib.disco_expected_tensor(i, C.byref(k), shp, C.byref(nd)) == 0
+        assert k.value.decode() == key and tuple(shp[: nd.value]) == tuple(shape)
+    assert lib.disco_expected_tensor(461, C.byref(k), shp, C.byref(nd)) < 0
+    assert b"bad index" in lib.disco_last_error()
+
+
+def test_argument_errors_without_gpu(lib):
+    assert lib.disco_workspace_bytes(None, 1, 256, 256, 0, C.byref(C.c_size_t())) < 0
+    assert lib.disco_forward(None, None) < 0
+    assert lib.disco_op_conv3x3(None, None, None, None, None, None, None, None, None, None) < 0
+    nb = C.c_size_t()
+    assert lib.disco_op_conv3x3_pack(None, 64, 65, None, C.byref(nb)) == 0
+    assert nb.value == 2 * (80 // 16) * 9 * 2 * 1024     # 2 cout blocks x 5 cin chunks x 9 taps x {hi,lo} x 1 KiB
+
+
+def test_dropin_state_dict_contract(synth_sd):
+    from disentangledcolorization_amd.model import AnchorColorProb
+
+    m = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=False,
+                        learning_pos=False, n_clusters=8, random_hint=False, hint2regress=False, enhanced=True,
+                        init_weights=False)
+    keys = list(m.state_dict().keys())
+    assert keys == [k for k, *_ in state_dict_spec()]
+    m.load_state_dict(synth_sd)                       # strict, like utils_train.py:151
+    assert torch.equal(m.state_dict()["repnet.conv4_3.2.weight_orig"], synth_sd["repnet.conv4_3.2.weight_orig"])
+    bad = dict(synth_sd); bad.pop("mid_word_prj.weight")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    bad = dict(synth_sd); bad["extra.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    m.eval()
+    with pytest.raises(NotImplementedError):
+        AnchorColorProb(enhanced=False)
+    with pytest.raises(NotImplementedError):
+        AnchorColorProb(enhanced=True, hint2regress=True)
+
+
+def test_forward_refuses_cpu_tensors(synth_sd):
+    from disentangledcolorization_amd.model import AnchorColorProb
+
+    m = AnchorColorProb(enhanced=True, init_weights=False)
+    with pytest.raises(_ffi.DiscoError):
+        m(torch.zeros(1, 1, 32, 32), torch.zeros(1, 2, 32, 32), True, 0)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: no import / include / dlopen of it anywhere in the product package."""
+    pkg = os.path.join(REPO, "disentangledcolorization_amd")
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|#\s*include\s*[\"<].*oracle|.*import_module\(.*oracle|.*CDLL\(.*oracle)", re.M)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                assert not pat.search(open(os.path.join(root, f)).read()), f

@@ -1,0 +1,132 @@
+"""-m gpu: the full HIP forward (through the C ABI, behind the drop-in AnchorColorProb class) against
+(1) the golden outputs of the real reference and (2) the CPU oracle on the same seeded inputs.
+Tolerances (BASELINE.json north_star): max|ab| <= 1e-3 in fp32 ab/110 units, anchors bit-exact."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from disentangledcolorization_amd import synth  # noqa: E402
+from disentangledcolorization_amd.model import AnchorColorProb  # noqa: E402
+from oracle import disco_ref as R  # noqa: E402
+
+AB_TOL = 1e-3
+LOGIT_TOL = 1e-3
+
+
+def _err(a, b):
+    return (torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs().max().item()
+
+
+_models = {}
+
+
+def _model(sd, k, random_hint=False):
+    key = (k, random_hint)
+    if key not in _models:
+        m = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=False,
+                            learning_pos=False, n_clusters=k, random_hint=random_hint, hint2regress=False, enhanced=True,
+                            init_weights=False)
+        m.load_state_dict(sd)          # strict
+        _models[key] = m.cuda().eval()
+    return _models[key]
+
+
+def _seed(seed):
+    np.random.seed(seed); torch.manual_seed(seed); random.seed(seed)
+
+
+CASES = ["fwd_n2_256_k8", "fwd_diverse_256_k16", "fwd_n1_128x192_k8", "fwd_randhint_128_k16", "fwd_gt_128_k8",
+         "fwd_n1_512x768_k8"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference_golden(golden_dir, synth_sd, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, h, w, k, T, rh, iseed, seed = (int(v) for v in g["recipe"])
+    gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
+    m = _model(synth_sd, k, bool(rh))
+    _seed(seed)
+    pal, ref, pred, aff, spix, mask = m(gray.cuda(), ab.cuda(), True, T)
+    torch.cuda.synchronize()
+    assert pred.shape[0] == (3 * n if T > 0 else n) and pred.dtype == torch.float32
+    fs, as_ = (int(v) for v in g["strides"])
+    sub = int(g["sub"])
+    assert torch.equal(mask.cpu(), torch.from_numpy(g["hint_mask"])), "anchor positions differ from the reference"
+    if T >= 0:
+        assert torch.equal(spix.cpu(), torch.from_numpy(g["spix_colors"])), "anchor colours differ"
+    else:
+        assert _err(spix, g["spix_colors"]) < 1e-5
+    assert _err(aff[: g["aff_sub"].shape[0], :, ::as_, ::as_], g["aff_sub"]) < 1e-4
+    if sub == 1:
+        assert _err(pal, g["pal_logit"]) < LOGIT_TOL and _err(ref, g["ref_logit"]) < LOGIT_TOL
+        e = _err(pred, g["pred_colors"])
+    else:
+        assert _err(pal[:, ::sub], g["pal_logit"]) < LOGIT_TOL and _err(ref[:, ::sub], g["ref_logit"]) < LOGIT_TOL
+        e = _err(pred[:, :, ::sub, ::sub], g["pred_colors"])
+    print(f"{name}: max|ab - ab_ref| = {e:.3e}")
+    assert e <= AB_TOL
+
+
+def test_forward_matches_oracle_batch(synth_sd, q_to_ab):
+    """A fresh seeded batch the golden files do not contain: HIP vs CPU oracle, every output."""
+    n, k = 3, 8
+    gray, ab = synth.synth_inputs(n, 256, 256, seed=21, ab_scale=0.3)
+    m = _model(synth_sd, k)
+    _seed(7)
+    got = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    _seed(7)
+    want, info = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=k).forward(gray, ab, return_info=True)
+    assert torch.equal(got[5].cpu(), want[5]) and torch.equal(got[4].cpu(), want[4])
+    assert _err(got[3], want[3]) < 1e-4
+    assert _err(got[0], want[0]) < LOGIT_TOL and _err(got[1], want[1]) < LOGIT_TOL
+    assert _err(got[2], want[2]) <= AB_TOL
+
+
+def test_batch_invariance_at_bench_size(synth_sd):
+    """Full BASELINE config-2 size (N=64 @256x256): images are independent, so any image of the big batch must
+    equal the same image run alone (same k-means init rows), anchors included; K anchors per image."""
+    n, k = 64, 8
+    gray, ab = synth.synth_inputs(n, 256, 256, seed=5)
+    m = _model(synth_sd, k)
+    _seed(130)
+    pal, ref, pred, aff, spix, mask = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pred).all() and pred.abs().max() <= 1.0
+    assert torch.allclose(aff.sum(1), torch.ones_like(aff[:, 0]), atol=1e-5)
+    assert (mask.flatten(1).sum(1) == k).all()
+    for i in (0, 17, 63):
+        _seed(130)
+        for _ in range(i):                       # advance NumPy's stream past the earlier images' draws
+            np.random.choice(256, k, replace=False)
+        one = m(gray[i:i + 1].cuda(), ab[i:i + 1].cuda(), True, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(one[5][0], mask[i]) and torch.equal(one[2][0], pred[i])
+
+
+def test_precision_mode_f16x1_runs(synth_sd):
+    """The hi-only mode is a speed option; it must run and stay within fp16-class error of the x3 path."""
+    gray, ab = synth.synth_inputs(1, 128, 128, seed=3)
+    m3 = _model(synth_sd, 8)
+    m1 = AnchorColorProb(n_clusters=8, enhanced=True, precision="f16x1", init_weights=False)
+    m1.load_state_dict(synth_sd); m1 = m1.cuda().eval()
+    _seed(1); a = m3(gray.cuda(), ab.cuda(), True, 0)
+    _seed(1); b = m1(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    assert _err(a[3], b[3]) < 2e-2
+
+
+def test_error_paths(synth_sd):
+    m = _model(synth_sd, 8)
+    gray, ab = synth.synth_inputs(1, 64, 64)
+    with pytest.raises(NotImplementedError):
+        m(gray.cuda(), ab.cuda(), False, 0)
+    with pytest.raises(ValueError):
+        m(gray[:, :, :60].cuda(), ab[:, :, :60].cuda(), True, 0)
+    with pytest.raises(Exception):
+        m(gray[:, :, :32, :32].cuda(), ab[:, :, :32, :32].cuda(), True, 0)   # 4 tokens < 8 clusters

@@ -1,0 +1,217 @@
+"""-m gpu: every HIP operator against the CPU oracle (oracle/disco_ref.py, plain torch fp32 ops)
+and against the golden vectors captured from the reference (tests/golden/components.npz)."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from disentangledcolorization_amd import _ffi  # noqa: E402
+from oracle import disco_ref as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def H():
+    import gpu_helpers
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _ffi.lib()  # fails loudly if the extension is missing
+    return gpu_helpers
+
+
+@pytest.fixture(scope="module")
+def comp(golden_dir):
+    return np.load(os.path.join(golden_dir, "components.npz"))
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_layout_roundtrip(H):
+    x = torch.randn(2, 19, 7, 9, generator=g(0))
+    y = H.from_act(H.to_act(x, 32), 19).cpu()
+    assert H.max_err(x, y) < 2e-7 * 4   # hi+lo carries ~22 bits
+
+
+CONV_CASES = [
+    # cin, cout, h, w, stride, act, slope, bn, res
+    (16, 16, 32, 32, 1, _ffi.ACT_LRELU, 0.1, False, False),
+    (32, 64, 24, 40, 1, _ffi.ACT_RELU, 0.0, True, False),
+    (64, 64, 16, 16, 1, _ffi.ACT_NONE, 0.0, False, True),
+    (64, 128, 32, 64, 2, _ffi.ACT_LRELU, 0.2, True, False),
+    (128, 256, 16, 16, 2, _ffi.ACT_RELU, 0.0, False, False),
+    (256, 32, 8, 8, 1, _ffi.ACT_RELU, 0.0, False, True),
+    (48, 64, 17, 33, 1, _ffi.ACT_TANH, 0.0, False, False),   # ragged: partial tiles, odd sizes
+    (512, 512, 8, 8, 1, _ffi.ACT_LRELU, 0.2, True, False),
+]
+
+
+def _ref_conv(x, w, b, stride, act, slope, bn, res):
+    y = F.conv2d(x, w, b, stride=stride, padding=1)
+    if res is not None:
+        y = y + res
+    if act == _ffi.ACT_RELU: y = F.relu(y)
+    elif act == _ffi.ACT_LRELU: y = F.leaky_relu(y, slope)
+    elif act == _ffi.ACT_TANH: y = torch.tanh(y)
+    if bn is not None:
+        y = y * bn[0][None, :, None, None] + bn[1][None, :, None, None]
+    return y
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("prec", [_ffi.PREC_F16X3, _ffi.PREC_F16X1])
+def test_conv3x3_matches_torch(H, case, prec):
+    cin, cout, h, w, stride, act, slope, use_bn, use_res = case
+    gen = g(cin * 1000 + cout)
+    x = torch.randn(2, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    bn = (torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.1) if use_bn else None
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = torch.randn(2, cout, ho, wo, generator=gen) if use_res else None
+    want = _ref_conv(x, wt, b, stride, act, slope, bn, res)
+    got = H.from_act(H.conv3x3(H.to_act(x), wt, b, stride=stride, act=act, slope=slope,
+                               bn_scale=bn[0] if bn else None, bn_shift=bn[1] if bn else None,
+                               res=H.to_act(res) if use_res else None, precision=prec))
+    tol = 2e-5 if prec == _ffi.PREC_F16X3 else 2e-2   # fp32-class vs plain fp16 operands
+    assert H.max_err(got, want) < tol * max(1.0, want.abs().max().item())
+
+
+def test_conv3x3_upsample_and_concat_on_read(H):
+    gen = g(5)
+    a = torch.randn(2, 32, 12, 20, generator=gen)      # half-resolution source, nearest x2 on read
+    s = torch.randn(2, 16, 24, 40, generator=gen)      # full-resolution skip
+    wt = torch.randn(64, 48, 3, 3, generator=gen) * 0.05
+    b = torch.randn(64, generator=gen) * 0.1
+    want = F.relu(F.conv2d(torch.cat((R.up2(a), s), 1), wt, b, padding=1))
+    got = H.from_act(H.conv3x3(H.to_act(a), wt, b, src1=H.to_act(s), up0=True, act=_ffi.ACT_RELU))
+    assert H.max_err(got, want) < 2e-5 * want.abs().max().item()
+
+
+def test_deconv4x4(H):
+    gen = g(6)
+    x = torch.randn(2, 32, 9, 11, generator=gen)
+    wt = torch.randn(32, 16, 4, 4, generator=gen) * 0.1
+    b = torch.randn(16, generator=gen) * 0.1
+    want = F.leaky_relu(F.conv_transpose2d(x, wt, b, stride=2, padding=1), 0.1)
+    L = _ffi.lib()
+    nb = C.c_size_t()
+    _ffi.check(L.disco_op_deconv4x4_pack(None, 32, 16, None, C.byref(nb)))
+    packed = torch.empty(nb.value, device=H.DEV, dtype=torch.uint8)
+    _ffi.check(L.disco_op_deconv4x4_pack(_ffi.ptr(wt.contiguous()), 32, 16, _ffi.ptr(packed), C.byref(nb)))
+    xa = H.to_act(x)
+    out = torch.empty(2, 2, 18, 22, 16, device=H.DEV, dtype=torch.float16)
+    bd = b.to(H.DEV)
+    _ffi.check(L.disco_op_deconv4x4(_ffi.ptr(xa), _ffi.ptr(packed), _ffi.ptr(bd), _ffi.ptr(out), 2, 9, 11, 32, 16, 0.1,
+                                    0, H.stream()))
+    assert H.max_err(H.from_act(out), want) < 2e-5 * want.abs().max().item()
+
+
+def test_pool_unpool_sizes_golden(H, comp):
+    prob = torch.from_numpy(comp["pool_prob"]).to(H.DEV)
+    feat = torch.from_numpy(comp["pool_feat"]).to(H.DEV)
+    n, c, hh, ww = feat.shape
+    h, w = hh // 16, ww // 16
+    L = _ffi.lib()
+    pooled = torch.empty(n, c, h, w, device=H.DEV); conf = torch.empty(n, 1, h, w, device=H.DEV)
+    sizes = torch.empty(n, h * w, device=H.DEV)
+    ws = torch.empty(n * h * w * 9 * (c + 2) * 4, device=H.DEV, dtype=torch.uint8)
+    _ffi.check(L.disco_op_poolfeat(_ffi.ptr(feat), _ffi.ptr(prob), _ffi.ptr(pooled), _ffi.ptr(conf), _ffi.ptr(sizes), n, c,
+                                   hh, ww, 16, _ffi.ptr(ws), ws.numel(), H.stream()))
+    assert H.max_err(pooled, torch.from_numpy(comp["pool_out"])) < 1e-5
+    assert H.max_err(conf, torch.from_numpy(comp["pool_conf"])) < 1e-6
+    assert torch.equal(sizes.cpu().reshape(n, 1, h, w), torch.from_numpy(comp["spix_size"]))   # exact
+    tok = torch.from_numpy(comp["up_tok"]).to(H.DEV)
+    out = torch.empty(n, tok.shape[1], hh, ww, device=H.DEV)
+    _ffi.check(L.disco_op_upfeat(_ffi.ptr(tok), _ffi.ptr(prob), _ffi.ptr(out), n, tok.shape[1], h, w, 16, H.stream()))
+    assert H.max_err(out, torch.from_numpy(comp["up_out"])) < 1e-6
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (32, 48), (8, 12)])
+def test_position_encoding_golden(H, comp, hw):
+    h, w = hw
+    pos = torch.empty(h * w, 64, device=H.DEV)
+    _ffi.check(_ffi.lib().disco_op_position_encoding(_ffi.ptr(pos), h, w, H.stream()))
+    want = torch.from_numpy(comp["pos_%dx%d" % hw]).flatten(1).t()
+    assert H.max_err(pos, want) < 2e-6
+
+
+def _encoder_weights(sd, path):
+    keys = ["self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+            "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm1.weight", "norm1.bias",
+            "norm2.weight", "norm2.bias"]
+    return torch.cat([sd[f"{path}.layers.{l}.{k}"].reshape(-1) for l in range(6) for k in keys])
+
+
+@pytest.mark.parametrize("n,hw", [(3, (16, 16)), (1, (8, 12)), (1, (32, 48))])
+def test_encoder_stack_matches_oracle(H, synth_sd, n, hw):
+    h, w = hw
+    l = h * w
+    x = torch.randn(n, l, 64, generator=g(l))
+    pos = R.position_encoding(h, w).flatten(1).t().contiguous()
+    want = R.encoder_stack(synth_sd, "wildpath", x, pos[None].expand(n, -1, -1))
+    wts = _encoder_weights(synth_sd, "wildpath").to(H.DEV)
+    assert wts.numel() == _ffi.lib().disco_op_encoder_weight_floats()
+    xd, pd = x.to(H.DEV), pos.to(H.DEV)
+    out = torch.empty_like(xd)
+    ws = torch.empty(n * l * 704 * 4, device=H.DEV, dtype=torch.uint8)
+    _ffi.check(_ffi.lib().disco_op_encoder_stack(_ffi.ptr(xd), _ffi.ptr(pd), _ffi.ptr(wts), _ffi.ptr(out), n, l,
+                                                 _ffi.ptr(ws), ws.numel(), H.stream()))
+    assert H.max_err(out, want) < 2e-5
+
+
+def _kmeans_gpu(H, x, sizes, init, fallback, k):
+    n, l, _ = x.shape
+    xd, sd_ = x.to(H.DEV).contiguous(), sizes.to(H.DEV).contiguous()
+    idx = torch.as_tensor(np.asarray(init), dtype=torch.int32).to(H.DEV)
+    fb = torch.as_tensor(np.asarray(fallback), dtype=torch.int32).to(H.DEV) if fallback is not None else None
+    mf = fb.shape[1] if fb is not None else 0
+    assign = torch.empty(n, l, dtype=torch.int32, device=H.DEV); anchor = torch.empty(n, k, dtype=torch.int32, device=H.DEV)
+    mask = torch.empty(n, l, device=H.DEV); info = torch.empty(n, 2, dtype=torch.int32, device=H.DEV)
+    _ffi.check(_ffi.lib().disco_op_kmeans_anchors(_ffi.ptr(xd), _ffi.ptr(sd_), _ffi.ptr(idx), _ffi.ptr(fb), mf, _ffi.ptr(assign),
+                                                  _ffi.ptr(anchor), _ffi.ptr(mask), _ffi.ptr(info), n, l, k, H.stream()))
+    torch.cuda.synchronize()
+    return assign.cpu().long(), anchor.cpu().long(), mask.cpu(), info.cpu()
+
+
+def test_kmeans_anchors_golden_and_oracle(H, comp):
+    x = torch.from_numpy(comp["km_x"])            # (4,256,64); the last one has 200 identical rows
+    init = comp["km_init"]
+    sizes = (torch.randint(0, 512, (4, 256), generator=g(3)).float() / 256.0)
+    fallback = torch.randint(0, 256, (4, 16), generator=g(4))
+    want_assign, want_anchor, want_mask, events = [], [], [], []
+    for i in range(4):
+        a, passes, ev = R.kmeans_one(x[i], init[i], 8, fallback_rows=[int(v) for v in fallback[i]])
+        want_assign.append(a); events.append(ev)
+    want_assign = torch.stack(want_assign)
+    want_anchor, want_mask = R.anchors_from_clusters(want_assign, sizes, 8)
+    assign, anchor, mask, info = _kmeans_gpu(H, x, sizes, init, fallback.numpy(), 8)
+    assert torch.equal(assign, want_assign)
+    assert torch.equal(anchor, want_anchor)
+    assert torch.equal(mask, want_mask)
+    assert info[:, 1].tolist() == events and events[3] > 0
+    # first three (no fallback draws involved) are also the reference's own assignments
+    assert np.array_equal(assign[:3].numpy(), comp["km_ids"][:3].astype(np.int64))
+
+
+@pytest.mark.parametrize("t", [0, 1, 2])
+def test_select_colors_golden(H, comp, t):
+    prob = torch.from_numpy(comp["samp_prob"])
+    n, _, h, w = prob.shape
+    logit = torch.log(prob).to(H.DEV).contiguous()      # softmax(log p) == p up to rounding
+    colors = torch.empty(n, 2, h * w, device=H.DEV); labels = torch.empty(n, h * w, dtype=torch.int32, device=H.DEV)
+    _ffi.check(_ffi.lib().disco_op_select_colors(_ffi.ptr(logit), _ffi.ptr(colors), _ffi.ptr(labels), n, h * w, t, H.stream()))
+    assert torch.equal(colors.cpu().reshape(n, 2, h, w), torch.from_numpy(comp["samp_T%d" % t]))
+
+
+def test_nearest_bin_golden(H, comp):
+    ab = torch.from_numpy(comp["enc_ab"]).to(H.DEV)
+    n, _, h, w = ab.shape
+    labels = torch.empty(n, h * w, dtype=torch.int32, device=H.DEV)
+    _ffi.check(_ffi.lib().disco_op_nearest_bin(_ffi.ptr(ab), _ffi.ptr(labels), n, h * w, H.stream()))
+    assert torch.equal(labels.cpu().long().reshape(n, 1, h, w), torch.from_numpy(comp["enc_label"]))
