@@ -164,8 +164,10 @@ struct disco_ctx {
     float* d_enc[2] = {nullptr, nullptr};
     float* d_mid_w = nullptr; float* d_emb_w = nullptr; float* d_trg_w = nullptr; float* d_q_to_ab = nullptr;
     std::map<std::pair<int, int>, float*> pos_cache;
-    bool profiling = false;
+    int profiling = 0;
     std::vector<ProfEntry> prof;
+    struct ConvProf { hipEvent_t e0, e1; double flops; };
+    std::vector<ConvProf> conv_prof;
     std::vector<std::pair<std::string, float>> prof_ms;
     std::vector<double> prof_flops;
 };
@@ -382,7 +384,14 @@ struct Plan {
         ca.out = out.p; ca.out_plane = (long)out.plane;
         ca.act = actc; ca.slope = slope; ca.precision = c->opt.precision;
         if (in0.c + (in1 ? in1->c : 0) != L.c_in_pad) { set_error("conv %s: input channels %d != %d", key.c_str(), in0.c + (in1 ? in1->c : 0), L.c_in_pad); rc = DISCO_ESHAPE; return out; }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = c->profiling >= 2 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        if (timed) hipEventRecord(e0, s);
         rc = launch_conv3x3(ca, s);
+        if (timed) {
+            hipEventRecord(e1, s);
+            c->conv_prof.push_back({e0, e1, 2.0 * 9.0 * L.c_in * L.c_out * (double)ho * wo * in0.n});
+        }
         return out;
     }
     Act deconv(const std::string& key, const Act& in, float slope) {
@@ -411,7 +420,12 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     const int rep = a->sampled_T > 0 ? 3 : 1, n2 = n * rep;
     const double px = (double)n * H * W;
     hipStream_t s = P.s;
-    if (!dry) { for (auto& e : c->prof) hipEventDestroy(e.ev); c->prof.clear(); }
+    if (!dry) {
+        for (auto& e : c->prof) hipEventDestroy(e.ev);
+        c->prof.clear();
+        for (auto& e : c->conv_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+        c->conv_prof.clear();
+    }
     P.mark("start");
 
     // ---- a1 SpixelNet (network.py:293-313) -------------------------------------------------------------------
@@ -633,6 +647,7 @@ int disco_destroy(disco_ctx* c) {
     if (!c) return DISCO_OK;
     hipSetDevice(c->device);
     for (auto& e : c->prof) hipEventDestroy(e.ev);
+    for (auto& e : c->conv_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
     for (void* p : c->allocs) hipFree(p);
     delete c;
     return DISCO_OK;
@@ -752,9 +767,20 @@ int disco_sync(void* stream) {
     return DISCO_OK;
 }
 
-int disco_set_profiling(disco_ctx* c, int enabled) {
+int disco_set_profiling(disco_ctx* c, int level) {
     if (!c) return DISCO_EINVAL;
-    c->profiling = enabled != 0;
+    c->profiling = level;
+    return DISCO_OK;
+}
+
+int disco_profile_conv(disco_ctx* c, int* launches, float* total_ms, double* total_flops) {
+    if (!c || !launches || !total_ms || !total_flops) { set_error("null argument"); return DISCO_EINVAL; }
+    *launches = 0; *total_ms = 0.f; *total_flops = 0.0;
+    for (auto& e : c->conv_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
+        *launches += 1; *total_ms += ms; *total_flops += e.flops;
+    }
     return DISCO_OK;
 }
 

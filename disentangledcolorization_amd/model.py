@@ -22,7 +22,7 @@ from . import _ffi
 from .layout import state_dict_spec
 
 _PARAM_KINDS = {"conv_w", "sn_w", "deconv_w", "bias", "bn_w", "bn_b", "lin_w", "lin_b", "ln_w", "ln_b"}
-MAX_FALLBACK = 16  # empty-cluster draws handed to the kernel per image and call
+KMEANS_ITERS = 20  # clusterkit.py:43 iter_limit -> at most (K-1)*20 empty-cluster draws per image
 
 
 class _Node(nn.Module):
@@ -126,10 +126,17 @@ class AnchorColorProb(nn.Module):
         self._ctx, self._ctx_device = ctx, device
         return ctx
 
-    def set_profiling(self, enabled=True):
-        self._profiling = bool(enabled)
+    def set_profiling(self, level=1):
+        """0 off, 1 per-stage hipEvents, 2 additionally an event pair around every MFMA conv launch."""
+        self._profiling = int(level)
         if self._ctx is not None:
-            _ffi.lib().disco_set_profiling(self._ctx, int(enabled))
+            _ffi.lib().disco_set_profiling(self._ctx, int(level))
+
+    def conv_profile(self):
+        """(launches, total ms, total algorithmic FLOPs) of the conv3x3_mfma launches of the last forward."""
+        n, ms, fl = C.c_int(), C.c_float(), C.c_double()
+        _ffi.check(_ffi.lib().disco_profile_conv(self._ctx, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
 
     def profile(self):
         """[(stage, ms, algorithmic flops)] of the last forward (after a device sync)."""
@@ -161,8 +168,14 @@ class AnchorColorProb(nn.Module):
         return [int(torch.randint(l, (1,), generator=g)) for _ in range(count)]
 
     # ---- forward ----------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, input_grays, input_colors, test_mode=False, sampled_T=0):
+        return self.forward_with_draws(input_grays, input_colors, test_mode, sampled_T)
+
+    @torch.no_grad()
+    def forward_with_draws(self, input_grays, input_colors, test_mode=True, sampled_T=0, init_idx=None, hint_pos=None):
+        """forward() with the host-side draws supplied by the caller (runner.py draws them once for the
+        global batch so that results do not depend on the number of GPUs): init_idx (n,K) k-means rows,
+        hint_pos (n,K) random-hint tokens.  None = draw from the global generators like the reference."""
         if not test_mode:
             raise NotImplementedError("test_mode=False (training forward) is outside the MI355X hot path")
         if not input_grays.is_cuda:
@@ -184,7 +197,7 @@ class AnchorColorProb(nn.Module):
         L = _ffi.lib()
         with torch.cuda.device(dev):
             ctx = self._context(dev)
-            L.disco_set_profiling(ctx, int(getattr(self, "_profiling", False)))
+            L.disco_set_profiling(ctx, int(getattr(self, "_profiling", 0)))
             f32 = dict(device=dev, dtype=torch.float32)
             pal = torch.empty(n, 313, h, w, **f32)
             ref = torch.empty(n2, 313, h, w, **f32)
@@ -205,12 +218,15 @@ class AnchorColorProb(nn.Module):
             a.d_workspace, a.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
             a.stream = torch.cuda.current_stream().cuda_stream
             if self.random_hint:
-                hint_pos = self._random_hints(n, l)
+                hint_pos = self._random_hints(n, l) if hint_pos is None else np.ascontiguousarray(hint_pos, dtype=np.int32)
                 a.h_hint_pos = hint_pos.ctypes.data
                 _ffi.check(L.disco_forward(ctx, C.byref(a)))
                 self._keep = (hint_pos,)
             else:
-                init_idx = self._kmeans_init(n, l)
+                init_idx = self._kmeans_init(n, l) if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.int32)
+                if init_idx.shape != (n, self.hint_num):
+                    raise ValueError("init_idx must be (n, n_clusters)")
+                MAX_FALLBACK = KMEANS_ITERS * self.hint_num
                 a.h_init_idx = init_idx.ctypes.data
                 a.max_fallback = MAX_FALLBACK
                 draws = self._peek_randint(l, MAX_FALLBACK * 2)

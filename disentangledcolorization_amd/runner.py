@@ -1,0 +1,85 @@
+"""Batch-sharded multi-GPU colorization: one process per GPU, one RCCL all-gather of the results.
+
+The reference has no batched/multi-GPU inference (inference.py:93 loops over files with batch 1;
+nn.DataParallel :76-82).  Every image is independent end to end, so the global batch
+is cut into contiguous shards, each rank runs the HIP forward on its shard with the full weights,
+and `pred_colors` (+ `hint_mask`) are all-gathered over xGMI (torch.distributed backend "nccl" =
+RCCL on ROCm; "gloo" in the CPU tests).  Host-side draws (k-means initial rows, random hints) are
+made once for the GLOBAL batch in image order from the same generators the reference consumes, and
+sliced per rank, so results do not depend on the number of GPUs.
+"""
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_global, world, rank):
+    """Contiguous [lo, hi) of `rank`; the first n_global % world ranks hold one extra image."""
+    base, extra = divmod(n_global, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def global_draws(n_global, n_tokens, k, random_hint):
+    """(init_idx, hint_pos) for the whole batch, image order — clusterkit.py:107 / basic.py:42-47."""
+    if random_hint:
+        pos = np.stack([np.asarray(random.sample(range(0, n_tokens), random.randint(k, k))) for _ in range(n_global)])
+        return None, pos.astype(np.int32)
+    idx = np.stack([np.random.choice(n_tokens, k, replace=False) for _ in range(n_global)])
+    return idx.astype(np.int32), None
+
+
+class ShardedColorizer:
+    """forward_fn(gray_local, ab_local, sampled_T, init_idx_local, hint_pos_local) -> 6-tuple like the model.
+
+    For the product path forward_fn = AnchorColorProb.forward_with_draws (HIP); tests inject a CPU function.
+    """
+
+    def __init__(self, forward_fn, n_clusters=8, random_hint=False, sp_size=16, group=None):
+        self.forward_fn = forward_fn
+        self.k, self.random_hint, self.sp = n_clusters, random_hint, sp_size
+        self.group = group
+
+    @classmethod
+    def from_model(cls, model, group=None):
+        fn = lambda g, a, T, idx, pos: model.forward_with_draws(g, a, True, T, init_idx=idx, hint_pos=pos)
+        return cls(fn, model.hint_num, model.random_hint, model.sp_size, group)
+
+    def world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group), dist.get_rank(self.group)
+        return 1, 0
+
+    def colorize(self, gray_local, ab_local, n_global, sampled_T=0, gather=True):
+        """gray_local/ab_local: this rank's shard (shard_bounds order).  Returns (pred_colors, hint_mask) of the
+        GLOBAL batch on every rank when gather=True (one all-gather each), else the local shard."""
+        world, rank = self.world()
+        lo, hi = shard_bounds(n_global, world, rank)
+        if gray_local.shape[0] != hi - lo:
+            raise ValueError("rank %d expects %d images, got %d" % (rank, hi - lo, gray_local.shape[0]))
+        h, w = gray_local.shape[2] // self.sp, gray_local.shape[3] // self.sp
+        idx, pos = global_draws(n_global, h * w, self.k, self.random_hint)
+        out = self.forward_fn(gray_local, ab_local, sampled_T,
+                              None if idx is None else idx[lo:hi], None if pos is None else pos[lo:hi])
+        pred, mask = out[2], out[5]
+        if not gather or world == 1:
+            return pred, mask
+        return self._all_gather(pred, n_global, world), self._all_gather(mask, n_global, world)
+
+    def _all_gather(self, local, n_global, world):
+        counts = [shard_bounds(n_global, world, r)[1] - shard_bounds(n_global, world, r)[0] for r in range(world)]
+        mine = counts[self.world()[1]]
+        rep = local.shape[0] // mine if mine else 1          # 3 outputs per image in diverse mode
+        per = [c * rep for c in counts]
+        if len(set(per)) == 1:   # equal shards: one fused collective
+            out = local.new_empty((per[0] * world,) + tuple(local.shape[1:]))
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+            return out
+        mx = max(per)            # ragged: pad to the largest shard
+        pad = local.new_zeros((mx,) + tuple(local.shape[1:]))
+        pad[: local.shape[0]] = local
+        out = local.new_empty((mx * world,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        return torch.cat([out[r * mx: r * mx + per[r]] for r in range(world)], 0)

@@ -118,9 +118,12 @@ int disco_sync(void *stream);
 
 /* Per-stage timing hooks used by bench.py: after a forward with profiling enabled the context
  * holds hipEvent timings of named stages on the forward's stream. */
-int disco_set_profiling(disco_ctx *ctx, int enabled);
+int disco_set_profiling(disco_ctx *ctx, int level); /* 0 off, 1 stages, 2 stages + every MFMA conv launch */
 int disco_profile_count(disco_ctx *ctx);
 int disco_profile_entry(disco_ctx *ctx, int i, const char **name, float *ms, double *flops);
+/* level 2: number of conv3x3_mfma launches of the last forward, their summed duration (hipEvent pairs around
+ * each launch on the forward's stream) and their summed algorithmic FLOPs (2*9*Cin*Cout*Hout*Wout*N). */
+int disco_profile_conv(disco_ctx *ctx, int *launches, float *total_ms, double *total_flops);
 
 /* ---- operator-level entry points (parity tests, micro-benchmarks) ------------------- */
 

@@ -1,0 +1,82 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard a batch, run a forward, all-gather — results must equal
+the single-process run bit for bit (anchors included).  The forward here is the CPU oracle's token path on
+precomputed features (the HIP forward needs a GPU); what is under test is runner.py's sharding, global draws and
+the collective."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from disentangledcolorization_amd.runner import ShardedColorizer, global_draws, shard_bounds  # noqa: E402
+
+
+def _fake_forward(gray, ab, T, idx, pos):
+    """Cheap deterministic stand-in with the model's output contract; depends on the per-image draws."""
+    n, _, H, W = gray.shape
+    h, w = H // 16, W // 16
+    base = gray.mean(dim=(1, 2, 3)).reshape(n, 1, 1, 1)
+    d = torch.as_tensor(idx if idx is not None else pos, dtype=torch.float32)
+    pred = torch.tanh(gray.repeat(1, 2, 1, 1) * 0.5 + d.sum(1).reshape(n, 1, 1, 1) * 1e-3)
+    mask = torch.zeros(n, h * w)
+    mask.scatter_add_(1, torch.as_tensor(idx if idx is not None else pos, dtype=torch.long), torch.ones(n, d.shape[1]))
+    return (None, None, pred, None, None, mask.reshape(n, 1, h, w))
+
+
+def _worker(rank, world, port, n_global, random_hint, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
+    np.random.seed(130); random.seed(130)
+    g = torch.Generator().manual_seed(1)
+    gray = torch.rand(n_global, 1, 64, 64, generator=g) * 2 - 1
+    ab = torch.zeros(n_global, 2, 64, 64)
+    lo, hi = shard_bounds(n_global, world, rank)
+    sc = ShardedColorizer(_fake_forward, n_clusters=4, random_hint=random_hint)
+    pred, mask = sc.colorize(gray[lo:hi], ab[lo:hi], n_global)
+    q.put((rank, pred.numpy(), mask.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global,random_hint", [(6, False), (5, False), (4, True)])
+def test_two_rank_gloo_equals_single_process(n_global, random_hint):
+    import random
+    np.random.seed(130); random.seed(130)
+    g = torch.Generator().manual_seed(1)
+    gray = torch.rand(n_global, 1, 64, 64, generator=g) * 2 - 1
+    ab = torch.zeros(n_global, 2, 64, 64)
+    want_pred, want_mask = ShardedColorizer(_fake_forward, 4, random_hint).colorize(gray, ab, n_global)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_global, random_hint, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs: p.join(timeout=60)
+    for rank, pred, mask in got:
+        assert np.array_equal(pred, want_pred.numpy()), rank
+        assert np.array_equal(mask, want_mask.numpy()), rank
+
+
+def test_shard_bounds_cover_batch():
+    for n in (1, 7, 64, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_global_draws_follow_reference_stream():
+    np.random.seed(130)
+    idx, _ = global_draws(3, 256, 8, False)
+    np.random.seed(130)
+    want = np.stack([np.random.choice(256, 8, replace=False) for _ in range(3)])
+    assert np.array_equal(idx, want)

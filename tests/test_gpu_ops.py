@@ -183,7 +183,7 @@ def test_kmeans_anchors_golden_and_oracle(H, comp):
     x = torch.from_numpy(comp["km_x"])            # (4,256,64); the last one has 200 identical rows
     init = comp["km_init"]
     sizes = (torch.randint(0, 512, (4, 256), generator=g(3)).float() / 256.0)
-    fallback = torch.randint(0, 256, (4, 16), generator=g(4))
+    fallback = torch.randint(0, 256, (4, 160), generator=g(4))   # <= (K-1)*20 events
     want_assign, want_anchor, want_mask, events = [], [], [], []
     for i in range(4):
         a, passes, ev = R.kmeans_one(x[i], init[i], 8, fallback_rows=[int(v) for v in fallback[i]])
