@@ -509,7 +509,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     // ---- a8/a9 anchors (model.py:141) ---------------------------------------------------------------------------
     int32_t* d_idx = (int32_t*)P.raw((size_t)n * K * 4);
     const int mf = a->max_fallback > 0 && a->h_fallback_rows ? a->max_fallback : 0;
-    int32_t* d_fb = (int32_t*)P.raw((size_t)n * std::max(mf, 1) * 4);
+    int32_t* d_fb = (int32_t*)P.raw((size_t)n * K * 20 * 4);   // fixed upper bound: (K-1)*20 draws per image at most
     int32_t* d_assign = (int32_t*)P.raw((size_t)n * L * 4);
     int32_t* d_anchor = (int32_t*)P.raw((size_t)n * K * 4);
     int32_t* d_info = (int32_t*)P.raw((size_t)n * 2 * 4);
@@ -606,6 +606,7 @@ int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
     const int sp = c->opt.sp_size;
     if (a->n < 1 || a->h < sp || a->w < sp || a->h % sp || a->w % sp) { set_error("bad input size %dx%dx%d (multiples of %d)", a->n, a->h, a->w, sp); return DISCO_ESHAPE; }
     if ((a->h / sp) * (a->w / sp) < c->opt.n_clusters) { set_error("fewer tokens than clusters"); return DISCO_ESHAPE; }
+    if (a->max_fallback > c->opt.n_clusters * 20) { set_error("max_fallback %d > K*20", a->max_fallback); return DISCO_EINVAL; }
     return DISCO_OK;
 }
 
