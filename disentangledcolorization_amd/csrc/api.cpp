@@ -3,6 +3,7 @@
 // AnchorColorProb.forward(test_mode=True) (models/model.py:103-199) as a sequence of HIP launches.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -190,6 +191,13 @@ int upload_vec(disco_ctx* c, const std::vector<T>& v, T** out) { return upload(c
 
 const HostTensor& T(disco_ctx* c, const std::string& k) { return c->sd.at(k); }
 
+// DISCO_CONV_V1=1 selects the first-generation register-staged conv kernel (A/B measurements)
+int run_conv(const ConvArgs& ca, hipStream_t s) {
+    static const bool v1 = [] { const char* e = getenv("DISCO_CONV_V1"); return e && e[0] == '1'; }();
+    if (v1 && !ca.out_f32 && ca.d2s_c == 0) return launch_conv3x3(ca, s);
+    return launch_conv3x3_v2(ca, s);
+}
+
 // effective conv weight (c_out, c_in, 3, 3): plain `.weight`, or spectral-norm weight_orig / (u . (W v))
 std::vector<float> eff_weight(disco_ctx* c, const std::string& key) {
     auto it = c->sd.find(key + ".weight");
@@ -287,15 +295,19 @@ int make_small_out(disco_ctx* c, const std::string& key) {
     return DISCO_OK;
 }
 
+// ConvTranspose2d(4,s2,p1) as a 4-phase 3x3 conv on the MFMA kernel with a depth-to-space epilogue
 int make_deconv(disco_ctx* c, const std::string& key) {
     const HostTensor& ws = T(c, key + ".weight");
     const int ci = (int)ws.shape[0], co = (int)ws.shape[1];
-    std::vector<char> packed(deconv4x4_packed_bytes(ci, co));
-    deconv4x4_pack_host(ws.data.data(), ci, co, packed.data());
-    DirectLayer L; L.c_in = ci; L.c_out = co;
+    std::vector<float> w3((size_t)4 * co * ci * 9);
+    deconv_as_conv3x3_host(ws.data.data(), ci, co, w3.data());
+    ConvLayer L;
+    L.c_in = ci; L.c_out = 4 * co; L.c_in_pad = round_up(ci, 16);
+    std::vector<char> packed(conv3x3_packed_bytes(L.c_out, L.c_in_pad));
+    conv3x3_pack_host(w3.data(), L.c_out, ci, nullptr, L.c_in_pad, packed.data());
     int rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w); if (rc) return rc;
     if ((rc = upload_vec(c, T(c, key + ".bias").data, &L.d_bias))) return rc;
-    c->direct[key] = L;
+    c->conv[key] = L;
     return DISCO_OK;
 }
 
@@ -366,11 +378,13 @@ struct Plan {
 
     // MFMA conv: out = bn(act(conv(cat(in0[,in1])) + bias [+ res]))
     Act conv(const std::string& key, const Act& in0, const Act* in1, int up0, int up1, int stride, int actc, float slope,
-             const Act* res = nullptr) {
+             const Act* res = nullptr, float* out_f32 = nullptr, bool d2s = false) {
         const ConvLayer& L = c->conv.at(key);
         const int hin = in0.h << up0, win = in0.w << up0;
         const int ho = (hin - 1) / stride + 1, wo = (win - 1) / stride + 1;
-        Act out = act(in0.n, ho, wo, L.c_out);
+        Act out{};
+        if (d2s) out = act(in0.n, 2 * ho, 2 * wo, L.c_out / 4);
+        else if (!out_f32) out = act(in0.n, ho, wo, L.c_out);
         if (dry || !ok()) return out;
         ConvArgs ca{};
         ca.src[0] = {in0.p, (long)in0.plane, in0.c, in0.h, in0.w, up0};
@@ -382,25 +396,23 @@ struct Plan {
         ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
         ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
         ca.out = out.p; ca.out_plane = (long)out.plane;
+        ca.out_f32 = out_f32; ca.d2s_c = d2s ? L.c_out / 4 : 0;
         ca.act = actc; ca.slope = slope; ca.precision = c->opt.precision;
         if (in0.c + (in1 ? in1->c : 0) != L.c_in_pad) { set_error("conv %s: input channels %d != %d", key.c_str(), in0.c + (in1 ? in1->c : 0), L.c_in_pad); rc = DISCO_ESHAPE; return out; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = c->profiling >= 2 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
         if (timed) hipEventRecord(e0, s);
-        rc = launch_conv3x3(ca, s);
+        rc = run_conv(ca, s);
         if (timed) {
             hipEventRecord(e1, s);
-            c->conv_prof.push_back({e0, e1, 2.0 * 9.0 * L.c_in * L.c_out * (double)ho * wo * in0.n});
+            // algorithmic FLOPs: a ConvTranspose 4x4 s2 has 16 (not 36) taps per (ci,co) and input pixel
+            const double taps = d2s ? 16.0 * (L.c_out / 4) : 9.0 * L.c_out;
+            c->conv_prof.push_back({e0, e1, 2.0 * taps * L.c_in * (double)ho * wo * in0.n});
         }
         return out;
     }
     Act deconv(const std::string& key, const Act& in, float slope) {
-        const DirectLayer& L = c->direct.at(key);
-        Act out = act(in.n, in.h * 2, in.w * 2, L.c_out);
-        if (dry || !ok()) return out;
-        rc = launch_deconv4x4(in.p, (long)in.plane, L.d_w, L.d_bias, out.p, (long)out.plane, in.n, in.h, in.w, L.c_in, L.c_out,
-                              slope, c->opt.precision, s);
-        return out;
+        return conv(key, in, nullptr, 0, 0, 1, DISCO_ACT_LRELU, slope, nullptr, nullptr, true);
     }
     Act c1(const std::string& key, const float* gray, int n, int h, int w, int actc, float slope) {
         const DirectLayer& L = c->direct.at(key);
@@ -581,10 +593,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     u = P.conv(en + "up1.combine", t, &e1, 1, 0, 1, RELU, 0.f); P.drop(t); P.drop(e1);
     t = P.conv(en + "up1.conv2.0", u, nullptr, 0, 0, 1, RELU, 0.f); P.drop(u);
     u = P.conv(en + "up1.conv2.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
-    if (!dry && P.ok()) {
-        const DirectLayer& Lo = c->direct.at(en + "outConv");
-        P.rc = launch_conv_small_out(u.p, (long)u.plane, 64, Lo.d_w, Lo.d_bias, a->d_pred_colors, n2, H, W, 2, 1, s);
-    }
+    P.conv(en + "outConv", u, nullptr, 0, 0, 1, DISCO_ACT_TANH, 0.f, nullptr, dry ? (float*)16 : a->d_pred_colors);
     P.drop(u);
     P.mark("enhance", 2.0 * 55.6794e9 * (double)n2 * H * W / 65536.0);
 
@@ -727,7 +736,7 @@ int disco_finalize(disco_ctx* c) {
         if ((rc = make_conv(c, en + k + ".conv2.0", "", ""))) return rc;
         if ((rc = make_conv(c, en + k + ".conv2.2", "", en + k + ".conv2.4"))) return rc;
     }
-    if ((rc = make_small_out(c, en + "outConv"))) return rc;
+    if ((rc = make_conv(c, en + "outConv", "", ""))) return rc;
     if ((rc = make_encoder(c, "wildpath", &c->d_enc[0]))) return rc;
     if ((rc = make_encoder(c, "hintpath", &c->d_enc[1]))) return rc;
     if ((rc = upload_vec(c, T(c, "mid_word_prj.weight").data, &c->d_mid_w))) return rc;
@@ -848,15 +857,19 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
     ca.out = (f16*)d_out; ca.out_plane = (long)d->n * ca.h_out * ca.w_out * d->c_out;
     ca.res = (const f16*)d_res; ca.res_plane = ca.out_plane;
     ca.act = d->act; ca.slope = d->slope; ca.precision = d->precision;
-    return launch_conv3x3(ca, (hipStream_t)stream);
+    return run_conv(ca, (hipStream_t)stream);
 }
 
 int disco_op_deconv4x4_pack(const float* h_w, int c_in, int c_out, void* d_packed, size_t* bytes) {
     if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }
-    *bytes = deconv4x4_packed_bytes(c_in, c_out);
+    const int cpad = round_up(c_in, 16);
+    *bytes = conv3x3_packed_bytes(4 * c_out, cpad);
     if (!d_packed) return DISCO_OK;
+    if (!h_w) { set_error("null weight"); return DISCO_EINVAL; }
+    std::vector<float> w3((size_t)4 * c_out * c_in * 9);
+    deconv_as_conv3x3_host(h_w, c_in, c_out, w3.data());
     std::vector<char> packed(*bytes);
-    deconv4x4_pack_host(h_w, c_in, c_out, packed.data());
+    conv3x3_pack_host(w3.data(), 4 * c_out, c_in, nullptr, cpad, packed.data());
     DISCO_HIP_CHECK(hipMemcpy(d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice));
     return DISCO_OK;
 }
@@ -864,8 +877,14 @@ int disco_op_deconv4x4_pack(const float* h_w, int c_in, int c_out, void* d_packe
 int disco_op_deconv4x4(const void* d_src, const void* d_packed_w, const float* d_bias, void* d_out, int n, int h_in, int w_in,
                        int c_in, int c_out, float slope, int precision, void* stream) {
     if (!d_src || !d_packed_w || !d_bias || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
-    return launch_deconv4x4((const f16*)d_src, (long)n * h_in * w_in * c_in, d_packed_w, d_bias, (f16*)d_out,
-                            (long)n * h_in * 2 * w_in * 2 * c_out, n, h_in, w_in, c_in, c_out, slope, precision, (hipStream_t)stream);
+    if (c_in % 16 || (4 * c_out) % 64) { set_error("deconv4x4: c_in %% 16 and c_out %% 16 required"); return DISCO_ESHAPE; }
+    ConvArgs ca{};
+    ca.src[0] = {(const f16*)d_src, (long)n * h_in * w_in * c_in, c_in, h_in, w_in, 0};
+    ca.nsrc = 1; ca.n = n; ca.h_in = h_in; ca.w_in = w_in; ca.c_in = c_in; ca.stride = 1; ca.h_out = h_in; ca.w_out = w_in;
+    ca.w = (const f16*)d_packed_w; ca.c_out = 4 * c_out; ca.c_out_pad = 4 * c_out; ca.bias = d_bias;
+    ca.out = (f16*)d_out; ca.out_plane = (long)n * 4 * h_in * w_in * c_out; ca.d2s_c = c_out;
+    ca.act = DISCO_ACT_LRELU; ca.slope = slope; ca.precision = precision;
+    return launch_conv3x3_v2(ca, (hipStream_t)stream);
 }
 
 int disco_op_poolfeat(const float* d_feat, const float* d_prob, float* d_pooled, float* d_conf, float* d_sizes, int n, int ch,

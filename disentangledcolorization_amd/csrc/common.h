@@ -67,6 +67,9 @@ struct ConvArgs {
     long res_plane;
     f16* out;
     long out_plane;
+    float* out_f32;     // if set: fp32 NCHW output (n, c_out, h_out, w_out) instead of act planes
+    int d2s_c;          // > 0: depth-to-space epilogue (ConvTranspose 4x4 s2 as a 4-phase conv): out channel
+                        // co' = phase*d2s_c + co goes to pixel (2y + phase/2, 2x + phase%2) of a (2h,2w,d2s_c) act
     int act;
     float slope;
     int precision;
@@ -76,6 +79,9 @@ size_t conv3x3_packed_bytes(int c_out, int c_in_pad);
 // h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map[i] = source channel index for packed channel i or -1 (zero)
 void conv3x3_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed);
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+int launch_conv3x3_v2(const ConvArgs& a, hipStream_t s);   // conv_mfma2.hip: LDS-DMA double-buffered pipeline
+// ConvTranspose2d(4,s2,p1) weight (c_in,c_out,4,4) -> equivalent 3x3 conv weight (4*c_out, c_in, 3, 3), phase-major
+void deconv_as_conv3x3_host(const float* h_w_iohw, int c_in, int c_out, float* h_w_oihw);
 
 // ---- direct (VALU) convs ------------------------------------------------------------------------
 // first layers: Cin = 1, fp32 NCHW gray input -> act output
@@ -86,11 +92,6 @@ int launch_conv_c1(const float* d_gray, const float* d_w /*(cout,9)*/, const flo
 int launch_conv_small_out(const f16* in, long in_plane, int c_in, const float* d_w /*(9,c_in,cout)*/,
                           const float* d_bias, float* d_out_nchw, int n, int h, int w, int c_out, int mode,
                           hipStream_t s);
-size_t deconv4x4_packed_bytes(int c_in, int c_out);
-void deconv4x4_pack_host(const float* h_w_iohw, int c_in, int c_out, void* h_packed);
-int launch_deconv4x4(const f16* in, long in_plane, const void* d_packed, const float* d_bias, f16* out,
-                     long out_plane, int n, int h_in, int w_in, int c_in, int c_out, float slope, int precision,
-                     hipStream_t s);
 
 // ---- layout conversion --------------------------------------------------------------------------
 int launch_nchw_to_act(const float* src, f16* dst, long plane, int n, int c, int h, int w, int c_pad, hipStream_t s);

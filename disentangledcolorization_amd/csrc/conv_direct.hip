@@ -2,10 +2,8 @@
 // kernels, plus the NCHW-fp32 <-> NHWC-fp16x2 layout converters.
 //
 //   conv_c1          Cin = 1 first layers  (segnet conv0a, network.py:263; repnet conv1_2.0, :152)
-//   conv_small_out   Cout in {9, 2} last layers with their epilogues fused:
-//                      pred_mask0 + softmax over the 9 slots (network.py:282-283, 311-312)  -> affinity NCHW fp32
-//                      enhanceNet.outConv + tanh (network.py:134, model.py:197)             -> pred_colors NCHW fp32
-//   deconv4x4        ConvTranspose2d(4, stride 2, pad 1) + bias + LeakyReLU (network.py:254-258)
+//   conv_small_out   pred_mask0 (16 -> 9) + softmax over the 9 slots (network.py:282-283, 311-312) -> affinity NCHW fp32
+// (enhanceNet.outConv and the ConvTranspose2d layers run on the MFMA kernel: conv_mfma2.hip epilogues.)
 #include "common.h"
 
 namespace disco {
@@ -129,59 +127,6 @@ __global__ __launch_bounds__(256) void conv_small_out_kernel(const f16* __restri
     }
 }
 
-// ---- ConvTranspose2d 4x4 s2 p1 -------------------------------------------------------------------
-// out[co, 2i-1+ky, 2j-1+kx] += in[ci,i,j] W[ci,co,ky,kx].  For an output pixel (Y,X) the contributing taps are
-// ky = (Y+1)%2 + {0,2} with i = (Y+1-ky)/2 (same in x): a 2x2 gather.  thread = (out pixel, 8 out channels);
-// packed weights: [ky][kx][ci][co] fp32.
-__global__ __launch_bounds__(256) void deconv4x4_kernel(const f16* __restrict__ in, long in_plane,
-                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                        f16* out, long out_plane, int n, int h_in, int w_in, int c_in,
-                                                        int c_out, float slope) {
-    const int groups = c_out >> 3;
-    const int ho = h_in * 2, wo = w_in * 2;
-    const long total = (long)n * ho * wo * groups;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(t % groups);
-        const long pix = t / groups;
-        const int X = (int)(pix % wo);
-        const int Y = (int)((pix / wo) % ho);
-        const long img = pix / ((long)wo * ho);
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int ky = ((Y + 1) & 1) + 2 * a;
-            const int i = (Y + 1 - ky) >> 1;
-            if (i < 0 || i >= h_in) continue;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int kx = ((X + 1) & 1) + 2 * b;
-                const int jx = (X + 1 - kx) >> 1;
-                if (jx < 0 || jx >= w_in) continue;
-                const f16* p = in + ((img * h_in + i) * w_in + jx) * c_in;
-                const float* wt = w + ((long)(ky * 4 + kx) * c_in) * c_out + g * 8;
-                for (int c8 = 0; c8 < c_in; c8 += 8) {
-                    float v[8];
-                    load_sum8(p + c8, in_plane, v);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float4 w0 = *reinterpret_cast<const float4*>(wt + (long)(c8 + q) * c_out);
-                        const float4 w1 = *reinterpret_cast<const float4*>(wt + (long)(c8 + q) * c_out + 4);
-                        acc[0] = fmaf(v[q], w0.x, acc[0]); acc[1] = fmaf(v[q], w0.y, acc[1]);
-                        acc[2] = fmaf(v[q], w0.z, acc[2]); acc[3] = fmaf(v[q], w0.w, acc[3]);
-                        acc[4] = fmaf(v[q], w1.x, acc[4]); acc[5] = fmaf(v[q], w1.y, acc[5]);
-                        acc[6] = fmaf(v[q], w1.z, acc[6]); acc[7] = fmaf(v[q], w1.w, acc[7]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = acc[j] >= 0.f ? acc[j] : acc[j] * slope;
-        store_split8(out + pix * c_out + g * 8, out_plane, acc);
-    }
-}
-
 // ---- layout converters -----------------------------------------------------------------------------
 __global__ void nchw_to_act_kernel(const float* __restrict__ src, f16* dst, long plane, int n, int c, int h, int w,
                                    int c_pad) {
@@ -237,39 +182,8 @@ int launch_conv_small_out(const f16* in, long in_plane, int c_in, const float* d
     if (c_out == 9 && mode == 0)
         hipLaunchKernelGGL((conv_small_out_kernel<9, 0>), grid, block, smem, s, in, in_plane, c_in, d_w, d_bias,
                            d_out_nchw, n, h, w);
-    else if (c_out == 2 && mode == 1)
-        hipLaunchKernelGGL((conv_small_out_kernel<2, 1>), grid, block, smem, s, in, in_plane, c_in, d_w, d_bias,
-                           d_out_nchw, n, h, w);
-    else if (c_out == 2 && mode == 2)
-        hipLaunchKernelGGL((conv_small_out_kernel<2, 2>), grid, block, smem, s, in, in_plane, c_in, d_w, d_bias,
-                           d_out_nchw, n, h, w);
     else { set_error("conv_small_out: unsupported c_out=%d mode=%d", c_out, mode); return DISCO_EUNSUPPORTED; }
     DISCO_LAUNCH_CHECK("conv_small_out_kernel");
-    return DISCO_OK;
-}
-
-size_t deconv4x4_packed_bytes(int c_in, int c_out) { return (size_t)16 * c_in * c_out * sizeof(float); }
-
-void deconv4x4_pack_host(const float* h_w_iohw, int c_in, int c_out, void* h_packed) {
-    float* dst = reinterpret_cast<float*>(h_packed);
-    for (int ky = 0; ky < 4; ++ky)
-        for (int kx = 0; kx < 4; ++kx)
-            for (int ci = 0; ci < c_in; ++ci)
-                for (int co = 0; co < c_out; ++co)
-                    dst[((size_t)(ky * 4 + kx) * c_in + ci) * c_out + co] =
-                        h_w_iohw[(((size_t)ci * c_out + co) * 4 + ky) * 4 + kx];
-}
-
-int launch_deconv4x4(const f16* in, long in_plane, const void* d_packed, const float* d_bias, f16* out,
-                     long out_plane, int n, int h_in, int w_in, int c_in, int c_out, float slope, int precision,
-                     hipStream_t s) {
-    (void)precision;
-    if (c_out % 8 || c_in % 8) { set_error("deconv4x4: channels must be multiples of 8"); return DISCO_ESHAPE; }
-    const long total = (long)n * h_in * 2 * w_in * 2 * (c_out / 8);
-    hipLaunchKernelGGL(deconv4x4_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, in_plane,
-                       reinterpret_cast<const float*>(d_packed), d_bias, out, out_plane, n, h_in, w_in, c_in, c_out,
-                       slope);
-    DISCO_LAUNCH_CHECK("deconv4x4_kernel");
     return DISCO_OK;
 }
 

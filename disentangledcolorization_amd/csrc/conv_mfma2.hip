@@ -1,0 +1,306 @@
+// conv_mfma2.hip — second-generation 3x3 implicit-GEMM conv for gfx950: same math and packed-weight format
+// as conv_mfma.hip, restructured around the CDNA4 async copy engine:
+//
+//   * both operands of a 16-channel chunk (input halo tile, 9 taps of weights) travel HBM/L2 -> LDS with
+//     global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass);
+//   * LDS is double buffered: the DMA of chunk k+1 is issued right after the single barrier of chunk k and
+//     lands while the waves run chunk k's 9 taps of MFMAs; each wave waits only for its own DMA pieces
+//     (s_waitcnt vmcnt(0)) right before that barrier;
+//   * the halo tile is stored 32 B per pixel (16 channels) with a 16-byte XOR swizzle on pixel bit 3 — applied
+//     on the DMA *source* address (the LDS image of a DMA piece is lane-linear) and on the fragment read — so
+//     the 64-lane ds_read_b128 of an A fragment is bank-conflict free; stride-2 tiles are additionally
+//     de-interleaved by column parity so consecutive output pixels read consecutive LDS pixels;
+//   * out-of-image halo pixels DMA from a 16-byte zero word;
+//   * 8 waves (2 per SIMD) on a 16x32-pixel x 64-channel tile where the image is large enough.
+//
+// Epilogue variants: NHWC fp16 hi/lo planes (default), fp32 NCHW (network outputs), depth-to-space
+// (ConvTranspose2d 4x4 s2 p1 expressed as a 4-phase 3x3 conv, network.py:254-258).
+#include "common.h"
+
+namespace disco {
+
+namespace {
+
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+constexpr int WBLK = 1024;
+constexpr int W_NB = 9 * 2 * WBLK;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+template <int TW, int TH, int STRIDE>
+struct Geo2 {
+    static constexpr int MB = TW * TH / 32;
+    static constexpr int TWI = (TW - 1) * STRIDE + 3;
+    static constexpr int THI = (TH - 1) * STRIDE + 3;
+    static constexpr int HALF = (TWI + 1) / 2;                       // stride 2: pixels per column-parity half row
+    static constexpr int PITCH = STRIDE == 1 ? TWI : 2 * HALF;       // LDS pixels per tile row
+    static constexpr int NPIX = THI * PITCH;
+    static constexpr int ROWS_PER_MB = 32 / TW;
+    static_assert(32 % TW == 0, "an M block covers whole tile rows");
+};
+
+template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvArgs a) {
+    using G = Geo2<TW, TH, STRIDE>;
+    constexpr int NWAVE = WM * WN;
+    constexpr int MT = G::MB / WM;             // M blocks per wave
+    constexpr int NTW = NT / WN;               // N blocks per wave
+    static_assert(G::MB % WM == 0 && NT % WN == 0, "tile split");
+    constexpr int NPLANE = X3 ? 2 : 1;
+    constexpr int PLANE_B = G::NPIX * 32;                          // bytes per plane in LDS
+    constexpr int A_UNITS = NPLANE * G::NPIX * 2;
+    constexpr int A_PIECES = (A_UNITS + 63) / 64;
+    constexpr int A_BYTES = A_PIECES * 1024;
+    constexpr int W_PIECES = NT * 18;
+    constexpr int BUF_BYTES = A_BYTES + W_PIECES * 1024;
+    constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;
+    constexpr int WPW = (W_PIECES + NWAVE - 1) / NWAVE;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
+
+    // ---- DMA descriptors: in-image element offset (plane in bit 30) or -1 (zero word) per owned unit ----------
+    int goff[APW];
+    int cur_src = -1;
+    const f16* src_img = nullptr;
+    long src_plane = 0;
+    int src_c0 = 0;
+    auto setup_source = [&](int si) {
+        const ConvSrc& sp = a.src[si];
+        cur_src = si;
+        src_img = sp.p + (size_t)n * sp.h * sp.w * sp.c;
+        src_plane = sp.plane;
+        src_c0 = si == 0 ? 0 : a.src[0].c;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int u = (i * NWAVE + wave) * 64 + lane;
+            const int plane = u / (G::NPIX * 2);
+            const int rem = u - plane * (G::NPIX * 2);
+            const int p = rem >> 1, j = rem & 1;
+            const int kh = j ^ ((p >> 3) & 1);
+            const int py = p / G::PITCH, q = p - py * G::PITCH;
+            int px;
+            bool slot_ok = u < A_UNITS;
+            if (STRIDE == 1) px = q;
+            else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok && px < G::TWI; }
+            const int gy = iy0 + py, gx = ix0 + px;
+            const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
+            goff[i] = in ? (((gy >> sp.up) * sp.w + (gx >> sp.up)) * sp.c + kh * 8) | (plane << 30) : -1;
+        }
+    };
+
+    const int nchunks = a.c_in >> 4;
+    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)(blockIdx.y * NT) * nchunks * W_NB;
+
+    auto issue = [&](int ck, int buf) {
+        int c0 = ck << 4;
+        const int si = (a.nsrc > 1 && c0 >= a.src[0].c) ? 1 : 0;
+        if (si != cur_src) setup_source(si);
+        c0 -= src_c0;
+        char* dA = smem + buf * BUF_BYTES;
+        char* dW = dA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int piece = i * NWAVE + wave;
+            if (piece < A_PIECES) {
+                const f16* gp = reinterpret_cast<const f16*>(&g_zero16);
+                if (goff[i] >= 0) gp = src_img + (goff[i] >> 30) * src_plane + (goff[i] & 0x3fffffff) + c0;
+                __builtin_amdgcn_global_load_lds((gbl_void*)gp, (lds_void*)(dA + piece * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int piece = i * NWAVE + wave;
+            if (piece < W_PIECES) {
+                const int nt = piece / 18, q = piece - nt * 18;
+                const char* gp = wbase + ((size_t)nt * nchunks + ck) * W_NB + q * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((gbl_void*)gp, (lds_void*)(dW + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- per-lane fragment addressing ---------------------------------------------------------------------------
+    const int r = lane & 31, kh = lane >> 5;
+    const int lox = r % TW, loy = r / TW;
+    const int p_lane = ((wm * MT * G::ROWS_PER_MB + loy) * STRIDE) * G::PITCH + lox;
+    const int w_off = lane * 16 + wn * NTW * W_NB;
+
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue(0, 0);
+    for (int ck = 0; ck < nchunks; ++ck) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of chunk ck have landed
+        __builtin_amdgcn_s_barrier();                        // ... everyone's have; chunk ck-1's reads are finished
+        if (ck + 1 < nchunks) issue(ck + 1, (ck + 1) & 1);
+        const char* sA = smem + (ck & 1) * BUF_BYTES;
+        const char* sW = sA + A_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int tapoff = ky * G::PITCH + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
+            f16x8 ah[MT], al[MT], bh[NTW], bl[NTW];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = p_lane + mt * G::ROWS_PER_MB * STRIDE * G::PITCH + tapoff;
+                const int off = (p << 5) + ((((p >> 3) ^ kh) & 1) << 4);
+                ah[mt] = *reinterpret_cast<const f16x8*>(sA + off);
+                if (X3) al[mt] = *reinterpret_cast<const f16x8*>(sA + PLANE_B + off);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int off = w_off + nt * W_NB + tap * 2 * WBLK;
+                bh[nt] = *reinterpret_cast<const f16x8*>(sW + off);
+                if (X3) bl[nt] = *reinterpret_cast<const f16x8*>(sW + off + WBLK);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if (X3) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: bias (+res) -> activation -> BN affine -> store ---------------------------------------------
+    const int cpad = a.c_out_pad;
+    const size_t img_elems = (size_t)a.h_out * a.w_out * cpad;
+    const f16* res_img = a.res ? a.res + (size_t)n * img_elems : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = (blockIdx.y * NT + wn * NTW + nt) * 32 + r;
+        const bool cok = co < a.c_out;
+        const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;     // per-channel parameters are shared by the 4 phases
+        const float bias = (cok && a.bias) ? a.bias[cpar] : 0.f;
+        const float bsc = (cok && a.bn_scale) ? a.bn_scale[cpar] : 1.f;
+        const float bsh = (cok && a.bn_shift) ? a.bn_shift[cpar] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                const int px = m % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + m / TW;
+                const int oy = oy0 + py, ox = ox0 + px;
+                if (cok && oy < a.h_out && ox < a.w_out) {
+                    float v = acc[mt][nt][e] + bias;
+                    if (res_img) {
+                        const size_t ridx = ((size_t)oy * a.w_out + ox) * cpad + co;
+                        v += (float)res_img[ridx] + (float)res_img[ridx + a.res_plane];
+                    }
+                    if (a.act == DISCO_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (a.act == DISCO_ACT_LRELU) v = v >= 0.f ? v : v * a.slope;
+                    else if (a.act == DISCO_ACT_TANH) v = tanhf(v);
+                    v = v * bsc + bsh;
+                    if (a.out_f32) {
+                        a.out_f32[(((size_t)n * a.c_out + co) * a.h_out + oy) * a.w_out + ox] = v;
+                    } else {
+                        size_t idx;
+                        if (a.d2s_c > 0) {
+                            const int ph = co / a.d2s_c, cc = co - ph * a.d2s_c;
+                            idx = (((size_t)n * 2 * a.h_out + 2 * oy + (ph >> 1)) * 2 * a.w_out + 2 * ox + (ph & 1)) * a.d2s_c + cc;
+                        } else idx = (size_t)n * img_elems + ((size_t)oy * a.w_out + ox) * cpad + co;
+                        const f16 hi = (f16)v;
+                        a.out[idx] = hi;
+                        a.out[idx + a.out_plane] = (f16)(v - (float)hi);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN>
+int launch_cfg2(const ConvArgs& a, hipStream_t s) {
+    using G = Geo2<TW, TH, STRIDE>;
+    constexpr int A_BYTES = (((X3 ? 2 : 1) * G::NPIX * 2 + 63) / 64) * 1024;
+    constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_mfma2_kernel<TW, TH, NT, STRIDE, X3, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int tiles = cdiv(a.w_out, TW) * cdiv(a.h_out, TH) * a.n;
+    dim3 grid(tiles, cdiv(a.c_out, 32 * NT));
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, a);
+    DISCO_LAUNCH_CHECK("conv3x3_mfma2_kernel");
+    return DISCO_OK;
+}
+
+template <bool X3>
+int dispatch2(const ConvArgs& a, hipStream_t s) {
+    const bool wide = a.w_out > 16;
+    const bool nt2 = a.c_out > 32;
+    if (a.stride == 1) {
+        if (wide) {
+            if (a.h_out > 8) return nt2 ? launch_cfg2<32, 16, 2, 1, X3, 8, 1>(a, s) : launch_cfg2<32, 16, 1, 1, X3, 8, 1>(a, s);
+            return nt2 ? launch_cfg2<32, 8, 2, 1, X3, 4, 2>(a, s) : launch_cfg2<32, 8, 1, 1, X3, 4, 1>(a, s);
+        }
+        return nt2 ? launch_cfg2<16, 16, 2, 1, X3, 4, 2>(a, s) : launch_cfg2<16, 16, 1, 1, X3, 4, 1>(a, s);
+    }
+    if (wide) return nt2 ? launch_cfg2<32, 4, 2, 2, X3, 4, 2>(a, s) : launch_cfg2<32, 4, 1, 2, X3, 4, 1>(a, s);
+    return nt2 ? launch_cfg2<16, 8, 2, 2, X3, 4, 2>(a, s) : launch_cfg2<16, 8, 1, 2, X3, 4, 1>(a, s);
+}
+
+}  // namespace
+
+void deconv_as_conv3x3_host(const float* w, int c_in, int c_out, float* out) {
+    // out[2a+py, 2b+px] = sum_{ky,kx} in[i,j] W[ci,co,ky,kx] with 2i-1+ky = 2a+py  =>  i = a + dy where
+    //   py = 0: ky = 1 -> dy = 0,  ky = 3 -> dy = -1;      py = 1: ky = 0 -> dy = +1,  ky = 2 -> dy = 0   (same in x)
+    const size_t total = (size_t)4 * c_out * c_in * 9;
+    for (size_t i = 0; i < total; ++i) out[i] = 0.f;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            for (int ky = 0; ky < 4; ++ky) {
+                if (((ky + 1) & 1) != py) continue;          // ky parity must match: ky = py+1 (mod 2)
+                const int dy = (py + 1 - ky) / 2;            // exact: numerator even
+                for (int kx = 0; kx < 4; ++kx) {
+                    if (((kx + 1) & 1) != px) continue;
+                    const int dx = (px + 1 - kx) / 2;
+                    for (int co = 0; co < c_out; ++co)
+                        for (int ci = 0; ci < c_in; ++ci)
+                            out[(((size_t)((py * 2 + px) * c_out + co) * c_in + ci) * 3 + (dy + 1)) * 3 + (dx + 1)] =
+                                w[(((size_t)ci * c_out + co) * 4 + ky) * 4 + kx];
+                }
+            }
+}
+
+int launch_conv3x3_v2(const ConvArgs& a, hipStream_t s) {
+    if (a.stride != 1 && a.stride != 2) { set_error("conv3x3: stride %d", a.stride); return DISCO_ESHAPE; }
+    if (a.c_in % 16 || a.src[0].c % 16 || (a.nsrc > 1 && a.src[1].c % 16)) {
+        set_error("conv3x3: input channels must be multiples of 16 (got %d)", a.c_in);
+        return DISCO_ESHAPE;
+    }
+    if (a.c_out > 32 && a.c_out % 64) { set_error("conv3x3: c_out %d (>32) must be a multiple of 64", a.c_out); return DISCO_ESHAPE; }
+    for (int i = 0; i < a.nsrc; ++i)
+        if ((size_t)a.src[i].h * a.src[i].w * a.src[i].c >= (1u << 30)) {
+            set_error("conv3x3: image too large for 30-bit in-image offsets");
+            return DISCO_ESHAPE;
+        }
+    return a.precision == DISCO_PREC_F16X1 ? dispatch2<false>(a, s) : dispatch2<true>(a, s);
+}
+
+}  // namespace disco

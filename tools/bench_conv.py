@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the MFMA conv kernel on the layer shapes of the DISCO forward (GPU box only).
+
+    python tools/bench_conv.py [--n 64] [--iters 10]
+Prints ms and algorithmic / executed TFLOP/s per shape.  Set DISCO_CONV_V1=1 for the first-generation kernel.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import ctypes as C  # noqa: E402
+
+import gpu_helpers as H  # noqa: E402
+from disentangledcolorization_amd import _ffi  # noqa: E402
+
+SHAPES = [  # name, cin0, cin1, cout, h_in (logical), stride, up0
+    ("512->512 @32", 512, 0, 512, 32, 1, 0),
+    ("256->256 @64", 256, 0, 256, 64, 1, 0),
+    ("128->128 @128", 128, 0, 128, 128, 1, 0),
+    ("64->64 @256", 64, 0, 64, 256, 1, 0),
+    ("up 512->256 @64", 512, 0, 256, 64, 1, 1),
+    ("up 128->64 @256", 128, 0, 64, 256, 1, 1),
+    ("cat 64+64->64 @256", 64, 64, 64, 256, 1, 1),
+    ("s2 64->128 @256", 64, 0, 128, 256, 2, 0),
+    ("s2 256->512 @64", 256, 0, 512, 64, 2, 0),
+    ("64->2(32) @256", 64, 0, 2, 256, 1, 0),
+    ("16->16 @256", 16, 0, 16, 256, 1, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--prec", type=int, default=0)
+    args = ap.parse_args()
+    L = _ffi.lib()
+    for name, c0, c1, co, hin, stride, up0 in SHAPES:
+        n = args.n
+        hs = hin // 2 if up0 else hin
+        src0 = torch.randn(2, n, hs, hs, c0, device="cuda").half()
+        src1 = torch.randn(2, n, hin, hin, c1, device="cuda").half() if c1 else None
+        w = torch.randn(co, c0 + c1, 3, 3) * 0.05
+        packed = H.pack_conv(w)
+        ho = (hin - 1) // stride + 1
+        out = torch.empty(2, n, ho, ho, co, device="cuda", dtype=torch.float16)
+        bias = torch.zeros(co, device="cuda")
+        d = _ffi.ConvDesc(n, hin, hin, c0, c1, up0, 0, co, stride, _ffi.ACT_RELU, 0.0, args.prec)
+
+        def run():
+            _ffi.check(L.disco_op_conv3x3(C.byref(d), _ffi.ptr(src0), _ffi.ptr(src1), _ffi.ptr(packed), _ffi.ptr(bias), None,
+                                          None, None, _ffi.ptr(out), H.stream()))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        fl = 2.0 * 9 * (c0 + c1) * co * ho * ho * n
+        mult = 3 if args.prec == 0 else 1
+        print(f"{name:22s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF alg  {mult * fl / ms / 1e9:8.1f} TF mfma", flush=True)
+
+
+if __name__ == "__main__":
+    main()
