@@ -32,7 +32,7 @@ int hip_fail(hipError_t e, const char* what);
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
-// ---- activation tensor: NHWC fp16, hi plane followed by lo plane -----------------------------
+// ---- activation tensor: channel-blocked [N][C/16][H][W][16] fp16, hi plane followed by lo plane ----
 struct Act {
     f16* p = nullptr;  // hi plane; lo plane at p + plane
     int n = 0, h = 0, w = 0, c = 0;
@@ -58,6 +58,7 @@ struct ConvArgs {
     int c_in;           // padded total input channels (multiple of 16)
     int h_out, w_out, stride;
     const f16* w;       // packed weights
+    const uint32_t* tapmask;  // per 32-cout block: bit t set = tap t has a non-zero weight (null: all 9 taps)
     int c_out;          // real output channels
     int c_out_pad;      // channel stride of the output tensor
     const float* bias;
@@ -78,10 +79,14 @@ struct ConvArgs {
 size_t conv3x3_packed_bytes(int c_out, int c_in_pad);
 // h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map[i] = source channel index for packed channel i or -1 (zero)
 void conv3x3_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed);
-int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_v2(const ConvArgs& a, hipStream_t s);   // conv_mfma2.hip: LDS-DMA double-buffered pipeline
 // ConvTranspose2d(4,s2,p1) weight (c_in,c_out,4,4) -> equivalent 3x3 conv weight (4*c_out, c_in, 3, 3), phase-major
 void deconv_as_conv3x3_host(const float* h_w_iohw, int c_in, int c_out, float* h_w_oihw);
+// nearest-x2-upsample followed by a 3x3 conv (c_out,c_in,3,3) -> 4-phase 3x3 conv on the low-res input
+// (4*c_out, c_in, 3, 3), phase-major, taps pre-summed (sub-pixel decomposition; 4 non-zero taps per phase)
+void upconv_as_conv3x3_host(const float* h_w_oihw, int c_in, int c_out, float* h_w4_oihw);
+// bit t of mask[nb] set iff any weight of tap t is non-zero in 32-cout block nb
+void conv3x3_tapmask_host(const float* h_w, int c_out, int c_in, uint32_t* mask /* cdiv(c_out,32) */);
 
 // ---- direct (VALU) convs ------------------------------------------------------------------------
 // first layers: Cin = 1, fp32 NCHW gray input -> act output

@@ -1,5 +1,6 @@
 // conv_direct.hip — the few convolutions that do not fit the MFMA implicit GEMM, as exact-fp32 VALU
-// kernels, plus the NCHW-fp32 <-> NHWC-fp16x2 layout converters.
+// kernels, plus the converters between fp32 NCHW and the internal activation layout
+// (channel-blocked [N][C/16][H][W][16] fp16, hi plane + lo plane).
 //
 //   conv_c1          Cin = 1 first layers  (segnet conv0a, network.py:263; repnet conv1_2.0, :152)
 //   conv_small_out   pred_mask0 (16 -> 9) + softmax over the 9 slots (network.py:282-283, 311-312) -> affinity NCHW fp32
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
             if (bsc) s = s * bsc[co] + bsh[co];
             v[j] = s;
         }
-        store_split8(out + pix * c_out + g * 8, out_plane, v);
+        // channel-blocked act: ((img*C/16 + ch/16)*H*W + y*W + x)*16 + ch%16
+        const long hw = (long)h * wd;
+        store_split8(out + ((img * (c_out >> 4) + (g >> 1)) * hw + (long)y * wd + x) * 16 + (g & 1) * 8, out_plane, v);
     }
 }
 
@@ -98,11 +101,12 @@ __global__ __launch_bounds__(256) void conv_small_out_kernel(const f16* __restri
             for (int kx = 0; kx < 3; ++kx) {
                 const int xx = x + kx - 1;
                 if (xx < 0 || xx >= wd) continue;
-                const f16* p = in + ((img * h + yy) * wd + xx) * c_in;
+                const long hw = (long)h * wd;
+                const f16* p = in + img * c_in * hw + ((long)yy * wd + xx) * 16;
                 const float* wt = sw + (ky * 3 + kx) * c_in * COUT;
                 for (int c8 = 0; c8 < c_in; c8 += 8) {
                     float v[8];
-                    load_sum8(p + c8, in_plane, v);
+                    load_sum8(p + (long)(c8 >> 4) * hw * 16 + (c8 & 15), in_plane, v);
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -132,10 +136,14 @@ __global__ void nchw_to_act_kernel(const float* __restrict__ src, f16* dst, long
                                    int c_pad) {
     const long total = (long)n * h * w * c_pad;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(t % c_pad);
-        const long pix = t / c_pad;
+        // t enumerates the channel-blocked destination: ((img*C/16 + blk)*hw + p)*16 + lane16
         const long hw = (long)h * w;
-        const long img = pix / hw, p = pix % hw;
+        const int l16 = (int)(t & 15);
+        const long q = t >> 4;
+        const long p = q % hw;
+        const int blk = (int)((q / hw) % (c_pad >> 4));
+        const long img = q / (hw * (c_pad >> 4));
+        const int ch = blk * 16 + l16;
         const float v = ch < c ? src[(img * c + ch) * hw + p] : 0.f;
         const f16 hi = (f16)v;
         dst[t] = hi;
@@ -151,7 +159,7 @@ __global__ void act_to_nchw_kernel(const f16* __restrict__ src, long plane, floa
         const long p = t % hw;
         const int ch = (int)((t / hw) % c);
         const long img = t / (hw * c);
-        const long s = (img * hw + p) * c_pad + ch;
+        const long s = ((img * (c_pad >> 4) + (ch >> 4)) * hw + p) * 16 + (ch & 15);
         dst[t] = (float)src[s] + (float)src[s + plane];
     }
 }
@@ -166,7 +174,7 @@ inline int grid_for(long total, int block = 256) {
 int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, const float* d_bn_scale,
                    const float* d_bn_shift, f16* out, long out_plane, int n, int h, int w, int c_out, int act,
                    float slope, hipStream_t s) {
-    if (c_out % 8) { set_error("conv_c1: c_out %d not a multiple of 8", c_out); return DISCO_ESHAPE; }
+    if (c_out % 16) { set_error("conv_c1: c_out %d not a multiple of 16", c_out); return DISCO_ESHAPE; }
     const long total = (long)n * h * w * (c_out / 8);
     hipLaunchKernelGGL(conv_c1_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale,
                        d_bn_shift, out, out_plane, n, h, w, c_out, act, slope);

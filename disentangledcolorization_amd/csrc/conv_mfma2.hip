@@ -10,11 +10,16 @@
 //     on the DMA *source* address (the LDS image of a DMA piece is lane-linear) and on the fragment read — so
 //     the 64-lane ds_read_b128 of an A fragment is bank-conflict free; stride-2 tiles are additionally
 //     de-interleaved by column parity so consecutive output pixels read consecutive LDS pixels;
+//   * activations are channel-blocked, [N][C/16][H][W][16] fp16 (hi plane, lo plane), so a tile row of one
+//     16-channel chunk is one contiguous run of 32-byte pixels: the halo DMA and the epilogue's 16-byte
+//     stores touch whole cache lines;
 //   * out-of-image halo pixels DMA from a 16-byte zero word;
 //   * 8 waves (2 per SIMD) on a 16x32-pixel x 64-channel tile where the image is large enough.
 //
 // Epilogue variants: NHWC fp16 hi/lo planes (default), fp32 NCHW (network outputs), depth-to-space
 // (ConvTranspose2d 4x4 s2 p1 expressed as a 4-phase 3x3 conv, network.py:254-258).
+#include <algorithm>
+#include <vector>
 #include "common.h"
 
 namespace disco {
@@ -76,12 +81,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     int cur_src = -1;
     const f16* src_img = nullptr;
     long src_plane = 0;
+    long src_blk = 0;               // elements per 16-channel block of one image: h*w*16
     int src_c0 = 0;
     auto setup_source = [&](int si) {
         const ConvSrc& sp = a.src[si];
         cur_src = si;
         src_img = sp.p + (size_t)n * sp.h * sp.w * sp.c;
         src_plane = sp.plane;
+        src_blk = (long)sp.h * sp.w * 16;
         src_c0 = si == 0 ? 0 : a.src[0].c;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
@@ -97,12 +104,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok && px < G::TWI; }
             const int gy = iy0 + py, gx = ix0 + px;
             const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
-            goff[i] = in ? (((gy >> sp.up) * sp.w + (gx >> sp.up)) * sp.c + kh * 8) | (plane << 30) : -1;
+            goff[i] = in ? (((gy >> sp.up) * sp.w + (gx >> sp.up)) * 16 + kh * 8) | (plane << 30) : -1;
         }
     };
 
     const int nchunks = a.c_in >> 4;
     const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)(blockIdx.y * NT) * nchunks * W_NB;
+    unsigned tmask = 0x1ffu;          // taps with non-zero weights in this workgroup's N blocks (wave-uniform)
+    if (a.tapmask) {
+        tmask = 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) tmask |= a.tapmask[blockIdx.y * NT + j];
+        tmask = __builtin_amdgcn_readfirstlane(tmask);
+    }
 
     auto issue = [&](int ck, int buf) {
         int c0 = ck << 4;
@@ -116,14 +130,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             const int piece = i * NWAVE + wave;
             if (piece < A_PIECES) {
                 const f16* gp = reinterpret_cast<const f16*>(&g_zero16);
-                if (goff[i] >= 0) gp = src_img + (goff[i] >> 30) * src_plane + (goff[i] & 0x3fffffff) + c0;
+                if (goff[i] >= 0) gp = src_img + (goff[i] >> 30) * src_plane + (goff[i] & 0x3fffffff) + (c0 >> 4) * src_blk;
                 __builtin_amdgcn_global_load_lds((gbl_void*)gp, (lds_void*)(dA + piece * 1024), 16, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int piece = i * NWAVE + wave;
-            if (piece < W_PIECES) {
+            const int qq = piece % 18;
+            if (piece < W_PIECES && ((tmask >> (qq >> 1)) & 1u)) {
                 const int nt = piece / 18, q = piece - nt * 18;
                 const char* gp = wbase + ((size_t)nt * nchunks + ck) * W_NB + q * 1024 + lane * 16;
                 __builtin_amdgcn_global_load_lds((gbl_void*)gp, (lds_void*)(dW + piece * 1024), 16, 0, 0);
@@ -154,6 +169,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         const char* sW = sA + A_BYTES;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+            if (!((tmask >> tap) & 1u)) continue;     // wave-uniform: all-zero tap (sub-pixel up-conv / deconv phases)
             const int ky = tap / 3, kx = tap % 3;
             const int tapoff = ky * G::PITCH + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
             f16x8 ah[MT], al[MT], bh[NTW], bl[NTW];
@@ -174,55 +190,128 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
+                    // weights as the row operand, pixels as the column operand: the accumulator tile is
+                    // [32 output channels][32 pixels], so a lane owns ONE pixel and 16 channels (vector stores)
                     if (X3) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
                     }
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
                 }
         }
     }
 
     // ---- epilogue: bias (+res) -> activation -> BN affine -> store ---------------------------------------------
+    // Accumulator tile layout (rows = channels, cols = pixels): this lane holds pixel (lane & 31) and channels
+    //   c(e) = (e & 3) + 8 * (e >> 2) + 4 * kh,  e = 0..15  -> four groups of 4 consecutive channels.
+    // v_permlane32_swap trades groups between the two half-waves so that the lower half ends up with channels
+    // 0-7 and 16-23 and the upper half with 8-15 and 24-31 of its pixel: 16-byte NHWC stores.
+    // activations are channel-blocked: element (n, ch, y, x) lives at ((n*C/16 + ch/16)*H*W + y*W + x)*16 + ch%16
     const int cpad = a.c_out_pad;
-    const size_t img_elems = (size_t)a.h_out * a.w_out * cpad;
-    const f16* res_img = a.res ? a.res + (size_t)n * img_elems : nullptr;
+    const bool d2s = a.d2s_c > 0;
+    const int oc = d2s ? a.d2s_c : cpad;                       // channels of the output tensor
+    const int oh = d2s ? 2 * a.h_out : a.h_out, ow = d2s ? 2 * a.w_out : a.w_out;
+    const size_t oblk = (size_t)oh * ow * 16;                  // elements per 16-channel block of one image
+    const size_t oimg = (size_t)n * oc * oh * ow;
+    const bool vec_ok = !a.out_f32 && oc % 16 == 0 && (!d2s || a.d2s_c % 32 == 0);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        const int co = (blockIdx.y * NT + wn * NTW + nt) * 32 + r;
-        const bool cok = co < a.c_out;
-        const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;     // per-channel parameters are shared by the 4 phases
-        const float bias = (cok && a.bias) ? a.bias[cpar] : 0.f;
-        const float bsc = (cok && a.bn_scale) ? a.bn_scale[cpar] : 1.f;
-        const float bsh = (cok && a.bn_shift) ? a.bn_shift[cpar] : 0.f;
+        const int cob = (blockIdx.y * NT + wn * NTW + nt) * 32;      // first channel of this N block
+        float bias[16], bsc[16], bsh[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            const bool cok = co < a.c_out;
+            const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;       // parameters are shared by the 4 deconv phases
+            bias[e] = (cok && a.bias) ? a.bias[cpar] : 0.f;
+            bsc[e] = (cok && a.bn_scale) ? a.bn_scale[cpar] : 1.f;
+            bsh[e] = (cok && a.bn_shift) ? a.bn_shift[cpar] : 0.f;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            const bool pok = oy < a.h_out && ox < a.w_out;
+            size_t pix = oimg + ((size_t)oy * ow + ox) * 16;   // + (channel/16)*oblk + channel%16
+            int cbase = cob;                  // first output-tensor channel of this N block
+            if (d2s) {                        // depth-to-space: phase ph of low-res pixel (oy,ox) -> hi-res pixel
+                const int ph = cob / a.d2s_c;
+                cbase = cob - ph * a.d2s_c;
+                pix = oimg + ((size_t)(2 * oy + (ph >> 1)) * ow + 2 * ox + (ph & 1)) * 16;
+            }
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = acc[mt][nt][e] + bias[e];
+            if (a.res && pok) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = cob + 8 * g4 + 4 * kh;
+                    if (co < a.c_out) {
+                        const int cc = cbase + 8 * g4 + 4 * kh;
+                        const f16* rp = a.res + pix + (size_t)(cc >> 4) * oblk + (cc & 15);
+                        const f16x4 rh = *reinterpret_cast<const f16x4*>(rp);
+                        const f16x4 rl = *reinterpret_cast<const f16x4*>(rp + a.res_plane);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[g4 * 4 + j] += (float)rh[j] + (float)rl[j];
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
-                const int px = m % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + m / TW;
-                const int oy = oy0 + py, ox = ox0 + px;
-                if (cok && oy < a.h_out && ox < a.w_out) {
-                    float v = acc[mt][nt][e] + bias;
-                    if (res_img) {
-                        const size_t ridx = ((size_t)oy * a.w_out + ox) * cpad + co;
-                        v += (float)res_img[ridx] + (float)res_img[ridx + a.res_plane];
+                float t = v[e];
+                if (a.act == DISCO_ACT_RELU) t = fmaxf(t, 0.f);
+                else if (a.act == DISCO_ACT_LRELU) t = t >= 0.f ? t : t * a.slope;
+                else if (a.act == DISCO_ACT_TANH) t = tanhf(t);
+                v[e] = t * bsc[e] + bsh[e];
+            }
+            if (vec_ok) {
+                // pack to fp16 pairs: dword d holds channels c(2d), c(2d+1)
+                unsigned hd[8], ld[8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const f16 h0 = (f16)v[2 * d], h1 = (f16)v[2 * d + 1];
+                    const f16 l0 = (f16)(v[2 * d] - (float)h0), l1 = (f16)(v[2 * d + 1] - (float)h1);
+                    hd[d] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    ld[d] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                // exchange: lower.(group 1) <-> upper.(group 0), lower.(group 3) <-> upper.(group 2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        auto sh = __builtin_amdgcn_permlane32_swap(hd[4 * q + d], hd[4 * q + 2 + d], false, false);
+                        hd[4 * q + d] = sh[0]; hd[4 * q + 2 + d] = sh[1];
+                        auto sl = __builtin_amdgcn_permlane32_swap(ld[4 * q + d], ld[4 * q + 2 + d], false, false);
+                        ld[4 * q + d] = sl[0]; ld[4 * q + 2 + d] = sl[1];
                     }
-                    if (a.act == DISCO_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (a.act == DISCO_ACT_LRELU) v = v >= 0.f ? v : v * a.slope;
-                    else if (a.act == DISCO_ACT_TANH) v = tanhf(v);
-                    v = v * bsc + bsh;
+                if (pok) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int co = cob + 16 * q + 8 * kh;     // 8 consecutive channels
+                        if (co < a.c_out) {
+                            const int cc = cbase + 16 * q + 8 * kh;
+                            f16* o = a.out + pix + (size_t)(cc >> 4) * oblk + (cc & 15);
+                            *reinterpret_cast<uint4*>(o) = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
+                            *reinterpret_cast<uint4*>(o + a.out_plane) = make_uint4(ld[4 * q], ld[4 * q + 1], ld[4 * q + 2], ld[4 * q + 3]);
+                        }
+                    }
+                }
+            } else if (pok) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    if (co >= a.c_out) continue;
                     if (a.out_f32) {
-                        a.out_f32[(((size_t)n * a.c_out + co) * a.h_out + oy) * a.w_out + ox] = v;
+                        a.out_f32[(((size_t)n * a.c_out + co) * a.h_out + oy) * a.w_out + ox] = v[e];
                     } else {
                         size_t idx;
-                        if (a.d2s_c > 0) {
+                        if (d2s) {
                             const int ph = co / a.d2s_c, cc = co - ph * a.d2s_c;
-                            idx = (((size_t)n * 2 * a.h_out + 2 * oy + (ph >> 1)) * 2 * a.w_out + 2 * ox + (ph & 1)) * a.d2s_c + cc;
-                        } else idx = (size_t)n * img_elems + ((size_t)oy * a.w_out + ox) * cpad + co;
-                        const f16 hi = (f16)v;
+                            idx = oimg + (size_t)(cc >> 4) * oblk + ((size_t)(2 * oy + (ph >> 1)) * ow + 2 * ox + (ph & 1)) * 16 + (cc & 15);
+                        } else idx = oimg + (size_t)(co >> 4) * oblk + ((size_t)oy * ow + ox) * 16 + (co & 15);
+                        const f16 hi = (f16)v[e];
                         a.out[idx] = hi;
-                        a.out[idx + a.out_plane] = (f16)(v - (float)hi);
+                        a.out[idx + a.out_plane] = (f16)(v[e] - (float)hi);
                     }
                 }
             }
@@ -267,6 +356,31 @@ int dispatch2(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+size_t conv3x3_packed_bytes(int c_out, int c_in_pad) {
+    return (size_t)cdiv(c_out, 32) * (c_in_pad / 16) * W_NB;
+}
+
+void conv3x3_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed) {
+    f16* dst = reinterpret_cast<f16*>(h_packed);
+    const int nb_n = cdiv(c_out, 32), nck = c_in_pad / 16;
+    for (int nb = 0; nb < nb_n; ++nb)
+        for (int ck = 0; ck < nck; ++ck)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nb * 32 + (lane & 31);
+                        const int cip = ck * 16 + (lane >> 5) * 8 + j;
+                        const int ci = ci_map ? ci_map[cip] : (cip < c_in ? cip : -1);
+                        float w = 0.f;
+                        if (co < c_out && ci >= 0) w = h_w[((size_t)co * c_in + ci) * 9 + tap];
+                        const f16 hi = (f16)w;
+                        const f16 lo = (f16)(w - (float)hi);
+                        const size_t base = (((size_t)nb * nck + ck) * 9 + tap) * 2 * 512 + lane * 8 + j;
+                        dst[base] = hi;
+                        dst[base + 512] = lo;
+                    }
+}
+
 void deconv_as_conv3x3_host(const float* w, int c_in, int c_out, float* out) {
     // out[2a+py, 2b+px] = sum_{ky,kx} in[i,j] W[ci,co,ky,kx] with 2i-1+ky = 2a+py  =>  i = a + dy where
     //   py = 0: ky = 1 -> dy = 0,  ky = 3 -> dy = -1;      py = 1: ky = 0 -> dy = +1,  ky = 2 -> dy = 0   (same in x)
@@ -288,6 +402,38 @@ void deconv_as_conv3x3_host(const float* w, int c_in, int c_out, float* out) {
             }
 }
 
+void upconv_as_conv3x3_host(const float* w, int c_in, int c_out, float* out) {
+    // hi-res output (2a+py, 2b+px) reads upsampled rows 2a+py+ky-1, i.e. low-res rows a+dy with
+    //   py = 0: ky=0 -> dy=-1, ky=1,2 -> dy=0;      py = 1: ky=0,1 -> dy=0, ky=2 -> dy=+1      (same in x)
+    const size_t total = (size_t)4 * c_out * c_in * 9;
+    std::vector<double> accd(total, 0.0);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            for (int ky = 0; ky < 3; ++ky) {
+                const int dy = (py + ky - 1) >> 1;                 // floor((py+ky-1)/2) in {-1,0,1}
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int dx = (px + kx - 1) >> 1;
+                    for (int co = 0; co < c_out; ++co)
+                        for (int ci = 0; ci < c_in; ++ci)
+                            accd[(((size_t)((py * 2 + px) * c_out + co) * c_in + ci) * 3 + (dy + 1)) * 3 + (dx + 1)] +=
+                                (double)w[(((size_t)co * c_in + ci) * 3 + ky) * 3 + kx];
+                }
+            }
+    for (size_t i = 0; i < total; ++i) out[i] = (float)accd[i];
+}
+
+void conv3x3_tapmask_host(const float* w, int c_out, int c_in, uint32_t* mask) {
+    const int nb_n = cdiv(c_out, 32);
+    for (int nb = 0; nb < nb_n; ++nb) {
+        uint32_t m = 0;
+        for (int co = nb * 32; co < std::min(c_out, nb * 32 + 32); ++co)
+            for (int ci = 0; ci < c_in; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    if (w[((size_t)co * c_in + ci) * 9 + t] != 0.f) m |= 1u << t;
+        mask[nb] = m;
+    }
+}
+
 int launch_conv3x3_v2(const ConvArgs& a, hipStream_t s) {
     if (a.stride != 1 && a.stride != 2) { set_error("conv3x3: stride %d", a.stride); return DISCO_ESHAPE; }
     if (a.c_in % 16 || a.src[0].c % 16 || (a.nsrc > 1 && a.src[1].c % 16)) {
@@ -296,7 +442,7 @@ int launch_conv3x3_v2(const ConvArgs& a, hipStream_t s) {
     }
     if (a.c_out > 32 && a.c_out % 64) { set_error("conv3x3: c_out %d (>32) must be a multiple of 64", a.c_out); return DISCO_ESHAPE; }
     for (int i = 0; i < a.nsrc; ++i)
-        if ((size_t)a.src[i].h * a.src[i].w * a.src[i].c >= (1u << 30)) {
+        if ((size_t)a.src[i].h * a.src[i].w * 16 >= (1u << 30)) {
             set_error("conv3x3: image too large for 30-bit in-image offsets");
             return DISCO_ESHAPE;
         }

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
                 float f;
                 if (ch == C) f = 1.f;
                 else if (ch < a.c_act) {
-                    const long idx = ((long)n * HW + pix) * a.c_act + ch;
+                    const long idx = (((long)n * (a.c_act >> 4) + (ch >> 4)) * HW + pix) * 16 + (ch & 15);
                     f = (float)a.feat_act[idx] + (float)a.feat_act[idx + a.feat_plane];
                 } else f = a.feat_nchw[((long)n * a.c_nchw + (ch - a.c_act)) * HW + pix];
 #pragma unroll
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ t
             f16x8 hv, lv;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { hv[j] = (f16)acc[j]; lv[j] = (f16)(acc[j] - (float)hv[j]); }
-            f16* o = out_act + pix * c + g * 8;
+            f16* o = out_act + (((long)img * (c >> 4) + (g >> 1)) * HW + p) * 16 + (g & 1) * 8;
             *reinterpret_cast<f16x8*>(o) = hv;
             *reinterpret_cast<f16x8*>(o + out_plane) = lv;
         }

@@ -138,6 +138,17 @@ class AnchorColorProb(nn.Module):
         _ffi.check(_ffi.lib().disco_profile_conv(self._ctx, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
 
+    def conv_profile_entries(self):
+        """[(layer key, ms, algorithmic FLOPs)] per MFMA conv launch of the last forward (profiling level 2)."""
+        L = _ffi.lib()
+        out, i = [], 0
+        while True:
+            key, ms, fl = C.c_char_p(), C.c_float(), C.c_double()
+            if L.disco_profile_conv_entry(self._ctx, i, C.byref(key), C.byref(ms), C.byref(fl)) != 0:
+                return out
+            out.append((key.value.decode(), ms.value, fl.value))
+            i += 1
+
     def profile(self):
         """[(stage, ms, algorithmic flops)] of the last forward (after a device sync)."""
         L = _ffi.lib()

@@ -124,11 +124,14 @@ int disco_profile_entry(disco_ctx *ctx, int i, const char **name, float *ms, dou
 /* level 2: number of conv3x3_mfma launches of the last forward, their summed duration (hipEvent pairs around
  * each launch on the forward's stream) and their summed algorithmic FLOPs (2*9*Cin*Cout*Hout*Wout*N). */
 int disco_profile_conv(disco_ctx *ctx, int *launches, float *total_ms, double *total_flops);
+/* level 2: the i-th MFMA conv launch of the last forward: checkpoint key of the layer, duration, algorithmic FLOPs */
+int disco_profile_conv_entry(disco_ctx *ctx, int i, const char **key, float *ms, double *flops);
 
 /* ---- operator-level entry points (parity tests, micro-benchmarks) ------------------- */
 
-/* Activation tensors are NHWC fp16 in two planes: hi at d_x, lo at d_x + plane_elems
- * (x ~= hi + lo, |lo| <= ulp(hi)/2).  Convert from / to the reference's fp32 NCHW: */
+/* Activation tensors are channel-blocked fp16, [N][C/16][H][W][16], in two planes: hi at d_x, lo at
+ * d_x + plane_elems (x ~= hi + lo, |lo| <= ulp(hi)/2; C padded to a multiple of 16).  Convert from / to the
+ * reference's fp32 NCHW: */
 int disco_op_nchw_to_act(const float *d_src, void *d_dst, int n, int c, int h, int w, int c_pad, void *stream);
 int disco_op_act_to_nchw(const void *d_src, float *d_dst, int n, int c, int h, int w, int c_pad, void *stream);
 

@@ -37,9 +37,12 @@ def main():
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--prec", type=int, default=0)
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
     args = ap.parse_args()
     L = _ffi.lib()
     for name, c0, c1, co, hin, stride, up0 in SHAPES:
+        if args.only and args.only not in name:
+            continue
         n = args.n
         hs = hin // 2 if up0 else hin
         src0 = torch.randn(2, n, hs, hs, c0, device="cuda").half()
