@@ -14,11 +14,16 @@
 //     16-channel chunk is one contiguous run of 32-byte pixels: the halo DMA and the epilogue's 16-byte
 //     stores touch whole cache lines;
 //   * out-of-image halo pixels DMA from a 16-byte zero word;
-//   * 8 waves (2 per SIMD) on a 16x32-pixel x 64-channel tile where the image is large enough.
+//   * 8 waves (2 per SIMD) on a 16x32-pixel x 64-channel tile where the image is large enough;
+//   * persistent workgroups: a workgroup owns one tile position (and N tile) and walks over the images of the
+//     batch; descriptors are computed once, and the DMA prefetch runs across image boundaries, so neither the
+//     launch of a workgroup nor the first DMA round trip of a tile is exposed (they cost ~30% on the 4-chunk
+//     64-channel layers).
 //
 // Epilogue variants: NHWC fp16 hi/lo planes (default), fp32 NCHW (network outputs), depth-to-space
 // (ConvTranspose2d 4x4 s2 p1 expressed as a 4-phase 3x3 conv, network.py:254-258).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "common.h"
 
@@ -69,27 +74,37 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+    const int nchunks = a.c_in >> 4;
+
+    // Persistent workgroup: blockIdx.x fixes the tile position (tx, ty) and the N tile (by); the workgroup then
+    // walks over the images n = blockIdx.y, blockIdx.y + gridDim.y, ... of the batch.  Everything that depends
+    // on the tile position (DMA descriptors, weight slice, tap mask) is computed once; per image only the
+    // source base pointer advances.
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
-    const int n = bid / tiles_y;
+    const int by = bid / tiles_y;
     const int ox0 = tx * TW, oy0 = ty * TH;
     const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
+    const int img_step = gridDim.y;
+    int n = blockIdx.y;
+    if (n >= a.n) return;
 
-    // ---- DMA descriptors: in-image element offset (plane in bit 30) or -1 (zero word) per owned unit ----------
-    int goff[APW];
-    int cur_src = -1;
-    const f16* src_img = nullptr;
-    long src_plane = 0;
-    long src_blk = 0;               // elements per 16-channel block of one image: h*w*16
-    int src_c0 = 0;
-    auto setup_source = [&](int si) {
+    unsigned tmask = 0x1ffu;          // taps with non-zero weights in this workgroup's N blocks (wave-uniform)
+    if (a.tapmask) {
+        tmask = 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) tmask |= a.tapmask[by * NT + j];
+        tmask = __builtin_amdgcn_readfirstlane(tmask);
+    }
+    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)(by * NT) * nchunks * W_NB;
+
+    // ---- DMA descriptors per source: in-image element offset (plane in bit 30) or -1 (zero word) per owned unit
+    int goff[2][APW];
+#pragma unroll
+    for (int si = 0; si < 2; ++si) {
+        if (si >= a.nsrc) break;
         const ConvSrc& sp = a.src[si];
-        cur_src = si;
-        src_img = sp.p + (size_t)n * sp.h * sp.w * sp.c;
-        src_plane = sp.plane;
-        src_blk = (long)sp.h * sp.w * 16;
-        src_c0 = si == 0 ? 0 : a.src[0].c;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int u = (i * NWAVE + wave) * 64 + lane;
@@ -104,33 +119,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok && px < G::TWI; }
             const int gy = iy0 + py, gx = ix0 + px;
             const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
-            goff[i] = in ? (((gy >> sp.up) * sp.w + (gx >> sp.up)) * 16 + kh * 8) | (plane << 30) : -1;
+            goff[si][i] = in ? (((gy >> sp.up) * sp.w + (gx >> sp.up)) * 16 + kh * 8) | (plane << 30) : -1;
         }
-    };
-
-    const int nchunks = a.c_in >> 4;
-    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)(blockIdx.y * NT) * nchunks * W_NB;
-    unsigned tmask = 0x1ffu;          // taps with non-zero weights in this workgroup's N blocks (wave-uniform)
-    if (a.tapmask) {
-        tmask = 0;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) tmask |= a.tapmask[blockIdx.y * NT + j];
-        tmask = __builtin_amdgcn_readfirstlane(tmask);
     }
+    const int c_src0 = a.src[0].c;
 
-    auto issue = [&](int ck, int buf) {
-        int c0 = ck << 4;
-        const int si = (a.nsrc > 1 && c0 >= a.src[0].c) ? 1 : 0;
-        if (si != cur_src) setup_source(si);
-        c0 -= src_c0;
+    auto issue = [&](int img, int ck, int buf) {
+        const int c0 = ck << 4;
+        const int si = (a.nsrc > 1 && c0 >= c_src0) ? 1 : 0;
+        const ConvSrc& sp = a.src[si];
+        const long blk = (long)sp.h * sp.w * 16;
+        const f16* src_blk = sp.p + (size_t)img * sp.c * sp.h * sp.w + (size_t)((c0 - (si ? c_src0 : 0)) >> 4) * blk;
         char* dA = smem + buf * BUF_BYTES;
         char* dW = dA + A_BYTES;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int piece = i * NWAVE + wave;
             if (piece < A_PIECES) {
+                const int g = si ? goff[1][i] : goff[0][i];
                 const f16* gp = reinterpret_cast<const f16*>(&g_zero16);
-                if (goff[i] >= 0) gp = src_img + (goff[i] >> 30) * src_plane + (goff[i] & 0x3fffffff) + (c0 >> 4) * src_blk;
+                if (g >= 0) gp = src_blk + (g >> 30) * sp.plane + (g & 0x3fffffff);
                 __builtin_amdgcn_global_load_lds((gbl_void*)gp, (lds_void*)(dA + piece * 1024), 16, 0, 0);
             }
         }
@@ -152,6 +160,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     const int p_lane = ((wm * MT * G::ROWS_PER_MB + loy) * STRIDE) * G::PITCH + lox;
     const int w_off = lane * 16 + wn * NTW * W_NB;
 
+    issue(n, 0, 0);
+    int buf = 0;
+
+    for (;;) {
     f32x16 acc[MT][NTW];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -160,13 +172,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    issue(0, 0);
+    const int next_n = n + img_step;
     for (int ck = 0; ck < nchunks; ++ck) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of chunk ck have landed
-        __builtin_amdgcn_s_barrier();                        // ... everyone's have; chunk ck-1's reads are finished
-        if (ck + 1 < nchunks) issue(ck + 1, (ck + 1) & 1);
-        const char* sA = smem + (ck & 1) * BUF_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of this chunk have landed
+        __builtin_amdgcn_s_barrier();                        // ... everyone's have; the previous chunk's reads are done
+        if (ck + 1 < nchunks) issue(n, ck + 1, buf ^ 1);
+        else if (next_n < a.n) issue(next_n, 0, buf ^ 1);    // prefetch across the image boundary
+        const char* sA = smem + buf * BUF_BYTES;
         const char* sW = sA + A_BYTES;
+        buf ^= 1;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             if (!((tmask >> tap) & 1u)) continue;     // wave-uniform: all-zero tap (sub-pixel up-conv / deconv phases)
@@ -186,12 +200,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                 bh[nt] = *reinterpret_cast<const f16x8*>(sW + off);
                 if (X3) bl[nt] = *reinterpret_cast<const f16x8*>(sW + off + WBLK);
             }
+            // weights as the row operand, pixels as the column operand: the accumulator tile is
+            // [32 output channels][32 pixels], so a lane owns ONE pixel and 16 channels (vector stores)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
-                    // weights as the row operand, pixels as the column operand: the accumulator tile is
-                    // [32 output channels][32 pixels], so a lane owns ONE pixel and 16 channels (vector stores)
                     if (X3) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
@@ -202,6 +216,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     }
 
     // ---- epilogue: bias (+res) -> activation -> BN affine -> store ---------------------------------------------
+    // The epilogue's inputs are invariant across the image loop; without this the compiler hoists ~100 VGPRs of
+    // per-channel parameters and lane masks out of the loop and spills.  Launder them once per image.
+    int by_e = by, oy0_e = oy0, ox0_e = ox0;
+    const float* bias_p = a.bias; const float* bsc_p = a.bn_scale; const float* bsh_p = a.bn_shift;
+    asm volatile("" : "+s"(by_e), "+s"(oy0_e), "+s"(ox0_e), "+s"(bias_p), "+s"(bsc_p), "+s"(bsh_p));
     // Accumulator tile layout (rows = channels, cols = pixels): this lane holds pixel (lane & 31) and channels
     //   c(e) = (e & 3) + 8 * (e >> 2) + 4 * kh,  e = 0..15  -> four groups of 4 consecutive channels.
     // v_permlane32_swap trades groups between the two half-waves so that the lower half ends up with channels
@@ -216,21 +235,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     const bool vec_ok = !a.out_f32 && oc % 16 == 0 && (!d2s || a.d2s_c % 32 == 0);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        const int cob = (blockIdx.y * NT + wn * NTW + nt) * 32;      // first channel of this N block
+        const int cob = (by_e * NT + wn * NTW + nt) * 32;      // first channel of this N block
         float bias[16], bsc[16], bsh[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;
             const bool cok = co < a.c_out;
             const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;       // parameters are shared by the 4 deconv phases
-            bias[e] = (cok && a.bias) ? a.bias[cpar] : 0.f;
-            bsc[e] = (cok && a.bn_scale) ? a.bn_scale[cpar] : 1.f;
-            bsh[e] = (cok && a.bn_shift) ? a.bn_shift[cpar] : 0.f;
+            bias[e] = (cok && bias_p) ? bias_p[cpar] : 0.f;
+            bsc[e] = (cok && bsc_p) ? bsc_p[cpar] : 1.f;
+            bsh[e] = (cok && bsh_p) ? bsh_p[cpar] : 0.f;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
-            const int oy = oy0 + py, ox = ox0 + px;
+            const int oy = oy0_e + py, ox = ox0_e + px;
             const bool pok = oy < a.h_out && ox < a.w_out;
             size_t pix = oimg + ((size_t)oy * ow + ox) * 16;   // + (channel/16)*oblk + channel%16
             int cbase = cob;                  // first output-tensor channel of this N block
@@ -317,6 +336,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             }
         }
     }
+
+    n = next_n;
+    if (n >= a.n) break;
+    }   // persistent loop over the images of the batch
+}
+
+inline int num_cus() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
 }
 
 template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN>
@@ -332,8 +364,12 @@ int launch_cfg2(const ConvArgs& a, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    const int tiles = cdiv(a.w_out, TW) * cdiv(a.h_out, TH) * a.n;
-    dim3 grid(tiles, cdiv(a.c_out, 32 * NT));
+    // grid.x = tile positions x N tiles; grid.y = image groups: enough groups to give every CU one persistent
+    // workgroup (LDS-limited residency), each walking n = g, g + groups, ... over the batch
+    const int combos = cdiv(a.w_out, TW) * cdiv(a.h_out, TH) * cdiv(a.c_out, 32 * NT);
+    static const int persist = [] { const char* e = getenv("DISCO_PERSIST"); return e ? atoi(e) : 1; }();
+    int groups = persist > 0 ? std::max(1, std::min(a.n, cdiv(persist * num_cus(), combos))) : a.n;
+    dim3 grid(combos, groups);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, a);
     DISCO_LAUNCH_CHECK("conv3x3_mfma2_kernel");
     return DISCO_OK;
