@@ -54,6 +54,16 @@ def cpu_baseline(sd, seconds_budget=25.0):
                       % (n, max(reps, 1), cores)}
 
 
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE; profiles/r01_pmc_traffic.json).  PMC counters cannot be read from inside a timed run."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,7 +148,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "conv3x3_mfma_kernel (all instantiations)",
                 "achieved": round(achieved / 1e12, 2), "peak": FP16_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": None,
+                "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic(),
                 "launches_per_step": conv_launches // max(args.steps, 1),
                 "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_fl / max(conv_launches, 1) / 1e9, 3),
