@@ -74,6 +74,7 @@ struct ConvArgs {
     int act;
     float slope;
     int precision;
+    int tune;           // bit 0: spread the next chunk's DMA over the 9 taps; bit 1: s_setprio around MFMA clusters
 };
 
 size_t conv3x3_packed_bytes(int c_out, int c_in_pad);

@@ -37,20 +37,23 @@ __device__ __forceinline__ void load_sum8(const f16* hi_p, long plane, float* v)
 }
 
 // ---- Cin = 1 ---------------------------------------------------------------------------------------
-// thread = (pixel, group of 8 output channels)
+// thread = (image, 16-channel block, pixel, 8-channel half) with the half fastest, then the pixel: consecutive
+// lanes write consecutive 16-byte pieces of the channel-blocked output
 __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ gray, const float* __restrict__ w,
                                                       const float* __restrict__ bias, const float* __restrict__ bsc,
                                                       const float* __restrict__ bsh, f16* out, long out_plane, int n,
                                                       int h, int wd, int c_out, int act, float slope) {
-    const int groups = c_out >> 3;
-    const long total = (long)n * h * wd * groups;
+    const int nblk = c_out >> 4;
+    const long hw = (long)h * wd;
+    const long total = (long)n * nblk * hw * 2;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(t % groups);
-        const long pix = t / groups;
-        const int x = (int)(pix % wd);
-        const int y = (int)((pix / wd) % h);
-        const long img = pix / ((long)wd * h);
-        const float* gi = gray + img * h * wd;
+        const int half = (int)(t & 1);
+        const long q = t >> 1;
+        const long p = q % hw;
+        const int blk = (int)((q / hw) % nblk);
+        const long img = q / (hw * nblk);
+        const int x = (int)(p % wd), y = (int)(p / wd);
+        const float* gi = gray + img * hw;
         float in[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int co = g * 8 + j;
+            const int co = blk * 16 + half * 8 + j;
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) s = fmaf(in[k], w[co * 9 + k], s);
@@ -71,9 +74,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
             if (bsc) s = s * bsc[co] + bsh[co];
             v[j] = s;
         }
-        // channel-blocked act: ((img*C/16 + ch/16)*H*W + y*W + x)*16 + ch%16
-        const long hw = (long)h * wd;
-        store_split8(out + ((img * (c_out >> 4) + (g >> 1)) * hw + (long)y * wd + x) * 16 + (g & 1) * 8, out_plane, v);
+        store_split8(out + t * 8, out_plane, v);   // ((img*nblk + blk)*hw + p)*16 + half*8 == t*8
     }
 }
 

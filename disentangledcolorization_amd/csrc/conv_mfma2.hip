@@ -124,7 +124,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     }
     const int c_src0 = a.src[0].c;
 
-    auto issue = [&](int img, int ck, int buf) {
+    // DMA of one chunk, split in 9 parts so the main loop can issue one part per tap, between MFMA clusters
+    // (part < 0: everything at once, used for the very first chunk)
+    constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;    // pieces per part and wave
+    auto issue = [&](int img, int ck, int buf, int part) {
         const int c0 = ck << 4;
         const int si = (a.nsrc > 1 && c0 >= c_src0) ? 1 : 0;
         const ConvSrc& sp = a.src[si];
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         char* dW = dA + A_BYTES;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
+            if (part >= 0 && i / APT != part) continue;
             const int piece = i * NWAVE + wave;
             if (piece < A_PIECES) {
                 const int g = si ? goff[1][i] : goff[0][i];
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         }
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
+            if (part >= 0 && i / WPT != part) continue;
             const int piece = i * NWAVE + wave;
             const int qq = piece % 18;
             if (piece < W_PIECES && ((tmask >> (qq >> 1)) & 1u)) {
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     const int p_lane = ((wm * MT * G::ROWS_PER_MB + loy) * STRIDE) * G::PITCH + lox;
     const int w_off = lane * 16 + wn * NTW * W_NB;
 
-    issue(n, 0, 0);
+    issue(n, 0, 0, -1);
     int buf = 0;
 
     for (;;) {
@@ -176,13 +181,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     for (int ck = 0; ck < nchunks; ++ck) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of this chunk have landed
         __builtin_amdgcn_s_barrier();                        // ... everyone's have; the previous chunk's reads are done
-        if (ck + 1 < nchunks) issue(n, ck + 1, buf ^ 1);
-        else if (next_n < a.n) issue(next_n, 0, buf ^ 1);    // prefetch across the image boundary
+        // next chunk (or the first chunk of the next image: prefetch across the image boundary)
+        const bool more = ck + 1 < nchunks;
+        const bool dma = more || next_n < a.n;
+        const int dma_img = more ? n : next_n, dma_ck = more ? ck + 1 : 0;
         const char* sA = smem + buf * BUF_BYTES;
         const char* sW = sA + A_BYTES;
         buf ^= 1;
+        const bool spread = a.tune & 1, prio = a.tune & 2;
+        if (dma && !spread) issue(dma_img, dma_ck, buf, -1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+            if (dma && spread) issue(dma_img, dma_ck, buf, tap);   // one ninth of the next chunk's DMA per tap (buf already flipped)
             if (!((tmask >> tap) & 1u)) continue;     // wave-uniform: all-zero tap (sub-pixel up-conv / deconv phases)
             const int ky = tap / 3, kx = tap % 3;
             const int tapoff = ky * G::PITCH + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             }
             // weights as the row operand, pixels as the column operand: the accumulator tile is
             // [32 output channels][32 pixels], so a lane owns ONE pixel and 16 channels (vector stores)
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                     }
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
                 }
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -470,7 +482,10 @@ void conv3x3_tapmask_host(const float* w, int c_out, int c_in, uint32_t* mask) {
     }
 }
 
-int launch_conv3x3_v2(const ConvArgs& a, hipStream_t s) {
+int launch_conv3x3_v2(const ConvArgs& a_in, hipStream_t s) {
+    static const int tune = [] { const char* e = getenv("DISCO_TUNE"); return e ? atoi(e) : 3; }();
+    ConvArgs a = a_in;
+    a.tune = tune;
     if (a.stride != 1 && a.stride != 2) { set_error("conv3x3: stride %d", a.stride); return DISCO_ESHAPE; }
     if (a.c_in % 16 || a.src[0].c % 16 || (a.nsrc > 1 && a.src[1].c % 16)) {
         set_error("conv3x3: input channels must be multiples of 16 (got %d)", a.c_in);

@@ -124,10 +124,13 @@ __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ t
     const int groups = c >> 3;
     const long total = (long)n * HW * groups;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(t % groups);
-        const long pix = t / groups;
-        const long p = pix % HW;
-        const int img = (int)(pix / HW);
+        // (image, 16-channel block, pixel, half) with half fastest: coalesced 16-byte stores in the blocked layout
+        const int half = (int)(t & 1);
+        const long q = t >> 1;
+        const long p = q % HW;
+        const int blk = (int)((q / HW) % (groups >> 1));
+        const int img = (int)(q / (HW * (groups >> 1)));
+        const int g = blk * 2 + half;
         const int y = (int)(p / W), x = (int)(p % W);
         const int cy = y / sp, cx = x / sp;
         const float* pr = prob + (long)(img / prob_rep) * 9 * HW + p;
@@ -241,7 +244,7 @@ int launch_poolfeat(const PoolArgs& a, hipStream_t s) {
 
 int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_rep, f16* out_act, long out_plane,
                   float* out_nchw, int n, int c, int h, int w, int sp, hipStream_t s) {
-    if (c % 8 == 0) {
+    if (c % 16 == 0) {
         const long total = (long)n * h * sp * w * sp * (c / 8);
         hipLaunchKernelGGL(upfeat_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, tok_layout, prob, prob_rep,
                            out_act, out_plane, out_nchw, n, c, h, w, sp);

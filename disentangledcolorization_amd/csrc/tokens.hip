@@ -225,12 +225,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 }
 
 // ---- k-means + anchors: one workgroup (256 threads) per image ---------------------------------------------------
+// The token matrix (L x 64 fp32) is staged once in LDS (row pitch 65 floats: conflict-free row-per-thread reads)
+// when it fits (L <= KM_LDS_TOKENS); larger images (no_resize path) read it from L2 with unconditional,
+// pipelined loads.  Summation orders are fixed (ascending token index), so results are run-to-run deterministic.
 constexpr int KMAX = 32;
+constexpr int KM_LDS_TOKENS = 384;
+constexpr int KM_PITCH = 65;
+template <bool XLDS>
 __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
                                                             const int32_t* __restrict__ init_idx,
                                                             const int32_t* __restrict__ fallback, int max_fallback,
                                                             int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
                                                             int32_t* info, int L, int K) {
+    extern __shared__ float dyn[];          // XLDS: [L][KM_PITCH] tokens, then [L] assignments (as int)
     __shared__ float cen[KMAX * 64];
     __shared__ float cnew[KMAX * 64];
     __shared__ int cnt[KMAX];
@@ -240,27 +247,31 @@ __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restr
     __shared__ int red_i[256];
     const int img = blockIdx.x, tid = threadIdx.x;
     const float* X = x + (size_t)img * L * 64;
+    float* xs = dyn;
+    int* asg = reinterpret_cast<int*>(dyn + (XLDS ? L * KM_PITCH : 0));
     int32_t* assign = assign_out + (size_t)img * L;
+    if (XLDS)
+        for (int u = tid; u < L * 64; u += 256) xs[(u >> 6) * KM_PITCH + (u & 63)] = X[u];
     for (int u = tid; u < K * 64; u += 256) cen[u] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
     if (tid == 0) { s_events = 0; s_stop = 0; }
     __syncthreads();
+    auto xat = [&](int t, int c) -> float { return XLDS ? xs[t * KM_PITCH + c] : X[(size_t)t * 64 + c]; };
     int passes = 0;
     while (true) {
         // assignment: first minimum of sum_c (x - c)^2
         for (int t = tid; t < L; t += 256) {
-            const float* xp = X + (size_t)t * 64;
             float best = INFINITY; int bi = 0;
             for (int j = 0; j < K; ++j) {
                 float d = 0.f;
 #pragma unroll 16
-                for (int c = 0; c < 64; ++c) { const float df = xp[c] - cen[j * 64 + c]; d = fmaf(df, df, d); }
+                for (int c = 0; c < 64; ++c) { const float df = xat(t, c) - cen[j * 64 + c]; d = fmaf(df, df, d); }
                 if (d < best) { best = d; bi = j; }
             }
-            assign[t] = bi;
+            asg[t] = bi;
         }
         if (tid < K) cnt[tid] = 0;
         __syncthreads();
-        for (int t = tid; t < L; t += 256) atomicAdd(&cnt[assign[t]], 1);
+        for (int t = tid; t < L; t += 256) atomicAdd(&cnt[asg[t]], 1);
         __syncthreads();
         // empty clusters take a fallback row, in cluster order (sequential bookkeeping by one thread)
         if (tid == 0) {
@@ -272,14 +283,15 @@ __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restr
                 }
         }
         __syncthreads();
-        // update: thread = (cluster, channel) pairs
+        // update: thread = (cluster, channel); unconditional loads so they pipeline, ascending-token sum order
         for (int u = tid; u < K * 64; u += 256) {
             const int j = u >> 6, c = u & 63;
             float s;
             if (cnt[j] < 0) s = X[(size_t)(-cnt[j] - 1) * 64 + c];
             else {
                 s = 0.f;
-                for (int t = 0; t < L; ++t) if (assign[t] == j) s += X[(size_t)t * 64 + c];
+#pragma unroll 8
+                for (int t = 0; t < L; ++t) { const float v = xat(t, c); s += (asg[t] == j) ? v : 0.f; }
                 s = s / (float)cnt[j];
             }
             cnew[u] = s;
@@ -302,6 +314,7 @@ __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restr
         __syncthreads();
         if (s_stop) break;
     }
+    for (int t = tid; t < L; t += 256) assign[t] = asg[t];
     // anchors: per cluster the first argmax of [assign==j] + sizes*0.01 (exact fp32 ops, no fma)
     const float* sz = sizes + (size_t)img * L;
     float* hm = hint_mask + (size_t)img * L;
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restr
     for (int j = 0; j < K; ++j) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int t = tid; t < L; t += 256) {
-            const float sc = __fadd_rn(assign[t] == j ? 1.f : 0.f, __fmul_rn(sz[t], 0.01f));
+            const float sc = __fadd_rn(asg[t] == j ? 1.f : 0.f, __fmul_rn(sz[t], 0.01f));
             if (sc > bv) { bv = sc; bi = t; }   // ascending t: keeps the first maximum
         }
         red_v[tid] = bv; red_i[tid] = bi;
@@ -527,8 +540,21 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
                           int l, int k, hipStream_t s) {
     if (k < 1 || k > KMAX) { set_error("kmeans: K=%d outside [1,%d]", k, KMAX); return DISCO_ESHAPE; }
     if (k > l) { set_error("kmeans: K=%d larger than %d tokens", k, l); return DISCO_ESHAPE; }
-    hipLaunchKernelGGL(kmeans_anchor_kernel, dim3(n), dim3(256), 0, s, x, sizes, init_idx, fallback_rows, max_fallback,
-                       assign, anchor, hint_mask, info, l, k);
+    if (l <= KM_LDS_TOKENS) {
+        const size_t smem = (size_t)l * KM_PITCH * sizeof(float) + (size_t)l * sizeof(int);
+        auto kern = kmeans_anchor_kernel<true>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)(KM_LDS_TOKENS * (KM_PITCH + 1) * sizeof(float))));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(n), dim3(256), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
+                           hint_mask, info, l, k);
+    } else {
+        hipLaunchKernelGGL(kmeans_anchor_kernel<false>, dim3(n), dim3(256), (size_t)l * sizeof(int), s, x, sizes, init_idx,
+                           fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
+    }
     DISCO_LAUNCH_CHECK("kmeans_anchor_kernel");
     return DISCO_OK;
 }
