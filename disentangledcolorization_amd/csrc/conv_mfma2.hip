@@ -244,7 +244,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     const int oh = d2s ? 2 * a.h_out : a.h_out, ow = d2s ? 2 * a.w_out : a.w_out;
     const size_t oblk = (size_t)oh * ow * 16;                  // elements per 16-channel block of one image
     const size_t oimg = (size_t)n * oc * oh * ow;
-    const bool vec_ok = !a.out_f32 && oc % 16 == 0 && (!d2s || a.d2s_c % 32 == 0);
+    const bool vec_ok = !a.out_f32 && oc % 16 == 0;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int cob = (by_e * NT + wn * NTW + nt) * 32;      // first channel of this N block
@@ -263,13 +263,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
             const int oy = oy0_e + py, ox = ox0_e + px;
             const bool pok = oy < a.h_out && ox < a.w_out;
-            size_t pix = oimg + ((size_t)oy * ow + ox) * 16;   // + (channel/16)*oblk + channel%16
-            int cbase = cob;                  // first output-tensor channel of this N block
-            if (d2s) {                        // depth-to-space: phase ph of low-res pixel (oy,ox) -> hi-res pixel
-                const int ph = cob / a.d2s_c;
-                cbase = cob - ph * a.d2s_c;
-                pix = oimg + ((size_t)(2 * oy + (ph >> 1)) * ow + 2 * ox + (ph & 1)) * 16;
-            }
+            // element address of output-tensor channel group starting at virtual channel cv (a multiple of 4):
+            //   plain: pixel (oy,ox), channel cv;   depth-to-space: phase ph = cv / d2s_c of low-res pixel (oy,ox)
+            //   goes to hi-res pixel (2oy + ph/2, 2ox + ph%2), channel cv % d2s_c (d2s_c is a multiple of 16)
+            auto elem = [&](int cv) -> size_t {
+                int cc = cv, yy = oy, xx = ox;
+                if (d2s) { const int ph = cv / a.d2s_c; cc = cv - ph * a.d2s_c; yy = 2 * oy + (ph >> 1); xx = 2 * ox + (ph & 1); }
+                return oimg + (size_t)(cc >> 4) * oblk + ((size_t)yy * ow + xx) * 16 + (cc & 15);
+            };
             float v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = acc[mt][nt][e] + bias[e];
@@ -278,8 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co = cob + 8 * g4 + 4 * kh;
                     if (co < a.c_out) {
-                        const int cc = cbase + 8 * g4 + 4 * kh;
-                        const f16* rp = a.res + pix + (size_t)(cc >> 4) * oblk + (cc & 15);
+                        const f16* rp = a.res + elem(co);
                         const f16x4 rh = *reinterpret_cast<const f16x4*>(rp);
                         const f16x4 rl = *reinterpret_cast<const f16x4*>(rp + a.res_plane);
 #pragma unroll
@@ -320,8 +320,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                     for (int q = 0; q < 2; ++q) {
                         const int co = cob + 16 * q + 8 * kh;     // 8 consecutive channels
                         if (co < a.c_out) {
-                            const int cc = cbase + 16 * q + 8 * kh;
-                            f16* o = a.out + pix + (size_t)(cc >> 4) * oblk + (cc & 15);
+                            f16* o = a.out + elem(co);
                             *reinterpret_cast<uint4*>(o) = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
                             *reinterpret_cast<uint4*>(o + a.out_plane) = make_uint4(ld[4 * q], ld[4 * q + 1], ld[4 * q + 2], ld[4 * q + 3]);
                         }
@@ -335,11 +334,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                     if (a.out_f32) {
                         a.out_f32[(((size_t)n * a.c_out + co) * a.h_out + oy) * a.w_out + ox] = v[e];
                     } else {
-                        size_t idx;
-                        if (d2s) {
-                            const int ph = co / a.d2s_c, cc = co - ph * a.d2s_c;
-                            idx = oimg + (size_t)(cc >> 4) * oblk + ((size_t)(2 * oy + (ph >> 1)) * ow + 2 * ox + (ph & 1)) * 16 + (cc & 15);
-                        } else idx = oimg + (size_t)(co >> 4) * oblk + ((size_t)oy * ow + ox) * 16 + (co & 15);
+                        const size_t idx = elem(co);
                         const f16 hi = (f16)v[e];
                         a.out[idx] = hi;
                         a.out[idx + a.out_plane] = (f16)(v[e] - (float)hi);

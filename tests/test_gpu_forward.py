@@ -109,6 +109,57 @@ def test_batch_invariance_at_bench_size(synth_sd):
         assert torch.equal(one[5][0], mask[i]) and torch.equal(one[2][0], pred[i])
 
 
+def test_diverse_batch_equals_per_image_runs(synth_sd):
+    """BASELINE config 5a: diverse sampling is N=1-only in the reference (model.py:148-159 expand()); batched diverse
+    is defined here as the per-image N=1 results, image-major [n][t].  K=16 clustering anchors."""
+    n, k = 4, 16
+    gray, ab = synth.synth_inputs(n, 256, 256, seed=31)
+    m = _model(synth_sd, k)
+    _seed(130)
+    pal, ref, pred, aff, spix, mask = m(gray.cuda(), ab.cuda(), True, 2)
+    torch.cuda.synchronize()
+    assert pred.shape == (3 * n, 2, 256, 256) and aff.shape[0] == 3 * n and mask.shape[0] == 3 * n
+    for i in range(n):
+        _seed(130)
+        for _ in range(i):
+            np.random.choice(256, k, replace=False)
+        one = m(gray[i:i + 1].cuda(), ab[i:i + 1].cuda(), True, 2)
+        torch.cuda.synchronize()
+        assert torch.equal(one[2], pred[3 * i:3 * i + 3]) and torch.equal(one[4], spix[3 * i:3 * i + 3])
+        assert torch.equal(one[5], mask[3 * i:3 * i + 3]) and torch.equal(one[1], ref[3 * i:3 * i + 3])
+
+
+def test_no_resize_shapes_batch(synth_sd, q_to_ab):
+    """BASELINE config 4 (--no_resize): 512x512 and 768x512 inputs (1024 / 1536 tokens); batch of 2 per shape against
+    the CPU oracle (anchors exact, ab within tolerance)."""
+    m = _model(synth_sd, 8)
+    for (h, w) in ((512, 512), (768, 512)):
+        gray, ab = synth.synth_inputs(2, h, w, seed=h + w)
+        _seed(130)
+        got = m(gray.cuda(), ab.cuda(), True, 0)
+        torch.cuda.synchronize()
+        _seed(130)
+        want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=8).forward(gray, ab)
+        assert torch.equal(got[5].cpu(), want[5]), (h, w)
+        assert _err(got[2], want[2]) <= AB_TOL and _err(got[0], want[0]) < LOGIT_TOL
+
+
+def test_random_hint_with_host_positions(synth_sd):
+    """BASELINE config 5b: random_hint with K=16 host-provided anchor positions (random.Random(130).sample)."""
+    import random as _r
+    n, k = 3, 16
+    gray, ab = synth.synth_inputs(n, 256, 256, seed=41)
+    m = _model(synth_sd, k, True)
+    rng = _r.Random(130)
+    pos = np.stack([np.asarray(rng.sample(range(256), k)) for _ in range(n)]).astype(np.int32)
+    out = m.forward_with_draws(gray.cuda(), ab.cuda(), True, 0, hint_pos=pos)
+    torch.cuda.synchronize()
+    mask = out[5].flatten(1).cpu()
+    for i in range(n):
+        assert sorted(torch.nonzero(mask[i]).flatten().tolist()) == sorted(pos[i].tolist())
+    assert torch.isfinite(out[2]).all()
+
+
 def test_precision_mode_f16x1_runs(synth_sd):
     """The hi-only mode is a speed option; it must run and stay within fp16-class error of the x3 path."""
     gray, ab = synth.synth_inputs(1, 128, 128, seed=3)
