@@ -74,7 +74,8 @@ struct ConvArgs {
     int act;
     float slope;
     int precision;
-    int tune;           // bit 0: spread the next chunk's DMA over the 9 taps; bit 1: s_setprio around MFMA clusters
+    uint32_t src_bytes[2];  // filled by the launcher: bytes addressable through each source's buffer descriptor
+    uint32_t w_bytes;       // ... and through the packed-weight descriptor
 };
 
 size_t conv3x3_packed_bytes(int c_out, int c_in_pad);

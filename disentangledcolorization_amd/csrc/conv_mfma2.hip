@@ -53,6 +53,7 @@ struct Geo2 {
 
 template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtins exist in the device pass only
     using G = Geo2<TW, TH, STRIDE>;
     constexpr int NWAVE = WM * WN;
     constexpr int MT = G::MB / WM;             // M blocks per wave
@@ -65,8 +66,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     constexpr int A_BYTES = A_PIECES * 1024;
     constexpr int W_PIECES = NT * 18;
     constexpr int BUF_BYTES = A_BYTES + W_PIECES * 1024;
-    constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;
+    constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;            // DMA pieces per wave and chunk
     constexpr int WPW = (W_PIECES + NWAVE - 1) / NWAVE;
+    constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;        // ... issued per tap
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -78,14 +80,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
 
     // Persistent workgroup: blockIdx.x fixes the tile position (tx, ty) and the N tile (by); the workgroup then
     // walks over the images n = blockIdx.y, blockIdx.y + gridDim.y, ... of the batch.  Everything that depends
-    // on the tile position (DMA descriptors, weight slice, tap mask) is computed once; per image only the
-    // source base pointer advances.
+    // on the tile position (DMA offsets, weight slice, tap mask) is computed once; per chunk only a scalar
+    // byte offset advances.
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int by = bid / tiles_y;
     const int ox0 = tx * TW, oy0 = ty * TH;
-    const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
     const int img_step = gridDim.y;
     int n = blockIdx.y;
     if (n >= a.n) return;
@@ -97,42 +98,48 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         for (int j = 0; j < NT; ++j) tmask |= a.tapmask[by * NT + j];
         tmask = __builtin_amdgcn_readfirstlane(tmask);
     }
-    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)(by * NT) * nchunks * W_NB;
 
-    // ---- DMA descriptors per source: in-image element offset (plane in bit 30) or -1 (zero word) per owned unit
-    int goff[2][APW];
+    // ---- LDS-DMA through raw buffer descriptors: address = base + soffset(chunk, image) + voffset(lane); a lane
+    // whose voffset is out of range reads 0 (hardware range check) = the conv's zero padding ----------------------
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[0].p, 0, a.src_bytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[a.nsrc > 1 ? 1 : 0].p, 0, a.src_bytes[a.nsrc > 1 ? 1 : 0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    unsigned voff[2][APW];            // per source: byte offset (plane included) of this lane's 16 bytes, or OOB
+    {
+        const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
 #pragma unroll
-    for (int si = 0; si < 2; ++si) {
-        if (si >= a.nsrc) break;
-        const ConvSrc& sp = a.src[si];
+        for (int si = 0; si < 2; ++si) {
+            const ConvSrc& sp = a.src[si < a.nsrc ? si : 0];
 #pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            const int u = (i * NWAVE + wave) * 64 + lane;
-            const int plane = u / (G::NPIX * 2);
-            const int rem = u - plane * (G::NPIX * 2);
-            const int p = rem >> 1, j = rem & 1;
-            const int kh = j ^ ((p >> 3) & 1);
-            const int py = p / G::PITCH, q = p - py * G::PITCH;
-            int px;
-            bool slot_ok = u < A_UNITS;
-            if (STRIDE == 1) px = q;
-            else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok && px < G::TWI; }
-            const int gy = iy0 + py, gx = ix0 + px;
-            const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
-            goff[si][i] = in ? (((gy >> sp.up) * sp.w + (gx >> sp.up)) * 16 + kh * 8) | (plane << 30) : -1;
+            for (int i = 0; i < APW; ++i) {
+                const int u = (i * NWAVE + wave) * 64 + lane;
+                const int plane = u / (G::NPIX * 2);
+                const int rem = u - plane * (G::NPIX * 2);
+                const int p = rem >> 1, j = rem & 1;
+                const int kh = j ^ ((p >> 3) & 1);
+                const int py = p / G::PITCH, q = p - py * G::PITCH;
+                int px;
+                bool slot_ok = u < A_UNITS;
+                if (STRIDE == 1) px = q;
+                else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok && px < G::TWI; }
+                const int gy = iy0 + py, gx = ix0 + px;
+                const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
+                voff[si][i] = in ? (unsigned)(plane * sp.plane + ((gy >> sp.up) * sp.w + (gx >> sp.up)) * 16 + kh * 8) * 2u : OOB;
+            }
         }
     }
     const int c_src0 = a.src[0].c;
+    const unsigned img_b0 = (unsigned)(a.src[0].c * a.src[0].h * a.src[0].w) * 2u, blk_b0 = (unsigned)(a.src[0].h * a.src[0].w) * 32u;
+    const unsigned img_b1 = (unsigned)(a.src[1].c * a.src[1].h * a.src[1].w) * 2u, blk_b1 = (unsigned)(a.src[1].h * a.src[1].w) * 32u;
+    const unsigned w_tile_b = (unsigned)(by * NT) * (unsigned)nchunks * W_NB, w_nt_b = (unsigned)nchunks * W_NB;
 
-    // DMA of one chunk, split in 9 parts so the main loop can issue one part per tap, between MFMA clusters
-    // (part < 0: everything at once, used for the very first chunk)
-    constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;    // pieces per part and wave
+    // one ninth (part 0..8) of the DMA of chunk `ck` of image `img` into LDS buffer `buf`; part < 0: all of it
     auto issue = [&](int img, int ck, int buf, int part) {
         const int c0 = ck << 4;
-        const int si = (a.nsrc > 1 && c0 >= c_src0) ? 1 : 0;
-        const ConvSrc& sp = a.src[si];
-        const long blk = (long)sp.h * sp.w * 16;
-        const f16* src_blk = sp.p + (size_t)img * sp.c * sp.h * sp.w + (size_t)((c0 - (si ? c_src0 : 0)) >> 4) * blk;
+        const bool s1 = a.nsrc > 1 && c0 >= c_src0;
+        const unsigned soff = s1 ? (unsigned)img * img_b1 + (unsigned)((c0 - c_src0) >> 4) * blk_b1
+                                 : (unsigned)img * img_b0 + (unsigned)(c0 >> 4) * blk_b0;
         char* dA = smem + buf * BUF_BYTES;
         char* dW = dA + A_BYTES;
 #pragma unroll
@@ -140,22 +147,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             if (part >= 0 && i / APT != part) continue;
             const int piece = i * NWAVE + wave;
             if (piece < A_PIECES) {
-                const int g = si ? goff[1][i] : goff[0][i];
-                const f16* gp = reinterpret_cast<const f16*>(&g_zero16);
-                if (g >= 0) gp = src_blk + (g >> 30) * sp.plane + (g & 0x3fffffff);
-                __builtin_amdgcn_global_load_lds((gbl_void*)gp, (lds_void*)(dA + piece * 1024), 16, 0, 0);
+                if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(dA + piece * 1024), 16, voff[1][i], soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(dA + piece * 1024), 16, voff[0][i], soff, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             if (part >= 0 && i / WPT != part) continue;
             const int piece = i * NWAVE + wave;
-            const int qq = piece % 18;
-            if (piece < W_PIECES && ((tmask >> (qq >> 1)) & 1u)) {
-                const int nt = piece / 18, q = piece - nt * 18;
-                const char* gp = wbase + ((size_t)nt * nchunks + ck) * W_NB + q * 1024 + lane * 16;
-                __builtin_amdgcn_global_load_lds((gbl_void*)gp, (lds_void*)(dW + piece * 1024), 16, 0, 0);
-            }
+            const int nt = piece / 18, q = piece - nt * 18;
+            if (piece < W_PIECES && ((tmask >> (q >> 1)) & 1u))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(dW + piece * 1024), 16, lane * 16,
+                                                         w_tile_b + (unsigned)nt * w_nt_b + (unsigned)ck * W_NB + q * 1024, 0, 0);
         }
     };
 
@@ -188,11 +191,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         const char* sA = smem + buf * BUF_BYTES;
         const char* sW = sA + A_BYTES;
         buf ^= 1;
-        const bool spread = a.tune & 1, prio = a.tune & 2;
-        if (dma && !spread) issue(dma_img, dma_ck, buf, -1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (dma && spread) issue(dma_img, dma_ck, buf, tap);   // one ninth of the next chunk's DMA per tap (buf already flipped)
+            if (dma) issue(dma_img, dma_ck, buf, tap);   // one ninth of the next chunk's DMA per tap (buf already flipped)
             if (!((tmask >> tap) & 1u)) continue;     // wave-uniform: all-zero tap (sub-pixel up-conv / deconv phases)
             const int ky = tap / 3, kx = tap % 3;
             const int tapoff = ky * G::PITCH + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             }
             // weights as the row operand, pixels as the column operand: the accumulator tile is
             // [32 output channels][32 pixels], so a lane owns ONE pixel and 16 channels (vector stores)
-            if (prio) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                     }
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
                 }
-            if (prio) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     n = next_n;
     if (n >= a.n) break;
     }   // persistent loop over the images of the batch
+#endif
 }
 
 inline int num_cus() {
@@ -478,9 +480,20 @@ void conv3x3_tapmask_host(const float* w, int c_out, int c_in, uint32_t* mask) {
 }
 
 int launch_conv3x3_v2(const ConvArgs& a_in, hipStream_t s) {
-    static const int tune = [] { const char* e = getenv("DISCO_TUNE"); return e ? atoi(e) : 3; }();
     ConvArgs a = a_in;
-    a.tune = tune;
+    // raw buffer descriptors address at most 4 GiB: tensor bytes (hi + lo plane) per source
+    for (int i = 0; i < 2; ++i) {
+        const ConvSrc& sp = a.src[i < a.nsrc ? i : 0];
+        const size_t bytes = ((size_t)sp.plane + (size_t)a.n * sp.c * sp.h * sp.w) * sizeof(f16);
+        if (bytes >= ((size_t)1 << 32)) { set_error("conv3x3: activation tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", bytes); return DISCO_ESHAPE; }
+        a.src_bytes[i] = (uint32_t)bytes;
+        if (i >= a.nsrc) a.src[i] = a.src[0];
+    }
+    {
+        const size_t wb = conv3x3_packed_bytes(a.c_out, a.c_in);
+        if (wb >= ((size_t)1 << 32)) { set_error("conv3x3: packed weights too large"); return DISCO_ESHAPE; }
+        a.w_bytes = (uint32_t)wb;
+    }
     if (a.stride != 1 && a.stride != 2) { set_error("conv3x3: stride %d", a.stride); return DISCO_ESHAPE; }
     if (a.c_in % 16 || a.src[0].c % 16 || (a.nsrc > 1 && a.src[1].c % 16)) {
         set_error("conv3x3: input channels must be multiples of 16 (got %d)", a.c_in);
