@@ -116,17 +116,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        # event queries need the step finished; the sync is part of the per-step pipeline cost we report
-        torch.cuda.synchronize()
-        nl, ms, fl = model.conv_profile()
-        conv_launches += nl; conv_ms += ms; conv_fl += fl
-        for name, sms, _ in model.profile():
-            stage_ms[name] = stage_ms.get(name, 0.0) + sms
+        step()          # asynchronous: no host sync inside the timed region; every conv launch is event-bracketed
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # per-launch hipEvent timings of the LAST timed step (the context keeps the events of its latest forward)
+    nl, ms, fl = model.conv_profile()
+    conv_launches, conv_ms, conv_fl = nl * args.steps, ms * args.steps, fl * args.steps
+    for name, sms, _ in model.profile():
+        stage_ms[name] = sms * args.steps
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -167,6 +167,11 @@ struct disco_ctx {
     float* d_enc[2] = {nullptr, nullptr};
     float* d_mid_w = nullptr; float* d_emb_w = nullptr; float* d_trg_w = nullptr; float* d_q_to_ab = nullptr;
     std::map<std::pair<int, int>, float*> pos_cache;
+    // pinned staging ring for the small host->device index arrays of disco_forward: a pageable hipMemcpyAsync
+    // blocks the host until the stream reaches the copy, which would stop the host from running ahead
+    struct Staging { void* h = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+    Staging stg[4];
+    int stg_next = 0;
     int profiling = 0;
     std::vector<ProfEntry> prof;
     struct ConvProf { hipEvent_t e0, e1; double flops; std::string key; };
@@ -192,6 +197,25 @@ template <class T>
 int upload_vec(disco_ctx* c, const std::vector<T>& v, T** out) { return upload(c, v.data(), v.size() * sizeof(T), (void**)out); }
 
 const HostTensor& T(disco_ctx* c, const std::string& k) { return c->sd.at(k); }
+
+// asynchronous host->device copy of a small array through the context's pinned staging ring
+int staged_h2d(disco_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    disco_ctx::Staging& g = c->stg[c->stg_next];
+    c->stg_next = (c->stg_next + 1) % 4;
+    if (g.used) DISCO_HIP_CHECK(hipEventSynchronize(g.ev));       // its previous copy has been consumed
+    if (g.cap < bytes) {
+        if (g.h) DISCO_HIP_CHECK(hipHostFree(g.h));
+        g.h = nullptr; g.cap = 0;
+        DISCO_HIP_CHECK(hipHostMalloc(&g.h, bytes, hipHostMallocDefault));
+        g.cap = bytes;
+    }
+    if (!g.ev) DISCO_HIP_CHECK(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+    memcpy(g.h, h_src, bytes);
+    DISCO_HIP_CHECK(hipMemcpyAsync(d_dst, g.h, bytes, hipMemcpyHostToDevice, s));
+    DISCO_HIP_CHECK(hipEventRecord(g.ev, s));
+    g.used = true;
+    return DISCO_OK;
+}
 
 int run_conv(const ConvArgs& ca, hipStream_t s) { return launch_conv3x3_v2(ca, s); }
 
@@ -550,15 +574,15 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
         if (c->opt.random_hint) {
             if (!a->h_hint_pos) { set_error("random_hint context needs h_hint_pos"); P.rc = DISCO_EINVAL; }
             else {
-                if (hipMemcpyAsync(d_idx, a->h_hint_pos, (size_t)n * K * 4, hipMemcpyHostToDevice, s) != hipSuccess) P.rc = DISCO_EHIP;
+                P.rc = staged_h2d(c, d_idx, a->h_hint_pos, (size_t)n * K * 4, s);
                 if (P.ok()) P.rc = launch_hint_mask_from_pos(d_idx, a->d_hint_mask, n, L, K, s);
                 if (P.ok() && hipMemsetAsync(d_info, 0, (size_t)n * 8, s) != hipSuccess) P.rc = DISCO_EHIP;
             }
         } else {
             if (!a->h_init_idx) { set_error("clustering context needs h_init_idx"); P.rc = DISCO_EINVAL; }
             else {
-                if (hipMemcpyAsync(d_idx, a->h_init_idx, (size_t)n * K * 4, hipMemcpyHostToDevice, s) != hipSuccess) P.rc = DISCO_EHIP;
-                if (P.ok() && mf && hipMemcpyAsync(d_fb, a->h_fallback_rows, (size_t)n * mf * 4, hipMemcpyHostToDevice, s) != hipSuccess) P.rc = DISCO_EHIP;
+                P.rc = staged_h2d(c, d_idx, a->h_init_idx, (size_t)n * K * 4, s);
+                if (P.ok() && mf) P.rc = staged_h2d(c, d_fb, a->h_fallback_rows, (size_t)n * mf * 4, s);
                 if (P.ok()) P.rc = launch_kmeans_anchors(enc, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s);
             }
         }
@@ -679,6 +703,7 @@ int disco_destroy(disco_ctx* c) {
     hipSetDevice(c->device);
     for (auto& e : c->prof) hipEventDestroy(e.ev);
     for (auto& e : c->conv_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+    for (auto& g : c->stg) { if (g.ev) hipEventDestroy(g.ev); if (g.h) hipHostFree(g.h); }
     for (void* p : c->allocs) hipFree(p);
     delete c;
     return DISCO_OK;

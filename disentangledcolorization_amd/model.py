@@ -57,6 +57,7 @@ class AnchorColorProb(nn.Module):
         self._ctx = None
         self._ctx_device = None
         self._workspace = None
+        self._ws_need = {}
         self._keep = None
         if init_weights:
             from .synth import synth_state_dict
@@ -176,7 +177,9 @@ class AnchorColorProb(nn.Module):
         """The next `count` values torch.randint(l,(1,)) would return, without consuming them."""
         g = torch.Generator()
         g.set_state(torch.get_rng_state())
-        return [int(torch.randint(l, (1,), generator=g)) for _ in range(count)]
+        # one vectorised draw yields the same values as `count` successive randint(l,(1,)) calls on the CPU
+        # generator (checked in tests/test_abi_cpu.py::test_peek_randint_matches_sequential_draws)
+        return torch.randint(l, (count,), generator=g).tolist()
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, input_grays, input_colors, test_mode=False, sampled_T=0):
@@ -216,11 +219,15 @@ class AnchorColorProb(nn.Module):
             aff = torch.empty(n, 9, H, W, **f32)
             spix = torch.empty(n2, 2, h, w, **f32)
             mask = torch.empty(n, 1, h, w, **f32)
-            need = C.c_size_t()
-            _ffi.check(L.disco_workspace_bytes(ctx, n, H, W, T, C.byref(need)))
-            if self._workspace is None or self._workspace.numel() < need.value or self._workspace.device != dev:
+            ws_key = (n, H, W, T > 0)
+            if ws_key not in self._ws_need:
+                need = C.c_size_t()
+                _ffi.check(L.disco_workspace_bytes(ctx, n, H, W, T, C.byref(need)))
+                self._ws_need[ws_key] = need.value
+            need_bytes = self._ws_need[ws_key]
+            if self._workspace is None or self._workspace.numel() < need_bytes or self._workspace.device != dev:
                 self._workspace = None
-                self._workspace = torch.empty(need.value, device=dev, dtype=torch.uint8)
+                self._workspace = torch.empty(need_bytes, device=dev, dtype=torch.uint8)
             a = _ffi.ForwardArgs()
             a.n, a.h, a.w, a.sampled_T = n, H, W, T
             a.d_gray, a.d_ab = gray.data_ptr(), ab.data_ptr()
@@ -240,14 +247,13 @@ class AnchorColorProb(nn.Module):
                 MAX_FALLBACK = KMEANS_ITERS * self.hint_num
                 a.h_init_idx = init_idx.ctypes.data
                 a.max_fallback = MAX_FALLBACK
-                draws = self._peek_randint(l, MAX_FALLBACK * 2)
+                draws = np.asarray(self._peek_randint(l, MAX_FALLBACK * 2), dtype=np.int32)
                 bases = [0] * n
                 events = np.zeros(n, np.int32)
                 for _ in range(n + 1):
                     while len(draws) < max(bases) + MAX_FALLBACK:
-                        draws = self._peek_randint(l, len(draws) * 2)
-                    rows = np.ascontiguousarray(
-                        np.asarray([draws[b:b + MAX_FALLBACK] for b in bases], dtype=np.int32))
+                        draws = np.asarray(self._peek_randint(l, len(draws) * 2), dtype=np.int32)
+                    rows = np.ascontiguousarray(draws[np.asarray(bases)[:, None] + np.arange(MAX_FALLBACK)[None, :]])
                     a.h_fallback_rows = rows.ctypes.data
                     a.h_kmeans_events = events.ctypes.data if self.sync_kmeans_events else None
                     _ffi.check(L.disco_forward(ctx, C.byref(a)))

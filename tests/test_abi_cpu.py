@@ -83,6 +83,17 @@ def test_forward_refuses_cpu_tensors(synth_sd):
         m(torch.zeros(1, 1, 32, 32), torch.zeros(1, 2, 32, 32), True, 0)
 
 
+def test_peek_randint_matches_sequential_draws():
+    """model._peek_randint must predict exactly what the reference's torch.randint(len(X),(1,)) calls would draw."""
+    from disentangledcolorization_amd.model import AnchorColorProb
+
+    for l in (96, 256, 1536):
+        torch.manual_seed(11)
+        peek = AnchorColorProb._peek_randint(l, 40)
+        seq = [int(torch.randint(l, (1,))) for _ in range(40)]
+        assert peek == seq
+
+
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure: no import / include / dlopen of it anywhere in the product package."""
     pkg = os.path.join(REPO, "disentangledcolorization_amd")
