@@ -69,6 +69,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;            // DMA pieces per wave and chunk
     constexpr int WPW = (W_PIECES + NWAVE - 1) / NWAVE;
     constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;        // ... issued per tap
+    constexpr int PAR_OFF = 2 * BUF_BYTES;                         // epilogue parameters: [3][32*NT] floats
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -98,6 +99,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         for (int j = 0; j < NT; ++j) tmask |= a.tapmask[by * NT + j];
         tmask = __builtin_amdgcn_readfirstlane(tmask);
     }
+
+    // per-channel epilogue parameters of this workgroup's N tile -> LDS, once (the workgroup is persistent), so the
+    // epilogue issues no global loads it would have to wait for
+    float* s_par = reinterpret_cast<float*>(smem + PAR_OFF);
+    for (int i = tid; i < 3 * 32 * NT; i += NWAVE * 64) {
+        const int which = i / (32 * NT), c = i - which * (32 * NT);
+        const int co = by * NT * 32 + c;
+        const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;         // parameters are shared by the 4 deconv phases
+        const float* src = which == 0 ? a.bias : (which == 1 ? a.bn_scale : a.bn_shift);
+        s_par[i] = (src && co < a.c_out) ? src[cpar] : (which == 1 ? 1.f : 0.f);
+    }
+    // (visible to all waves after the first chunk's barrier)
 
     // ---- LDS-DMA through raw buffer descriptors: address = base + soffset(chunk, image) + voffset(lane); a lane
     // whose voffset is out of range reads 0 (hardware range check) = the conv's zero padding ----------------------
@@ -232,12 +245,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     // The epilogue's inputs are invariant across the image loop; without this the compiler hoists ~100 VGPRs of
     // per-channel parameters and lane masks out of the loop and spills.  Launder them once per image.
     int by_e = by, oy0_e = oy0, ox0_e = ox0;
-    const float* bias_p = a.bias; const float* bsc_p = a.bn_scale; const float* bsh_p = a.bn_shift;
-    asm volatile("" : "+s"(by_e), "+s"(oy0_e), "+s"(ox0_e), "+s"(bias_p), "+s"(bsc_p), "+s"(bsh_p));
-    // Accumulator tile layout (rows = channels, cols = pixels): this lane holds pixel (lane & 31) and channels
-    //   c(e) = (e & 3) + 8 * (e >> 2) + 4 * kh,  e = 0..15  -> four groups of 4 consecutive channels.
-    // v_permlane32_swap trades groups between the two half-waves so that the lower half ends up with channels
-    // 0-7 and 16-23 and the upper half with 8-15 and 24-31 of its pixel: 16-byte NHWC stores.
+    const float* par_e = s_par;
+    asm volatile("" : "+s"(by_e), "+s"(oy0_e), "+s"(ox0_e), "+v"(par_e));
     // activations are channel-blocked: element (n, ch, y, x) lives at ((n*C/16 + ch/16)*H*W + y*W + x)*16 + ch%16
     const int cpad = a.c_out_pad;
     const bool d2s = a.d2s_c > 0;
@@ -251,13 +260,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         const int cob = (by_e * NT + wn * NTW + nt) * 32;      // first channel of this N block
         float bias[16], bsc[16], bsh[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            const bool cok = co < a.c_out;
-            const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;       // parameters are shared by the 4 deconv phases
-            bias[e] = (cok && bias_p) ? bias_p[cpar] : 0.f;
-            bsc[e] = (cok && bsc_p) ? bsc_p[cpar] : 1.f;
-            bsh[e] = (cok && bsh_p) ? bsh_p[cpar] : 0.f;
+        for (int g4 = 0; g4 < 4; ++g4) {                        // channels c(e) = (e&3) + 8*(e>>2) + 4*kh: 4 groups of 4
+            const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
+            const float4 b4 = *reinterpret_cast<const float4*>(par_e + cl);
+            const float4 s4 = *reinterpret_cast<const float4*>(par_e + 32 * NT + cl);
+            const float4 h4 = *reinterpret_cast<const float4*>(par_e + 64 * NT + cl);
+            bias[g4 * 4] = b4.x; bias[g4 * 4 + 1] = b4.y; bias[g4 * 4 + 2] = b4.z; bias[g4 * 4 + 3] = b4.w;
+            bsc[g4 * 4] = s4.x; bsc[g4 * 4 + 1] = s4.y; bsc[g4 * 4 + 2] = s4.z; bsc[g4 * 4 + 3] = s4.w;
+            bsh[g4 * 4] = h4.x; bsh[g4 * 4 + 1] = h4.y; bsh[g4 * 4 + 2] = h4.z; bsh[g4 * 4 + 3] = h4.w;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -364,7 +374,7 @@ template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN>
 int launch_cfg2(const ConvArgs& a, hipStream_t s) {
     using G = Geo2<TW, TH, STRIDE>;
     constexpr int A_BYTES = (((X3 ? 2 : 1) * G::NPIX * 2 + 63) / 64) * 1024;
-    constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024);
+    constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_mfma2_kernel<TW, TH, NT, STRIDE, X3, WM, WN>;
     static bool attr_set = false;
