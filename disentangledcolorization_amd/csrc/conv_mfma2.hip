@@ -183,6 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
 
     issue(n, 0, 0, -1);
     int buf = 0;
+    bool dma_waited = false;      // the first chunk's DMA wait of the next image is taken before the epilogue
 
     for (;;) {
     f32x16 acc[MT][NTW];
@@ -195,7 +196,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
 
     const int next_n = n + img_step;
     for (int ck = 0; ck < nchunks; ++ck) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of this chunk have landed
+        // my DMA pieces of this chunk have landed (vmcnt also counts stores: for the first chunk of an image the
+        // wait was already taken BEFORE the previous image's epilogue stores were issued, so those stores drain
+        // under this chunk's MFMAs instead of stalling here)
+        if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // ... everyone's have; the previous chunk's reads are done
         // next chunk (or the first chunk of the next image: prefetch across the image boundary)
         const bool more = ck + 1 < nchunks;
@@ -242,8 +246,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     }
 
     // ---- epilogue: bias (+res) -> activation -> BN affine -> store ---------------------------------------------
-    // The epilogue's inputs are invariant across the image loop; without this the compiler hoists ~100 VGPRs of
-    // per-channel parameters and lane masks out of the loop and spills.  Launder them once per image.
+    // Three phases: (1) all the math, in registers (results replace the accumulators); (2) wait for the next
+    // image's first chunk, whose DMA was issued during the last chunk - its latency hides behind phase 1;
+    // (3) the stores.  vmcnt also counts stores, so with the wait taken here the stores of this image drain
+    // under the next image's first chunk instead of stalling its first barrier.
+    // The epilogue's inputs are invariant across the image loop; without laundering them the compiler hoists
+    // ~100 VGPRs of per-channel parameters and lane masks out of the loop and spills.
     int by_e = by, oy0_e = oy0, ox0_e = ox0;
     const float* par_e = s_par;
     asm volatile("" : "+s"(by_e), "+s"(oy0_e), "+s"(ox0_e), "+v"(par_e));
@@ -255,6 +263,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     const size_t oblk = (size_t)oh * ow * 16;                  // elements per 16-channel block of one image
     const size_t oimg = (size_t)n * oc * oh * ow;
     const bool vec_ok = !a.out_f32 && oc % 16 == 0;
+    // element address of output-tensor channel group starting at virtual channel cv (a multiple of 4) of low-res /
+    // plain pixel (oy,ox): plain: channel cv; depth-to-space: phase ph = cv / d2s_c goes to hi-res pixel
+    // (2oy + ph/2, 2ox + ph%2), channel cv % d2s_c (d2s_c is a multiple of 16)
+    auto elem = [&](int cv, int oy, int ox) -> size_t {
+        int cc = cv, yy = oy, xx = ox;
+        if (d2s) { const int ph = cv / a.d2s_c; cc = cv - ph * a.d2s_c; yy = 2 * oy + (ph >> 1); xx = 2 * ox + (ph & 1); }
+        return oimg + (size_t)(cc >> 4) * oblk + ((size_t)yy * ow + xx) * 16 + (cc & 15);
+    };
+    // ---- phase 1: math ----
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int cob = (by_e * NT + wn * NTW + nt) * 32;      // first channel of this N block
@@ -274,14 +291,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
             const int oy = oy0_e + py, ox = ox0_e + px;
             const bool pok = oy < a.h_out && ox < a.w_out;
-            // element address of output-tensor channel group starting at virtual channel cv (a multiple of 4):
-            //   plain: pixel (oy,ox), channel cv;   depth-to-space: phase ph = cv / d2s_c of low-res pixel (oy,ox)
-            //   goes to hi-res pixel (2oy + ph/2, 2ox + ph%2), channel cv % d2s_c (d2s_c is a multiple of 16)
-            auto elem = [&](int cv) -> size_t {
-                int cc = cv, yy = oy, xx = ox;
-                if (d2s) { const int ph = cv / a.d2s_c; cc = cv - ph * a.d2s_c; yy = 2 * oy + (ph >> 1); xx = 2 * ox + (ph & 1); }
-                return oimg + (size_t)(cc >> 4) * oblk + ((size_t)yy * ow + xx) * 16 + (cc & 15);
-            };
             float v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = acc[mt][nt][e] + bias[e];
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co = cob + 8 * g4 + 4 * kh;
                     if (co < a.c_out) {
-                        const f16* rp = a.res + elem(co);
+                        const f16* rp = a.res + elem(co, oy, ox);
                         const f16x4 rh = *reinterpret_cast<const f16x4*>(rp);
                         const f16x4 rl = *reinterpret_cast<const f16x4*>(rp + a.res_plane);
 #pragma unroll
@@ -316,7 +325,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                     hd[d] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
                     ld[d] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
                 }
-                // exchange: lower.(group 1) <-> upper.(group 0), lower.(group 3) <-> upper.(group 2)
+                // v_permlane32_swap: lower.(group 1) <-> upper.(group 0), lower.(group 3) <-> upper.(group 2), so the
+                // lower half-wave holds channels 0-7 and 16-23 of its pixel, the upper half 8-15 and 24-31
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -326,29 +336,53 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                         auto sl = __builtin_amdgcn_permlane32_swap(ld[4 * q + d], ld[4 * q + 2 + d], false, false);
                         ld[4 * q + d] = sl[0]; ld[4 * q + 2 + d] = sl[1];
                     }
-                if (pok) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int co = cob + 16 * q + 8 * kh;     // 8 consecutive channels
-                        if (co < a.c_out) {
-                            f16* o = a.out + elem(co);
-                            *reinterpret_cast<uint4*>(o) = make_uint4(hd[4 * q], hd[4 * q + 1], hd[4 * q + 2], hd[4 * q + 3]);
-                            *reinterpret_cast<uint4*>(o + a.out_plane) = make_uint4(ld[4 * q], ld[4 * q + 1], ld[4 * q + 2], ld[4 * q + 3]);
-                        }
+                for (int d = 0; d < 8; ++d) {     // park the packed words in the accumulator registers
+                    acc[mt][nt][d] = __builtin_bit_cast(float, hd[d]);
+                    acc[mt][nt][8 + d] = __builtin_bit_cast(float, ld[d]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = v[e];
+            }
+        }
+    }
+    // ---- phase 2: the next image's first chunk has landed ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dma_waited = true;
+    // ---- phase 3: stores ----
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int cob = (by_e * NT + wn * NTW + nt) * 32;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
+            const int oy = oy0_e + py, ox = ox0_e + px;
+            if (!(oy < a.h_out && ox < a.w_out)) continue;
+            if (vec_ok) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int co = cob + 16 * q + 8 * kh;     // 8 consecutive channels
+                    if (co < a.c_out) {
+                        f16* o = a.out + elem(co, oy, ox);
+                        const f32x16& t = acc[mt][nt];
+                        *reinterpret_cast<float4*>(o) = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+                        *reinterpret_cast<float4*>(o + a.out_plane) = make_float4(t[8 + 4 * q], t[8 + 4 * q + 1], t[8 + 4 * q + 2], t[8 + 4 * q + 3]);
                     }
                 }
-            } else if (pok) {
+            } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;
                     if (co >= a.c_out) continue;
+                    const float val = acc[mt][nt][e];
                     if (a.out_f32) {
-                        a.out_f32[(((size_t)n * a.c_out + co) * a.h_out + oy) * a.w_out + ox] = v[e];
+                        a.out_f32[(((size_t)n * a.c_out + co) * a.h_out + oy) * a.w_out + ox] = val;
                     } else {
-                        const size_t idx = elem(co);
-                        const f16 hi = (f16)v[e];
+                        const size_t idx = elem(co, oy, ox);
+                        const f16 hi = (f16)val;
                         a.out[idx] = hi;
-                        a.out[idx + a.out_plane] = (f16)(v[e] - (float)hi);
+                        a.out[idx + a.out_plane] = (f16)(val - (float)hi);
                     }
                 }
             }
