@@ -20,7 +20,7 @@ class DiscoError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("sp_size", C.c_int32), ("n_clusters", C.c_int32), ("random_hint", C.c_int32),
-                ("precision", C.c_int32)]
+                ("precision", C.c_int32), ("segnet_only", C.c_int32)]
 
 
 class ForwardArgs(C.Structure):
@@ -55,6 +55,7 @@ SIGNATURES = {
     "disco_expected_tensor": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(_I)]),
     "disco_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "disco_forward": (_I, [_P, C.POINTER(ForwardArgs)]),
+    "disco_forward_segnet": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "disco_sync": (_I, [_P]),
     "disco_set_profiling": (_I, [_P, _I]),
     "disco_profile_count": (_I, [_P]),
@@ -75,6 +76,9 @@ SIGNATURES = {
     "disco_op_select_colors": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "disco_op_nearest_bin": (_I, [_P, _P, _I, _I, _P]),
     "disco_op_position_encoding": (_I, [_P, _I, _I, _P]),
+    "disco_op_decode_ind2ab": (_I, [_P, _P, _I, _I, _I, _P]),
+    "disco_op_rgb2lab": (_I, [_P, _P, _I, _I, _I, _P]),
+    "disco_op_lab2rgb": (_I, [_P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -1,0 +1,125 @@
+"""HIP-backed mirror of the `models/basic.py` helpers the reference's inference scripts call around the forward
+(SURVEY §8f rows 1-2, 4): same names, argument meaning and error behaviour, CUDA/HIP tensors in and out.
+
+    tensor2array            basic.py:10-12      (inference.py:119,124)
+    poolfeat                basic.py:274-324    (spixelseg/inference.py:91,107)
+    get_spixel_size         basic.py:327-335
+    upfeat                  basic.py:338-376    (inference.py:115,129; spixelseg/inference.py:108)
+    ColorLabel.decode_ind2ab  basic.py:196-218  (inference.py:114, integer T)
+    rgb2lab / lab2rgb       basic.py:395-475
+
+No CPU fallback: CPU tensors raise DiscoError.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .gamut import gamut_points
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise _ffi.DiscoError("HIP path only: expected CUDA/HIP tensors (no CPU fallback)")
+
+
+def tensor2array(tensors):
+    arrays = tensors.detach().to("cpu").numpy()
+    return np.transpose(arrays, (0, 2, 3, 1))
+
+
+def _pool(input, prob, sp, want_sizes):
+    _need_cuda(input, prob)
+    x, p = input.contiguous().float(), prob.contiguous().float()
+    n, c, hh, ww = x.shape
+    if p.shape != (n, 9, hh, ww):
+        raise ValueError("prob must be (N,9,H,W) matching input")
+    if hh % sp or ww % sp:
+        raise ValueError("H and W must be multiples of the superpixel size")
+    h, w = hh // sp, ww // sp
+    with torch.cuda.device(x.device):
+        pooled = torch.empty(n, c, h, w, device=x.device)
+        conf = torch.empty(n, 1, h, w, device=x.device)
+        sizes = torch.empty(n, 1, h, w, device=x.device) if want_sizes else None
+        ws = torch.empty(n * h * w * 9 * (c + 2) * 4, dtype=torch.uint8, device=x.device)
+        _ffi.check(_ffi.lib().disco_op_poolfeat(_ffi.ptr(x), _ffi.ptr(p), _ffi.ptr(pooled), _ffi.ptr(conf), _ffi.ptr(sizes),
+                                                n, c, hh, ww, sp, _ffi.ptr(ws), ws.numel(), _stream()))
+    return pooled, conf, sizes
+
+
+def poolfeat(input, prob, sp_h=2, sp_w=2, need_entry_prob=False):
+    if sp_h != sp_w:
+        raise NotImplementedError("square superpixels only (the reference always passes sp_h == sp_w)")
+    pooled, conf, _ = _pool(input, prob, sp_h, False)
+    return (pooled, conf) if need_entry_prob else pooled
+
+
+def get_spixel_size(affinity_map, sp_h=2, sp_w=2, elem_thres=25):
+    if sp_h != sp_w:
+        raise NotImplementedError("square superpixels only")
+    ones = torch.ones(affinity_map.shape[0], 1, *affinity_map.shape[2:], device=affinity_map.device)
+    return _pool(ones, affinity_map, sp_h, True)[2]
+
+
+def upfeat(input, prob, up_h=2, up_w=2):
+    if up_h != up_w:
+        raise NotImplementedError("square superpixels only")
+    _need_cuda(input, prob)
+    x, p = input.contiguous().float(), prob.contiguous().float()
+    n, c, h, w = x.shape
+    if p.shape != (n, 9, h * up_h, w * up_w):
+        raise ValueError("prob must be (N,9,h*up,w*up)")
+    with torch.cuda.device(x.device):
+        out = torch.empty(n, c, h * up_h, w * up_w, device=x.device)
+        _ffi.check(_ffi.lib().disco_op_upfeat(_ffi.ptr(x), _ffi.ptr(p), _ffi.ptr(out), n, c, h, w, up_h, _stream()))
+    return out
+
+
+class ColorLabel:
+    """313-bin gamut labels; only what inference needs (q_to_ab, decode_ind2ab with integer T)."""
+
+    def __init__(self, lambda_=0.5, device="cuda"):
+        self.q_to_ab = torch.from_numpy(gamut_points()).to(device)
+
+    def decode_ind2ab(self, batch_q, T=0.38):
+        if T % 1 != 0:
+            raise NotImplementedError("annealed-mean decoding (non-integer T) is outside the MI355X hot path")
+        _need_cuda(batch_q)
+        q = batch_q.contiguous().float()
+        n, c, h, w = q.shape
+        if c != 313:
+            raise ValueError("expected 313 colour bins")
+        with torch.cuda.device(q.device):
+            ab = torch.empty(n, 2, h, w, device=q.device)
+            _ffi.check(_ffi.lib().disco_op_decode_ind2ab(_ffi.ptr(q), _ffi.ptr(ab), n, h * w, int(T), _stream()))
+        return ab.type(batch_q.dtype)
+
+
+def _color(fn_name, x):
+    _need_cuda(x)
+    t = x.contiguous().float()
+    n, c, h, w = t.shape
+    if c != 3:
+        raise ValueError("expected (N,3,H,W)")
+    with torch.cuda.device(t.device):
+        out = torch.empty_like(t)
+        _ffi.check(getattr(_ffi.lib(), fn_name)(_ffi.ptr(t), _ffi.ptr(out), n, h, w, _stream()))
+    return out
+
+
+def rgb2lab(rgb, l_mean=50, l_norm=50, ab_norm=110):
+    if (l_mean, l_norm, ab_norm) != (50, 50, 110):
+        raise NotImplementedError("only the reference's default normalisation (50, 50, 110)")
+    return _color("disco_op_rgb2lab", rgb)
+
+
+def lab2rgb(lab_rs, l_mean=50, l_norm=50, ab_norm=110):
+    if (l_mean, l_norm, ab_norm) != (50, 50, 110):
+        raise NotImplementedError("only the reference's default normalisation (50, 50, 110)")
+    return _color("disco_op_lab2rgb", lab_rs)

@@ -470,24 +470,12 @@ struct Plan {
 
 constexpr int RELU = DISCO_ACT_RELU, LRELU = DISCO_ACT_LRELU, NOACT = DISCO_ACT_NONE;
 
-int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, size_t* peak) {
-    Plan P(c, a, cap, dry);
-    const int n = a->n, H = a->h, W = a->w, sp = c->opt.sp_size, K = c->opt.n_clusters;
-    const int hs = H / sp, ws = W / sp, L = hs * ws;
-    const int rep = a->sampled_T > 0 ? 3 : 1, n2 = n * rep;
-    const double px = (double)n * H * W;
+// ---- a1 SpixelNet (network.py:293-313): gray -> affinity (n,9,H,W), softmax over the 9 neighbour slots -------------
+void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int W, float* d_affinity) {
+    const bool dry = P.dry;
     hipStream_t s = P.s;
-    if (!dry) {
-        for (auto& e : c->prof) hipEventDestroy(e.ev);
-        c->prof.clear();
-        for (auto& e : c->conv_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
-        c->conv_prof.clear();
-    }
-    P.mark("start");
-
-    // ---- a1 SpixelNet (network.py:293-313) -------------------------------------------------------------------
     const std::string sg = "segnet.net.";
-    Act s0a = P.c1(sg + "conv0a.0", a->d_gray, n, H, W, LRELU, 0.1f);
+    Act s0a = P.c1(sg + "conv0a.0", d_gray, n, H, W, LRELU, 0.1f);
     Act o1 = P.conv(sg + "conv0b.0", s0a, nullptr, 0, 0, 1, LRELU, 0.1f); P.drop(s0a);
     Act t = P.conv(sg + "conv1a.0", o1, nullptr, 0, 0, 2, LRELU, 0.1f);
     Act o2 = P.conv(sg + "conv1b.0", t, nullptr, 0, 0, 1, LRELU, 0.1f); P.drop(t);
@@ -507,14 +495,32 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     cc = P.conv(sg + "conv0_1.0", o1, &d, 0, 0, 1, LRELU, 0.1f); P.drop(d); P.drop(o1);
     if (!dry && P.ok()) {
         const DirectLayer& Lp = c->direct.at(sg + "pred_mask0");
-        P.rc = launch_conv_small_out(cc.p, (long)cc.plane, 16, Lp.d_w, Lp.d_bias, a->d_affinity, n, H, W, 9, 0, s);
+        P.rc = launch_conv_small_out(cc.p, (long)cc.plane, 16, Lp.d_w, Lp.d_bias, d_affinity, n, H, W, 9, 0, s);
     }
     P.drop(cc);
+}
+
+int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, size_t* peak) {
+    Plan P(c, a, cap, dry);
+    const int n = a->n, H = a->h, W = a->w, sp = c->opt.sp_size, K = c->opt.n_clusters;
+    const int hs = H / sp, ws = W / sp, L = hs * ws;
+    const int rep = a->sampled_T > 0 ? 3 : 1, n2 = n * rep;
+    const double px = (double)n * H * W;
+    hipStream_t s = P.s;
+    if (!dry) {
+        for (auto& e : c->prof) hipEventDestroy(e.ev);
+        c->prof.clear();
+        for (auto& e : c->conv_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+        c->conv_prof.clear();
+    }
+    P.mark("start");
+
+    segnet_stage(P, c, a->d_gray, n, H, W, dry ? nullptr : a->d_affinity);
     P.mark("segnet", 2.0 * 2.8962e9 * px / 65536.0);
 
     // ---- a2 ColorProbNet (network.py:220-236) ----------------------------------------------------------------
     const std::string rp = "repnet.";
-    t = P.c1(rp + "conv1_2.0", a->d_gray, n, H, W, LRELU, 0.2f);
+    Act t = P.c1(rp + "conv1_2.0", a->d_gray, n, H, W, LRELU, 0.2f);
     Act f = P.conv(rp + "conv1_2.2", t, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(t);
     Act f3{};
     const char* blk[6] = {"conv2_3", "conv3_3", "conv4_3", "conv5_3", "conv6_3", "conv7_3"};
@@ -659,7 +665,7 @@ int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
     if (!c->finalized) { set_error("disco_forward before disco_finalize"); return DISCO_ESTATE; }
     const int sp = c->opt.sp_size;
     if (a->n < 1 || a->h < sp || a->w < sp || a->h % sp || a->w % sp) { set_error("bad input size %dx%dx%d (multiples of %d)", a->n, a->h, a->w, sp); return DISCO_ESHAPE; }
-    if ((a->h / sp) * (a->w / sp) < c->opt.n_clusters) { set_error("fewer tokens than clusters"); return DISCO_ESHAPE; }
+    if (!c->opt.segnet_only && (a->h / sp) * (a->w / sp) < c->opt.n_clusters) { set_error("fewer tokens than clusters"); return DISCO_ESHAPE; }
     if (a->max_fallback > c->opt.n_clusters * 20) { set_error("max_fallback %d > K*20", a->max_fallback); return DISCO_EINVAL; }
     return DISCO_OK;
 }
@@ -722,17 +728,22 @@ int disco_load_tensor(disco_ctx* c, const char* key, const float* h_data, const 
 int disco_finalize(disco_ctx* c) {
     if (!c) { set_error("null context"); return DISCO_EINVAL; }
     if (c->finalized) return DISCO_OK;
+    const bool seg_only = c->opt.segnet_only != 0;
     // strict: same key set and shapes as the reference's load_state_dict(strict=True) (utils_train.py:151)
+    size_t n_expected = 0;
     for (const ExpectedTensor& e : layout().t) {
+        if (seg_only && e.key.compare(0, 11, "segnet.net.") != 0) continue;
+        ++n_expected;
         auto it = c->sd.find(e.key);
         if (it == c->sd.end()) { set_error("missing key in state_dict: %s", e.key.c_str()); return DISCO_ESTATE; }
         if (it->second.shape != e.shape) { set_error("size mismatch for %s", e.key.c_str()); return DISCO_ESHAPE; }
         if (!e.is_count && it->second.data.size() != it->second.numel()) { set_error("no data for %s", e.key.c_str()); return DISCO_EINVAL; }
     }
-    if (c->sd.size() != layout().t.size()) {
+    if (c->sd.size() != n_expected) {
         for (auto& kv : c->sd) {
             bool found = false;
-            for (const ExpectedTensor& e : layout().t) if (e.key == kv.first) { found = true; break; }
+            for (const ExpectedTensor& e : layout().t)
+                if (e.key == kv.first && (!seg_only || e.key.compare(0, 11, "segnet.net.") == 0)) { found = true; break; }
             if (!found) { set_error("unexpected key in state_dict: %s", kv.first.c_str()); return DISCO_ESTATE; }
         }
     }
@@ -745,6 +756,7 @@ int disco_finalize(disco_ctx* c) {
         if ((rc = make_conv(c, sg + k + ".0", sg + k + ".1", ""))) return rc;
     for (const char* k : {"deconv3", "deconv2", "deconv1", "deconv0"}) if ((rc = make_deconv(c, sg + k + ".0"))) return rc;
     if ((rc = make_small_out(c, sg + "pred_mask0"))) return rc;
+    if (seg_only) { c->sd.clear(); c->finalized = true; return DISCO_OK; }
     const std::string rp = "repnet.";
     if ((rc = make_c1(c, rp + "conv1_2.0", ""))) return rc;
     if ((rc = make_conv(c, rp + "conv1_2.2", "", rp + "conv1_2.4"))) return rc;
@@ -804,12 +816,30 @@ int disco_workspace_bytes(disco_ctx* c, int n, int h, int w, int sampled_T, size
     int rc = check_forward_args(c, &a);
     if (rc) return rc;
     size_t peak = 0;
-    rc = run_plan(c, &a, (size_t)1 << 46, true, &peak);
+    if (c->opt.segnet_only) {
+        Plan P(c, &a, (size_t)1 << 46, true);
+        segnet_stage(P, c, nullptr, n, h, w, nullptr);
+        peak = P.arena.peak; rc = P.rc;
+    } else rc = run_plan(c, &a, (size_t)1 << 46, true, &peak);
     *bytes = peak + 4096;
     return rc;
 }
 
+int disco_forward_segnet(disco_ctx* c, int n, int h, int w, const float* d_gray, float* d_affinity, void* d_ws, size_t ws_bytes,
+                         void* stream) {
+    disco_forward_args a{};
+    a.n = n; a.h = h; a.w = w; a.d_workspace = d_ws; a.workspace_bytes = ws_bytes; a.stream = stream;
+    if (!c || !c->finalized) { set_error("disco_forward_segnet before disco_finalize"); return DISCO_ESTATE; }
+    if (n < 1 || h < 16 || w < 16 || h % 16 || w % 16) { set_error("bad input size %dx%dx%d (multiples of 16)", n, h, w); return DISCO_ESHAPE; }
+    if (!d_gray || !d_affinity || !d_ws) { set_error("null tensor pointer"); return DISCO_EINVAL; }
+    DISCO_HIP_CHECK(hipSetDevice(c->device));
+    Plan P(c, &a, ws_bytes, false);
+    segnet_stage(P, c, d_gray, n, h, w, d_affinity);
+    return P.rc;
+}
+
 int disco_forward(disco_ctx* c, const disco_forward_args* a) {
+    if (c && c->opt.segnet_only) { set_error("segnet_only context: use disco_forward_segnet"); return DISCO_ESTATE; }
     int rc = check_forward_args(c, a);
     if (rc) return rc;
     if (!a->d_gray || !a->d_ab || !a->d_pal_logit || !a->d_ref_logit || !a->d_pred_colors || !a->d_affinity ||
@@ -1002,6 +1032,25 @@ int disco_op_nearest_bin(const float* d_ab, int32_t* d_labels, int n, int hw, vo
     int rc = gamut_device(&q);
     if (rc) return rc;
     return launch_nearest_bin(d_ab, q, d_labels, n, hw, (hipStream_t)stream);
+}
+
+int disco_op_decode_ind2ab(const float* d_logit, float* d_ab, int n, int hw, int T, void* stream) {
+    if (!d_logit || !d_ab) { set_error("null argument"); return DISCO_EINVAL; }
+    if (T < 0 || T > 9) { set_error("decode_ind2ab: integer T in [0,9] supported, got %d", T); return DISCO_EUNSUPPORTED; }
+    float* q = nullptr;
+    int rc = gamut_device(&q);
+    if (rc) return rc;
+    return launch_select_colors(d_logit, q, d_ab, nullptr, n, hw, 0, 1, (hipStream_t)stream, T);
+}
+
+int disco_op_rgb2lab(const float* d_rgb, float* d_lab, int n, int h, int w, void* stream) {
+    if (!d_rgb || !d_lab || n < 1 || h < 1 || w < 1) { set_error("bad argument"); return DISCO_EINVAL; }
+    return launch_rgb2lab(d_rgb, d_lab, (long)n * h * w, (long)h * w, (hipStream_t)stream);
+}
+
+int disco_op_lab2rgb(const float* d_lab, float* d_rgb, int n, int h, int w, void* stream) {
+    if (!d_lab || !d_rgb || n < 1 || h < 1 || w < 1) { set_error("bad argument"); return DISCO_EINVAL; }
+    return launch_lab2rgb(d_lab, d_rgb, (long)n * h * w, (long)h * w, (hipStream_t)stream);
 }
 
 int disco_op_position_encoding(float* d_pos, int h, int w, void* stream) {

@@ -142,7 +142,10 @@ void position_encoding_host(float* h_pos /*(h*w,64)*/, int h, int w);
 // logits: (n,L,64) x (313,64)^T -> NCHW (n,313,L)
 int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s);
 int launch_select_colors(const float* logit_nchw, const float* q_to_ab, float* colors, int32_t* labels, int n, int l,
-                         int t_first, int t_count, hipStream_t s);
+                         int t_first, int t_count, hipStream_t s, int plain_rank = -1);
+// colour space (models/basic.py:395-475): rgb in [0,1] <-> normalised Lab ((L-50)/50, a/110, b/110), fp32 NCHW
+int launch_rgb2lab(const float* rgb, float* lab, long npix_total, long hw, hipStream_t s);
+int launch_lab2rgb(const float* lab, float* rgb, long npix_total, long hw, hipStream_t s);
 int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labels, int n, int l, hipStream_t s);
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,

@@ -353,7 +353,7 @@ __global__ void hint_mask_from_pos_kernel(const int32_t* pos, float* hint_mask, 
 // probabilities exactly as softmax: exp(x-max)/sum; order = (p desc, bin asc) = stable descending sort.
 __global__ __launch_bounds__(256) void select_colors_kernel(const float* __restrict__ logit, const float* __restrict__ q_to_ab,
                                                             float* colors, int32_t* labels, int n, int L, int t_first,
-                                                            int t_count) {
+                                                            int t_count, int plain_rank) {
     const int lane = threadIdx.x & 63;
     const int tokg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tokg >= n * L) return;
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void select_colors_kernel(const float* __restr
     }
     const int pick[3] = {0, j1, j2};
     for (int tt = 0; tt < t_count; ++tt) {
-        const int r = pick[t_first + tt];
+        // plain_rank >= 0: the plain_rank-th most probable bin (ColorLabel.decode_ind2ab, basic.py:196-209)
+        const int r = plain_rank >= 0 ? plain_rank : pick[t_first + tt];
         // output image index: image-major [img][tt]
         const size_t oi = (size_t)img * t_count + tt;
         colors[(oi * 2 + 0) * L + t] = ca[r];
@@ -521,10 +522,10 @@ int launch_hint_embed(const float* src, int src_rep, const int32_t* labels, cons
 }
 
 int launch_select_colors(const float* logit_nchw, const float* q_to_ab, float* colors, int32_t* labels, int n, int l,
-                         int t_first, int t_count, hipStream_t s) {
-    if (t_first < 0 || t_first + t_count > 3) { set_error("select_colors: T range"); return DISCO_EINVAL; }
+                         int t_first, int t_count, hipStream_t s, int plain_rank) {
+    if (t_first < 0 || t_first + t_count > 3 || plain_rank > 9) { set_error("select_colors: T range"); return DISCO_EINVAL; }
     hipLaunchKernelGGL(select_colors_kernel, dim3(cdiv(n * l, 4)), dim3(256), 0, s, logit_nchw, q_to_ab, colors, labels,
-                       n, l, t_first, t_count);
+                       n, l, t_first, t_count, plain_rank);
     DISCO_LAUNCH_CHECK("select_colors_kernel");
     return DISCO_OK;
 }

@@ -29,6 +29,96 @@ class _Node(nn.Module):
     """Bare container so that dotted checkpoint keys map onto a module tree."""
 
 
+class SpixelSeg(nn.Module):
+    """Drop-in for `models/model.py::SpixelSeg` (model.py:12-29): the superpixel network alone, as used by
+    main/spixelseg/inference.py:45-89.  state_dict keys `net.*` (94 tensors); forward(gray) -> (N,9,H,W) affinity."""
+
+    def __init__(self, inChannel=1, outChannel=9, batchNorm=True, precision="f16x3"):
+        super().__init__()
+        if inChannel != 1 or outChannel != 9 or not batchNorm:
+            raise NotImplementedError("SpixelSeg(inChannel=1, outChannel=9, batchNorm=True) only")
+        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1}[precision]
+        for key, shape, dt, kind in state_dict_spec():
+            if not key.startswith("segnet."):
+                continue
+            parts = key[len("segnet."):].split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            t = torch.zeros(shape, dtype=getattr(torch, dt))
+            if kind in _PARAM_KINDS:
+                node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+            else:
+                node.register_buffer(parts[-1], t)
+        self._ctx, self._ctx_device, self._workspace = None, None, None
+
+    def get_trainable_params(self, lr=1.0):
+        raise NotImplementedError("training is outside the MI355X hot path")
+
+    def _drop_ctx(self):
+        if getattr(self, "_ctx", None) is not None:
+            _ffi.lib().disco_destroy(self._ctx)
+        self._ctx = None
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        self._drop_ctx()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._drop_ctx()
+        return out
+
+    def __del__(self):
+        try:
+            self._drop_ctx()
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def forward(self, input_grays):
+        if not input_grays.is_cuda:
+            raise _ffi.DiscoError("SpixelSeg needs CUDA/HIP tensors: the HIP path has no CPU fallback")
+        dev = input_grays.device
+        gray = input_grays.contiguous().float()
+        n, c, H, W = gray.shape
+        if c != 1 or H % 16 or W % 16:
+            raise ValueError("expected gray (N,1,H,W) with H, W multiples of 16")
+        L = _ffi.lib()
+        with torch.cuda.device(dev):
+            if self._ctx is None or self._ctx_device != dev:
+                self._drop_ctx()
+                opt = _ffi.Options(16, 1, 0, self.precision, 1)
+                ctx = C.c_void_p()
+                _ffi.check(L.disco_create(dev.index if dev.index is not None else torch.cuda.current_device(),
+                                          C.byref(opt), C.byref(ctx)))
+                try:
+                    for key, t in self.state_dict().items():
+                        shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                        full = ("segnet." + key).encode()
+                        if t.dtype == torch.float32:
+                            h = t.detach().to("cpu").contiguous()
+                            _ffi.check(L.disco_load_tensor(ctx, full, C.c_void_p(h.data_ptr()), shape, t.dim()))
+                        else:
+                            _ffi.check(L.disco_load_tensor(ctx, full, None, shape, t.dim()))
+                    _ffi.check(L.disco_finalize(ctx))
+                except Exception:
+                    L.disco_destroy(ctx)
+                    raise
+                self._ctx, self._ctx_device = ctx, dev
+            need = C.c_size_t()
+            _ffi.check(L.disco_workspace_bytes(self._ctx, n, H, W, 0, C.byref(need)))
+            if self._workspace is None or self._workspace.numel() < need.value or self._workspace.device != dev:
+                self._workspace = torch.empty(need.value, device=dev, dtype=torch.uint8)
+            aff = torch.empty(n, 9, H, W, device=dev, dtype=torch.float32)
+            _ffi.check(L.disco_forward_segnet(self._ctx, n, H, W, gray.data_ptr(), aff.data_ptr(), self._workspace.data_ptr(),
+                                              self._workspace.numel(), torch.cuda.current_stream().cuda_stream))
+        return aff
+
+
 class AnchorColorProb(nn.Module):
     def __init__(self, inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=False,
                  learning_pos=False, n_clusters=8, random_hint=False, hint2regress=False, enhanced=False,
@@ -108,7 +198,7 @@ class AnchorColorProb(nn.Module):
             return self._ctx
         self._drop_ctx()
         L = _ffi.lib()
-        opt = _ffi.Options(self.sp_size, self.hint_num, int(self.random_hint), self.precision)
+        opt = _ffi.Options(self.sp_size, self.hint_num, int(self.random_hint), self.precision, 0)
         ctx = C.c_void_p()
         _ffi.check(L.disco_create(device.index if device.index is not None else torch.cuda.current_device(),
                                   C.byref(opt), C.byref(ctx)))

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 1
+#define DISCO_ABI_VERSION 2
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -71,6 +71,8 @@ typedef struct disco_options {
     int32_t n_clusters;  /* K anchors (inference.py:156) */
     int32_t random_hint; /* 1: anchors come from h_hint_pos instead of k-means (model.py:69) */
     int32_t precision;   /* DISCO_PREC_* for the conv stacks */
+    int32_t segnet_only; /* 1: the context holds only the SpixelSeg weights ("segnet.net.*", 94 tensors) and serves
+                            disco_forward_segnet (models/model.py:12-29, main/spixelseg/inference.py:89) */
 } disco_options;
 
 int disco_create(int device, const disco_options *opt, disco_ctx **out);
@@ -113,6 +115,10 @@ typedef struct disco_forward_args {
 } disco_forward_args;
 
 int disco_workspace_bytes(disco_ctx *ctx, int n, int h, int w, int sampled_T, size_t *bytes);
+/* SpixelSeg.forward(gray) -> affinity (n,9,h,w), softmax over the 9 neighbour slots (models/network.py:293-313).
+ * Works on full and segnet_only contexts; workspace as reported by disco_workspace_bytes. */
+int disco_forward_segnet(disco_ctx *ctx, int n, int h, int w, const float *d_gray, float *d_affinity, void *d_workspace,
+                         size_t workspace_bytes, void *stream);
 int disco_forward(disco_ctx *ctx, const disco_forward_args *a);
 int disco_sync(void *stream);
 
@@ -182,6 +188,11 @@ int disco_op_select_colors(const float *d_logit_nchw, float *d_colors, int32_t *
                            void *stream);
 int disco_op_nearest_bin(const float *d_ab_nchw, int32_t *d_labels, int n, int hw, void *stream);
 int disco_op_position_encoding(float *d_pos, int h, int w, void *stream);
+/* ColorLabel.decode_ind2ab(logit, T) for integer T in [0,9]: ab/110 of the T-th most probable bin (basic.py:196-209) */
+int disco_op_decode_ind2ab(const float *d_logit_nchw, float *d_ab_nchw, int n, int hw, int T, void *stream);
+/* basic.rgb2lab / basic.lab2rgb (models/basic.py:395-475): rgb in [0,1] <-> ((L-50)/50, a/110, b/110), (n,3,h,w) fp32 */
+int disco_op_rgb2lab(const float *d_rgb, float *d_lab, int n, int h, int w, void *stream);
+int disco_op_lab2rgb(const float *d_lab, float *d_rgb, int n, int h, int w, void *stream);
 
 #ifdef __cplusplus
 }

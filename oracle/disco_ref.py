@@ -416,6 +416,39 @@ def decode_ind2ab(logit: Tensor, q_to_ab: Tensor, t: int = 0) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# §8f row 1  colour space  (basic.py:395-475: rgb2xyz, xyz2lab, lab2xyz, xyz2rgb, rgb2lab, lab2rgb)
+# --------------------------------------------------------------------------------------
+
+_WHITE = (0.95047, 1.0, 1.08883)
+
+
+def rgb2lab(rgb: Tensor) -> Tensor:
+    """rgb (N,3,H,W) in [0,1] -> ((L-50)/50, a/110, b/110).  sRGB gamma 2.4, D65 white."""
+    lin = torch.where(rgb > 0.04045, ((rgb + 0.055) / 1.055) ** 2.4, rgb / 12.92)
+    r, g, b = lin[:, 0], lin[:, 1], lin[:, 2]
+    xyz = torch.stack((0.412453 * r + 0.357580 * g + 0.180423 * b,
+                       0.212671 * r + 0.715160 * g + 0.072169 * b,
+                       0.019334 * r + 0.119193 * g + 0.950227 * b), 1)
+    t = xyz / torch.tensor(_WHITE).view(1, 3, 1, 1)
+    f = torch.where(t > 0.008856, t ** (1 / 3.0), 7.787 * t + 16.0 / 116.0)
+    lab = torch.stack((116.0 * f[:, 1] - 16.0, 500.0 * (f[:, 0] - f[:, 1]), 200.0 * (f[:, 1] - f[:, 2])), 1)
+    return torch.cat(((lab[:, :1] - 50.0) / 50.0, lab[:, 1:] / 110.0), 1)
+
+
+def lab2rgb(lab_rs: Tensor) -> Tensor:
+    """inverse of rgb2lab; negative linear RGB clamps to 0 (basic.py:421)."""
+    L, a, b = lab_rs[:, 0] * 50.0 + 50.0, lab_rs[:, 1] * 110.0, lab_rs[:, 2] * 110.0
+    fy = (L + 16.0) / 116.0
+    f = torch.stack((a / 500.0 + fy, fy, torch.clamp(fy - b / 200.0, min=0.0)), 1)
+    t = torch.where(f > 0.2068966, f ** 3.0, (f - 16.0 / 116.0) / 7.787) * torch.tensor(_WHITE).view(1, 3, 1, 1)
+    x, y, z = t[:, 0], t[:, 1], t[:, 2]
+    lin = torch.stack((3.24048134 * x - 1.53715152 * y - 0.49853633 * z,
+                       -0.96925495 * x + 1.87599 * y + 0.04155593 * z,
+                       0.05564664 * x - 0.20404134 * y + 1.05731107 * z), 1).clamp(min=0.0)
+    return torch.where(lin > 0.0031308, 1.055 * lin ** (1.0 / 2.4) - 0.055, 12.92 * lin)
+
+
+# --------------------------------------------------------------------------------------
 # a14  the forward  (model.py:103-199, test_mode=True, enhanced=True, dense pos)
 # --------------------------------------------------------------------------------------
 

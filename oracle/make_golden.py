@@ -134,13 +134,42 @@ def components():
     d["km_x"] = np.stack([npy(x) for x in xs])
     d["km_ids"] = np.stack(ids).astype(np.int16)
     d["km_torch_rng"] = npy(tst)              # CPU generator state before the 4 runs (fallback draws)
+    # colour space (basic.py:395-475) incl. values at the piecewise thresholds, and decode_ind2ab for T = 0..3
+    rgb = torch.rand(2, 3, 24, 40, generator=g)
+    rgb[0, :, 0, :8] = torch.tensor([0.0, 0.04045, 0.0404, 0.0405, 1.0, 0.5, 0.003, 0.9])[None]
+    d["cs_rgb"] = npy(rgb)
+    lab = basic.rgb2lab(rgb)
+    d["cs_lab"] = npy(lab)
+    lab_in = torch.cat((torch.rand(2, 1, 24, 40, generator=g) * 2 - 1, (torch.rand(2, 2, 24, 40, generator=g) * 2 - 1) * 0.9), 1)
+    d["cs_lab_in"] = npy(lab_in)
+    d["cs_rgb_out"] = npy(basic.lab2rgb(lab_in))
+    for t in (1, 2, 3):
+        d[f"dec_ab_T{t}"] = npy(cl.decode_ind2ab(lg, T=t))
     np.savez_compressed(os.path.join(OUT, "components.npz"), **d)
     print("components", {k: v.shape for k, v in d.items()})
+
+
+def spixelseg_case(sd):
+    """models/model.py:12-29 SpixelSeg as main/spixelseg/inference.py:45-59,89 uses it (weights = the segnet.* subset)."""
+    ref_harness.install()
+    import model  # reference
+
+    m = model.SpixelSeg(inChannel=1, outChannel=9, batchNorm=True)
+    sub = {k[len("segnet."):]: v for k, v in sd.items() if k.startswith("segnet.")}
+    m.load_state_dict(sub)   # strict
+    m.eval()
+    gray, _ = synth.synth_inputs(2, 96, 160, seed=12)
+    with torch.no_grad():
+        prob = m(gray)
+    np.savez_compressed(os.path.join(OUT, "spixelseg.npz"), recipe=np.array([2, 96, 160, 12], dtype=np.int64),
+                        prob=npy(prob), keys=np.array(sorted(sub.keys())))
+    print("spixelseg", prob.shape, len(sub))
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     sd = synth.synth_state_dict(SEED)
+    spixelseg_case(sd)
     components()
     run_case("fwd_n2_256_k8", sd, n=2, h=256, w=256, k=8)
     run_case("fwd_diverse_256_k16", sd, n=1, h=256, w=256, k=16, sampled_T=2, input_seed=6)

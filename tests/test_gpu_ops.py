@@ -215,3 +215,62 @@ def test_nearest_bin_golden(H, comp):
     labels = torch.empty(n, h * w, dtype=torch.int32, device=H.DEV)
     _ffi.check(_ffi.lib().disco_op_nearest_bin(_ffi.ptr(ab), _ffi.ptr(labels), n, h * w, H.stream()))
     assert torch.equal(labels.cpu().long().reshape(n, 1, h, w), torch.from_numpy(comp["enc_label"]))
+
+
+# ---- §8f "next" rows: the helpers either side of the forward (disentangledcolorization_amd/basic.py) -----------------
+
+
+def test_basic_mirror_pool_unpool(H, comp):
+    from disentangledcolorization_amd import basic
+
+    prob = torch.from_numpy(comp["pool_prob"]).to(H.DEV)
+    feat = torch.from_numpy(comp["pool_feat"]).to(H.DEV)
+    pooled, conf = basic.poolfeat(feat, prob, 16, 16, True)
+    assert H.max_err(pooled, torch.from_numpy(comp["pool_out"])) < 1e-5 and H.max_err(conf, torch.from_numpy(comp["pool_conf"])) < 1e-6
+    assert torch.equal(basic.get_spixel_size(prob, 16, 16).cpu(), torch.from_numpy(comp["spix_size"]))
+    tok = torch.from_numpy(comp["up_tok"]).to(H.DEV)
+    assert H.max_err(basic.upfeat(tok, prob, 16, 16), torch.from_numpy(comp["up_out"])) < 1e-6
+    assert basic.tensor2array(tok).shape == (2, 4, 6, 5)
+    with pytest.raises(_ffi.DiscoError):
+        basic.upfeat(tok.cpu(), prob.cpu(), 16, 16)
+
+
+@pytest.mark.parametrize("t", [0, 1, 2, 3])
+def test_basic_mirror_decode_ind2ab(H, comp, t):
+    from disentangledcolorization_amd import basic
+
+    lg = torch.from_numpy(comp["dec_logit"]).to(H.DEV)
+    got = basic.ColorLabel().decode_ind2ab(lg, T=t)
+    assert torch.equal(got.cpu(), torch.from_numpy(comp["dec_ab_T%d" % t]))
+    with pytest.raises(NotImplementedError):
+        basic.ColorLabel().decode_ind2ab(lg, T=0.38)
+
+
+def test_basic_mirror_colour_space(H, comp):
+    from disentangledcolorization_amd import basic
+
+    lab = basic.rgb2lab(torch.from_numpy(comp["cs_rgb"]).to(H.DEV))
+    assert H.max_err(lab, torch.from_numpy(comp["cs_lab"])) < 5e-6
+    rgb = basic.lab2rgb(torch.from_numpy(comp["cs_lab_in"]).to(H.DEV))
+    assert H.max_err(rgb, torch.from_numpy(comp["cs_rgb_out"])) < 5e-6
+    # round trip at full benchmark size (64 x 256 x 256): rgb -> lab -> rgb is the identity on in-gamut colours
+    big = torch.rand(64, 3, 256, 256, generator=g(9)).to(H.DEV)
+    assert H.max_err(basic.lab2rgb(basic.rgb2lab(big)), big) < 2e-4
+
+
+def test_spixelseg_dropin(H, golden_dir, synth_sd):
+    from disentangledcolorization_amd import synth
+    from disentangledcolorization_amd.model import SpixelSeg
+
+    gd = np.load(os.path.join(golden_dir, "spixelseg.npz"))
+    n, h, w, seed = (int(v) for v in gd["recipe"])
+    m = SpixelSeg(inChannel=1, outChannel=9, batchNorm=True)
+    assert sorted(m.state_dict().keys()) == list(gd["keys"])
+    m.load_state_dict({k[len("segnet."):]: v for k, v in synth_sd.items() if k.startswith("segnet.")})   # strict
+    m = m.cuda().eval()
+    gray, _ = synth.synth_inputs(n, h, w, seed=seed)
+    prob = m(gray.cuda())
+    torch.cuda.synchronize()
+    assert H.max_err(prob, torch.from_numpy(gd["prob"])) < 1e-4
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"net.conv0a.0.weight": torch.zeros(16, 1, 3, 3)})

@@ -63,6 +63,27 @@ def test_labels_and_decode(golden_dir, q_to_ab):
     assert torch.equal(R.decode_ind2ab(torch.from_numpy(g["dec_logit"]), q, 0), torch.from_numpy(g["dec_ab_T0"]))
 
 
+def test_colour_space_and_ranked_decode(golden_dir, q_to_ab):
+    """§8f rows 1-2: rgb2lab / lab2rgb (basic.py:395-475) and decode_ind2ab for T = 1..3 (basic.py:196-209)."""
+    g = _load(golden_dir, "components")
+    _close(R.rgb2lab(torch.from_numpy(g["cs_rgb"])), g["cs_lab"], 2e-6)
+    _close(R.lab2rgb(torch.from_numpy(g["cs_lab_in"])), g["cs_rgb_out"], 2e-6)
+    q = torch.from_numpy(q_to_ab)
+    for t in (1, 2, 3):
+        assert torch.equal(R.decode_ind2ab(torch.from_numpy(g["dec_logit"]), q, t), torch.from_numpy(g["dec_ab_T%d" % t]))
+
+
+def test_spixelseg_standalone(golden_dir, synth_sd):
+    """§8f row 4: models.model.SpixelSeg (segnet alone, `net.*` keys) == the oracle's segnet stage."""
+    g = _load(golden_dir, "spixelseg")
+    from disentangledcolorization_amd import synth
+
+    n, h, w, seed = (int(v) for v in g["recipe"])
+    gray, _ = synth.synth_inputs(n, h, w, seed=seed)
+    _close(R.segnet_forward(synth_sd, gray), g["prob"], 1e-5)
+    assert sorted(k[len("segnet."):] for k in synth_sd if k.startswith("segnet.")) == list(g["keys"])
+
+
 def test_kmeans_matches_reference(golden_dir):
     g = _load(golden_dir, "components")
     torch.set_rng_state(torch.from_numpy(g["km_torch_rng"]))  # the reference's fallback draws
