@@ -81,7 +81,8 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -111,13 +112,13 @@ def main():
     conv_ms = conv_fl = 0.0
     conv_launches = 0
     stage_ms = {}
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()          # asynchronous: no host sync inside the timed region; every conv launch is event-bracketed
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -126,7 +127,7 @@ def main():
     conv_launches, conv_ms, conv_fl = nl * args.steps, ms * args.steps, fl * args.steps
     for name, sms, _ in model.profile():
         stage_ms[name] = sms * args.steps
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -160,7 +161,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -64,7 +64,7 @@ class ShardedColorizer:
         out = self.forward_fn(gray_local, ab_local, sampled_T,
                               None if idx is None else idx[lo:hi], None if pos is None else pos[lo:hi])
         pred, mask = out[2], out[5]
-        if not gather or world == 1:
+        if not gather or not (dist.is_available() and dist.is_initialized()):
             return pred, mask
         return self._all_gather(pred, n_global, world), self._all_gather(mask, n_global, world)
 
