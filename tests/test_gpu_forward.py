@@ -144,6 +144,24 @@ def test_no_resize_shapes_batch(synth_sd, q_to_ab):
         assert _err(got[2], want[2]) <= AB_TOL and _err(got[0], want[0]) < LOGIT_TOL
 
 
+@pytest.mark.parametrize("hw", [(272, 336), (16 * 3, 16 * 5), (256, 16 * 9)])
+def test_ragged_sizes_match_oracle(synth_sd, q_to_ab, hw):
+    """Sizes that are multiples of 16 but not of the conv tiles (odd token grids, partially filled tiles at every
+    scale, single-row/column tiles) — the edge cases of the --no_resize pad-to-16 path (inference.py:26-31)."""
+    h, w = hw
+    k = 4
+    gray, ab = synth.synth_inputs(2, h, w, seed=h * 7 + w)
+    m = _model(synth_sd, k)
+    _seed(130)
+    got = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    _seed(130)
+    want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=k).forward(gray, ab)
+    assert torch.equal(got[5].cpu(), want[5]) and torch.equal(got[4].cpu(), want[4])
+    assert _err(got[3], want[3]) < 1e-4 and _err(got[0], want[0]) < LOGIT_TOL and _err(got[1], want[1]) < LOGIT_TOL
+    assert _err(got[2], want[2]) <= AB_TOL
+
+
 def test_random_hint_with_host_positions(synth_sd):
     """BASELINE config 5b: random_hint with K=16 host-provided anchor positions (random.Random(130).sample)."""
     import random as _r
