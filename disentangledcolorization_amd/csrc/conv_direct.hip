@@ -5,6 +5,7 @@
 //   conv_c1          Cin = 1 first layers  (segnet conv0a, network.py:263; repnet conv1_2.0, :152)
 //   conv_small_out   pred_mask0 (16 -> 9) + softmax over the 9 slots (network.py:282-283, 311-312) -> affinity NCHW fp32
 // (enhanceNet.outConv and the ConvTranspose2d layers run on the MFMA kernel: conv_mfma2.hip epilogues.)
+#include <algorithm>
 #include "common.h"
 
 namespace disco {
@@ -37,23 +38,27 @@ __device__ __forceinline__ void load_sum8(const f16* hi_p, long plane, float* v)
 }
 
 // ---- Cin = 1 ---------------------------------------------------------------------------------------
-// thread = (image, 16-channel block, pixel, 8-channel half) with the half fastest, then the pixel: consecutive
-// lanes write consecutive 16-byte pieces of the channel-blocked output
+// thread = (image, 16-channel block, pixel), pixel fastest: a wave writes 64 consecutive 32-byte pixels of one
+// channel block (2 KiB contiguous per plane).  blockIdx.y = (image, block): the block's 16x9 weights and its
+// bias / BN affine sit in LDS and are read as wave-uniform broadcasts.
 __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ gray, const float* __restrict__ w,
                                                       const float* __restrict__ bias, const float* __restrict__ bsc,
                                                       const float* __restrict__ bsh, f16* out, long out_plane, int n,
                                                       int h, int wd, int c_out, int act, float slope) {
+    __shared__ float sw[16 * 9 + 48];
     const int nblk = c_out >> 4;
+    const int blk = blockIdx.y % nblk;
+    const long img = blockIdx.y / nblk;
     const long hw = (long)h * wd;
-    const long total = (long)n * nblk * hw * 2;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int half = (int)(t & 1);
-        const long q = t >> 1;
-        const long p = q % hw;
-        const int blk = (int)((q / hw) % nblk);
-        const long img = q / (hw * nblk);
+    if (threadIdx.x < 144) sw[threadIdx.x] = w[blk * 144 + threadIdx.x];
+    else if (threadIdx.x < 160) sw[threadIdx.x] = bias ? bias[blk * 16 + threadIdx.x - 144] : 0.f;
+    else if (threadIdx.x < 176) sw[threadIdx.x] = bsc ? bsc[blk * 16 + threadIdx.x - 160] : 1.f;
+    else if (threadIdx.x < 192) sw[threadIdx.x] = bsh ? bsh[blk * 16 + threadIdx.x - 176] : 0.f;
+    __syncthreads();
+    const float* gi = gray + img * hw;
+    f16* ob = out + ((img * nblk + blk) * hw) * 16;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x) {
         const int x = (int)(p % wd), y = (int)(p / wd);
-        const float* gi = gray + img * hw;
         float in[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -62,19 +67,18 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
                 const int yy = y + ky - 1, xx = x + kx - 1;
                 in[ky * 3 + kx] = (yy >= 0 && yy < h && xx >= 0 && xx < wd) ? gi[(long)yy * wd + xx] : 0.f;
             }
-        float v[8];
+        float v[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int co = blk * 16 + half * 8 + j;
+        for (int j = 0; j < 16; ++j) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) s = fmaf(in[k], w[co * 9 + k], s);
-            s += bias ? bias[co] : 0.f;
+            for (int k = 0; k < 9; ++k) s = fmaf(in[k], sw[j * 9 + k], s);
+            s += sw[144 + j];
             s = apply_act(s, act, slope);
-            if (bsc) s = s * bsc[co] + bsh[co];
-            v[j] = s;
+            v[j] = s * sw[160 + j] + sw[176 + j];
         }
-        store_split8(out + t * 8, out_plane, v);   // ((img*nblk + blk)*hw + p)*16 + half*8 == t*8
+        store_split8(ob + p * 16, out_plane, v);
+        store_split8(ob + p * 16 + 8, out_plane, v + 8);
     }
 }
 
@@ -176,9 +180,10 @@ int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, c
                    const float* d_bn_shift, f16* out, long out_plane, int n, int h, int w, int c_out, int act,
                    float slope, hipStream_t s) {
     if (c_out % 16) { set_error("conv_c1: c_out %d not a multiple of 16", c_out); return DISCO_ESHAPE; }
-    const long total = (long)n * h * w * (c_out / 8);
-    hipLaunchKernelGGL(conv_c1_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale,
-                       d_bn_shift, out, out_plane, n, h, w, c_out, act, slope);
+    const long hw = (long)h * w;
+    dim3 grid((unsigned)std::min<long>((hw + 255) / 256, 1024), (unsigned)(n * (c_out / 16)));
+    hipLaunchKernelGGL(conv_c1_kernel, grid, dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale, d_bn_shift, out, out_plane,
+                       n, h, w, c_out, act, slope);
     DISCO_LAUNCH_CHECK("conv_c1_kernel");
     return DISCO_OK;
 }

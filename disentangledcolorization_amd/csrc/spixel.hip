@@ -50,17 +50,32 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
 #pragma unroll
         for (int c = 0; c < 9; ++c) acc[c] = 0.f;
         if (ch <= C) {
-            for (int p = g; p < npix; p += 4) {
-                const int py = p / a.sp, px = p % a.sp;
-                const long pix = (long)(cy * a.sp + py) * a.W + cx * a.sp + px;
-                float f;
-                if (ch == C) f = 1.f;
-                else if (ch < a.c_act) {
-                    const long idx = (((long)n * (a.c_act >> 4) + (ch >> 4)) * HW + pix) * 16 + (ch & 15);
-                    f = (float)a.feat_act[idx] + (float)a.feat_act[idx + a.feat_plane];
-                } else f = a.feat_nchw[((long)n * a.c_nchw + (ch - a.c_act)) * HW + pix];
+            // 4 pixels per trip with all loads issued before their use: the pass is HBM-latency bound, this puts
+            // 4x more bytes in flight per wave
+            for (int p0 = g; p0 < npix; p0 += 16) {
+                float f[4];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) acc[c] = fmaf(f, sp_prob[p * 9 + c], acc[c]);
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + 4 * u;
+                    f[u] = 0.f;
+                    if (p < npix) {
+                        const int py = p / a.sp, px = p % a.sp;
+                        const long pix = (long)(cy * a.sp + py) * a.W + cx * a.sp + px;
+                        if (ch == C) f[u] = 1.f;
+                        else if (ch < a.c_act) {
+                            const long idx = (((long)n * (a.c_act >> 4) + (ch >> 4)) * HW + pix) * 16 + (ch & 15);
+                            f[u] = (float)a.feat_act[idx] + (float)a.feat_act[idx + a.feat_plane];
+                        } else f[u] = a.feat_nchw[((long)n * a.c_nchw + (ch - a.c_act)) * HW + pix];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + 4 * u;
+                    if (p < npix) {
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) acc[c] = fmaf(f[u], sp_prob[p * 9 + c], acc[c]);
+                    }
+                }
             }
         }
         // reduce the 4 pixel groups
@@ -114,62 +129,66 @@ __global__ void pool_gather_kernel(PoolArgs a) {
     }
 }
 
-// upfeat: out(p) = sum_c P_c(p) tok[cell(p) + (dy,dx)]; thread = (pixel, 8 channels)
+// upfeat: out(p) = sum_c P_c(p) tok[cell(p) + (dy,dx)].  thread = (image, pixel), looping over the 16-channel blocks:
+// the 9 probabilities of a pixel are read once, the neighbour tokens are L1/L2-resident broadcasts (a 16x16 cell
+// shares them), and a wave writes 64 consecutive 32-byte pixels per block and plane.
 __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ tok, int tok_layout,
                                                      const float* __restrict__ prob, int prob_rep, f16* out_act,
                                                      long out_plane, float* out_nchw, int n, int c, int hs, int ws,
                                                      int sp) {
     const int H = hs * sp, W = ws * sp, L = hs * ws;
     const long HW = (long)H * W;
-    const int groups = c >> 3;
-    const long total = (long)n * HW * groups;
+    const int nblk = c >> 4;
+    const long total = (long)n * HW;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        // (image, 16-channel block, pixel, half) with half fastest: coalesced 16-byte stores in the blocked layout
-        const int half = (int)(t & 1);
-        const long q = t >> 1;
-        const long p = q % HW;
-        const int blk = (int)((q / HW) % (groups >> 1));
-        const int img = (int)(q / (HW * (groups >> 1)));
-        const int g = blk * 2 + half;
+        const long p = t % HW;
+        const int img = (int)(t / HW);
         const int y = (int)(p / W), x = (int)(p % W);
         const int cy = y / sp, cx = x / sp;
         const float* pr = prob + (long)(img / prob_rep) * 9 * HW + p;
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        float pw[9];
+        int tokidx[9];
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            const int dy = s / 3 - 1, dx = s % 3 - 1;
-            const int ty = cy + dy, tx = cx + dx;
-            const float pw = pr[s * HW];
-            float tv[8];
-            if (ty < 0 || ty >= hs || tx < 0 || tx >= ws) {
+            const int ty = cy + s / 3 - 1, tx = cx + s % 3 - 1;
+            pw[s] = pr[s * HW];
+            tokidx[s] = (ty < 0 || ty >= hs || tx < 0 || tx >= ws) ? -1 : ty * ws + tx;
+        }
+        for (int blk = 0; blk < nblk; ++blk) {
+            float acc[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tv[j] = 0.f;
-            } else if (tok_layout) {
-                const float* tp = tok + ((long)img * L + ty * ws + tx) * c + g * 8;
-                const float4 a0 = *reinterpret_cast<const float4*>(tp), a1 = *reinterpret_cast<const float4*>(tp + 4);
-                tv[0] = a0.x; tv[1] = a0.y; tv[2] = a0.z; tv[3] = a0.w;
-                tv[4] = a1.x; tv[5] = a1.y; tv[6] = a1.z; tv[7] = a1.w;
-            } else {
+            for (int s = 0; s < 9; ++s) {
+                float tv[16];
+                if (tokidx[s] < 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tv[j] = tok[((long)img * c + g * 8 + j) * L + ty * ws + tx];
+                    for (int j = 0; j < 16; ++j) tv[j] = 0.f;
+                } else if (tok_layout) {
+                    const float4* tp = reinterpret_cast<const float4*>(tok + ((long)img * L + tokidx[s]) * c + blk * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float4 a4 = tp[q]; tv[4 * q] = a4.x; tv[4 * q + 1] = a4.y; tv[4 * q + 2] = a4.z; tv[4 * q + 3] = a4.w; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) tv[j] = tok[((long)img * c + blk * 16 + j) * L + tokidx[s]];
+                }
+                // the reference multiplies then accumulates in slot order (no fused multiply-add)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = s == 0 ? __fmul_rn(tv[j], pw[0]) : __fadd_rn(acc[j], __fmul_rn(tv[j], pw[s]));
             }
-            // the reference multiplies then accumulates in slot order (no fused multiply-add)
+            if (out_act) {
+                f16x8 hv, lv;
+                f16* o = out_act + (((long)img * nblk + blk) * HW + p) * 16;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = s == 0 ? __fmul_rn(tv[j], pw) : __fadd_rn(acc[j], __fmul_rn(tv[j], pw));
-        }
-        if (out_act) {
-            f16x8 hv, lv;
+                for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { hv[j] = (f16)acc[j]; lv[j] = (f16)(acc[j] - (float)hv[j]); }
-            f16* o = out_act + (((long)img * (c >> 4) + (g >> 1)) * HW + p) * 16 + (g & 1) * 8;
-            *reinterpret_cast<f16x8*>(o) = hv;
-            *reinterpret_cast<f16x8*>(o + out_plane) = lv;
-        }
-        if (out_nchw) {
+                    for (int j = 0; j < 8; ++j) { hv[j] = (f16)acc[half * 8 + j]; lv[j] = (f16)(acc[half * 8 + j] - (float)hv[j]); }
+                    *reinterpret_cast<f16x8*>(o + half * 8) = hv;
+                    *reinterpret_cast<f16x8*>(o + half * 8 + out_plane) = lv;
+                }
+            }
+            if (out_nchw) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) out_nchw[((long)img * c + g * 8 + j) * HW + p] = acc[j];
+                for (int j = 0; j < 16; ++j) out_nchw[((long)img * c + blk * 16 + j) * HW + p] = acc[j];
+            }
         }
     }
 }
@@ -245,7 +264,7 @@ int launch_poolfeat(const PoolArgs& a, hipStream_t s) {
 int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_rep, f16* out_act, long out_plane,
                   float* out_nchw, int n, int c, int h, int w, int sp, hipStream_t s) {
     if (c % 16 == 0) {
-        const long total = (long)n * h * sp * w * sp * (c / 8);
+        const long total = (long)n * h * sp * w * sp;
         hipLaunchKernelGGL(upfeat_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, tok_layout, prob, prob_rep,
                            out_act, out_plane, out_nchw, n, c, h, w, sp);
         DISCO_LAUNCH_CHECK("upfeat_kernel");
