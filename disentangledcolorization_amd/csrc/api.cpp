@@ -218,6 +218,7 @@ int staged_h2d(disco_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipSt
 }
 
 int run_conv(const ConvArgs& ca, hipStream_t s) { return launch_conv3x3_v2(ca, s); }
+unsigned long long* g_conv_probe = nullptr;   // timing probe buffer for disco_op_conv3x3 (tools/conv_timeline.py)
 
 // effective conv weight (c_out, c_in, 3, 3): plain `.weight`, or spectral-norm weight_orig / (u . (W v))
 std::vector<float> eff_weight(disco_ctx* c, const std::string& key) {
@@ -941,8 +942,11 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
     ca.out = (f16*)d_out; ca.out_plane = (long)d->n * ca.h_out * ca.w_out * d->c_out;
     ca.res = (const f16*)d_res; ca.res_plane = ca.out_plane;
     ca.act = d->act; ca.slope = d->slope; ca.precision = d->precision;
+    ca.dbg = g_conv_probe;
     return run_conv(ca, (hipStream_t)stream);
 }
+
+int disco_op_conv3x3_set_probe(void* d_buf) { g_conv_probe = (unsigned long long*)d_buf; return DISCO_OK; }
 
 int disco_op_deconv4x4_pack(const float* h_w, int c_in, int c_out, void* d_packed, size_t* bytes) {
     if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }

@@ -76,6 +76,7 @@ struct ConvArgs {
     int precision;
     uint32_t src_bytes[2];  // filled by the launcher: bytes addressable through each source's buffer descriptor
     uint32_t w_bytes;       // ... and through the packed-weight descriptor
+    unsigned long long* dbg;  // timing probe (tools/conv_timeline.py): per-chunk s_memtime stamps of workgroup 0, or null
 };
 
 size_t conv3x3_packed_bytes(int c_out, int c_in_pad);

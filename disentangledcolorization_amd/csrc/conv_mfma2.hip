@@ -184,6 +184,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     issue(n, 0, 0, -1);
     int buf = 0;
     bool dma_waited = false;      // the first chunk's DMA wait of the next image is taken before the epilogue
+    int dbg_n = 0;                // timing probe: chunks recorded so far
 
     for (;;) {
     f32x16 acc[MT][NTW];
@@ -199,8 +200,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         // my DMA pieces of this chunk have landed (vmcnt also counts stores: for the first chunk of an image the
         // wait was already taken BEFORE the previous image's epilogue stores were issued, so those stores drain
         // under this chunk's MFMAs instead of stalling here)
+        const bool probe = a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && dbg_n < 64;
+        unsigned long long t_a = 0, t_b = 0, t_c = 0;
+        if (probe) t_a = __builtin_amdgcn_s_memtime();
         if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (probe) t_b = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();                        // ... everyone's have; the previous chunk's reads are done
+        if (probe) t_c = __builtin_amdgcn_s_memtime();
         // next chunk (or the first chunk of the next image: prefetch across the image boundary)
         const bool more = ck + 1 < nchunks;
         const bool dma = more || next_n < a.n;
@@ -230,7 +236,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             }
             // weights as the row operand, pixels as the column operand: the accumulator tile is
             // [32 output channels][32 pixels], so a lane owns ONE pixel and 16 channels (vector stores)
-            __builtin_amdgcn_s_setprio(1);
+            // The two waves that share a SIMD alternate MFMA priority per tap (ping-pong: one issues its MFMA cluster
+            // while the other fetches fragments).  With equal priorities the older half of the workgroup wins
+            // arbitration, finishes ~2000 cycles early and idles at the barrier while the younger half runs a
+            // single-wave tail (s_memtime probe, profiles/r01_conv_timeline.txt); a static priority only flips that.
+            if ((tap + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -241,7 +251,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                     }
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
                 }
-            __builtin_amdgcn_s_setprio(0);
+        }
+        if (probe) {   // [wave][chunk][4]: before the DMA wait, after it, after the barrier, after the last MFMA was issued
+            unsigned long long* d = a.dbg + ((size_t)wave * 64 + dbg_n) * 4;
+            d[0] = t_a; d[1] = t_b; d[2] = t_c; d[3] = __builtin_amdgcn_s_memtime();
+            ++dbg_n;
         }
     }
 

@@ -160,6 +160,11 @@ int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d
                      const float *d_bias, const float *d_bn_scale, const float *d_bn_shift, const void *d_res,
                      void *d_out, void *stream);
 
+/* Timing probe for disco_op_conv3x3 (tools/conv_timeline.py): d_buf = device buffer of 16*64*4 uint64 that workgroup 0
+ * fills with s_memtime stamps per wave and chunk {before DMA wait, after it, after the barrier, after the last MFMA};
+ * NULL switches it off. */
+int disco_op_conv3x3_set_probe(void *d_buf);
+
 /* ConvTranspose2d 4x4 s2 p1 + bias + LeakyReLU(slope): h_w_iohw is the (c_in,c_out,4,4) fp32 weight */
 int disco_op_deconv4x4_pack(const float *h_w_iohw, int c_in, int c_out, void *d_packed, size_t *bytes);
 int disco_op_deconv4x4(const void *d_src, const void *d_packed_w, const float *d_bias, void *d_out, int n,
