@@ -24,6 +24,7 @@
 // (ConvTranspose2d 4x4 s2 p1 expressed as a 4-phase 3x3 conv, network.py:254-258).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "common.h"
 
@@ -264,144 +265,169 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     // image's first chunk, whose DMA was issued during the last chunk - its latency hides behind phase 1;
     // (3) the stores.  vmcnt also counts stores, so with the wait taken here the stores of this image drain
     // under the next image's first chunk instead of stalling its first barrier.
+    // The code is specialised at compile time by output mode (0: channel-blocked act, 1: depth-to-space act,
+    // 2: fp32 NCHW) so the common path carries no integer divisions or dead branches.
     // The epilogue's inputs are invariant across the image loop; without laundering them the compiler hoists
     // ~100 VGPRs of per-channel parameters and lane masks out of the loop and spills.
     int by_e = by, oy0_e = oy0, ox0_e = ox0;
     const float* par_e = s_par;
     asm volatile("" : "+s"(by_e), "+s"(oy0_e), "+s"(ox0_e), "+v"(par_e));
-    // activations are channel-blocked: element (n, ch, y, x) lives at ((n*C/16 + ch/16)*H*W + y*W + x)*16 + ch%16
-    const int cpad = a.c_out_pad;
-    const bool d2s = a.d2s_c > 0;
-    const int oc = d2s ? a.d2s_c : cpad;                       // channels of the output tensor
-    const int oh = d2s ? 2 * a.h_out : a.h_out, ow = d2s ? 2 * a.w_out : a.w_out;
-    const size_t oblk = (size_t)oh * ow * 16;                  // elements per 16-channel block of one image
-    const size_t oimg = (size_t)n * oc * oh * ow;
-    const bool vec_ok = !a.out_f32 && oc % 16 == 0;
-    // element address of output-tensor channel group starting at virtual channel cv (a multiple of 4) of low-res /
-    // plain pixel (oy,ox): plain: channel cv; depth-to-space: phase ph = cv / d2s_c goes to hi-res pixel
-    // (2oy + ph/2, 2ox + ph%2), channel cv % d2s_c (d2s_c is a multiple of 16)
-    auto elem = [&](int cv, int oy, int ox) -> size_t {
-        int cc = cv, yy = oy, xx = ox;
-        if (d2s) { const int ph = cv / a.d2s_c; cc = cv - ph * a.d2s_c; yy = 2 * oy + (ph >> 1); xx = 2 * ox + (ph & 1); }
-        return oimg + (size_t)(cc >> 4) * oblk + ((size_t)yy * ow + xx) * 16 + (cc & 15);
+    const int act = a.act;
+    const float slope = a.slope;
+    const bool has_bn = a.bn_scale != nullptr;
+    auto epilogue = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        // activations are channel-blocked: element (n, ch, y, x) at ((n*C/16 + ch/16)*H*W + y*W + x)*16 + ch%16
+        const int oc = MODE == 1 ? a.d2s_c : a.c_out_pad;          // channels of the output tensor
+        const int oh = MODE == 1 ? 2 * a.h_out : a.h_out, ow = MODE == 1 ? 2 * a.w_out : a.w_out;
+        const size_t oblk = (size_t)oh * ow * 16;                  // elements per 16-channel block of one image
+        const size_t oimg = (size_t)n * oc * oh * ow;
+        // per 16-channel group (nt, q): first channel inside the output tensor and, for depth-to-space, the
+        // sub-pixel phase: virtual channel cv goes to hi-res pixel (2oy + ph/2, 2ox + ph%2), channel cv % d2s_c,
+        // ph = cv / d2s_c (d2s_c is a multiple of 16, so a group never straddles two phases)
+        int cbase[NTW][2], phy[NTW][2], phx[NTW][2];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cv = (by_e * NT + wn * NTW + nt) * 32 + 16 * q;
+                if (MODE == 1) {
+                    const int ph = cv / a.d2s_c;
+                    cbase[nt][q] = cv - ph * a.d2s_c; phy[nt][q] = ph >> 1; phx[nt][q] = ph & 1;
+                } else { cbase[nt][q] = cv; phy[nt][q] = 0; phx[nt][q] = 0; }
+            }
+        // element offset of this lane's pixel for M block mt and channel group (nt, q), channel offset excluded
+        auto pix_off = [&](int mt, int nt, int q, bool& pok) -> size_t {
+            const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
+            const int oy = oy0_e + py, ox = ox0_e + px;
+            pok = oy < a.h_out && ox < a.w_out;
+            if (MODE == 1) return oimg + ((size_t)(2 * oy + phy[nt][q]) * ow + 2 * ox + phx[nt][q]) * 16;
+            return oimg + ((size_t)oy * ow + ox) * 16;
+        };
+        // ---- phase 1: math ----
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            float bias[16], bsc[16], bsh[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                    // channels c(e) = (e&3) + 8*(e>>2) + 4*kh: 4 groups of 4
+                const float4 b4 = *reinterpret_cast<const float4*>(par_e + (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh);
+                bias[g4 * 4] = b4.x; bias[g4 * 4 + 1] = b4.y; bias[g4 * 4 + 2] = b4.z; bias[g4 * 4 + 3] = b4.w;
+            }
+            if (has_bn) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {                // channels c(e) = (e&3) + 8*(e>>2) + 4*kh: 4 groups of 4
+                    const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
+                    const float4 s4 = *reinterpret_cast<const float4*>(par_e + 32 * NT + cl);
+                    const float4 h4 = *reinterpret_cast<const float4*>(par_e + 64 * NT + cl);
+                    bsc[g4 * 4] = s4.x; bsc[g4 * 4 + 1] = s4.y; bsc[g4 * 4 + 2] = s4.z; bsc[g4 * 4 + 3] = s4.w;
+                    bsh[g4 * 4] = h4.x; bsh[g4 * 4 + 1] = h4.y; bsh[g4 * 4 + 2] = h4.z; bsh[g4 * 4 + 3] = h4.w;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[mt][nt][e] + bias[e];
+                if (MODE != 2 && a.res) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        bool pok;
+                        const size_t po = pix_off(mt, nt, g4 >> 1, pok);
+                        const int cc = cbase[nt][g4 >> 1] + 8 * (g4 & 1) + 4 * kh;
+                        if (pok && (by_e * NT + wn * NTW + nt) * 32 + 8 * g4 + 4 * kh < a.c_out) {
+                            const f16* rp = a.res + po + (size_t)(cc >> 4) * oblk + (cc & 15);
+                            const f16x4 rh = *reinterpret_cast<const f16x4*>(rp);
+                            const f16x4 rl = *reinterpret_cast<const f16x4*>(rp + a.res_plane);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[g4 * 4 + j] += (float)rh[j] + (float)rl[j];
+                        }
+                    }
+                }
+                if (act == DISCO_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (act == DISCO_ACT_LRELU) {            // 0 <= slope <= 1 (checked by the launcher)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+                } else if (act == DISCO_ACT_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = tanhf(v[e]);
+                }
+                if (has_bn) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = v[e] * bsc[e] + bsh[e];
+                }
+                if (MODE != 2) {
+                    // split into fp16 hi + lo, packed in pairs (v_cvt_pk_f16_f32): dword d holds channels c(2d), c(2d+1)
+                    unsigned hd[8], ld[8];
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        const f32x2 v2 = {v[2 * d], v[2 * d + 1]};
+                        const f16x2 h2 = __builtin_convertvector(v2, f16x2);
+                        const f16x2 l2 = __builtin_convertvector(v2 - __builtin_convertvector(h2, f32x2), f16x2);
+                        hd[d] = __builtin_bit_cast(unsigned, h2);
+                        ld[d] = __builtin_bit_cast(unsigned, l2);
+                    }
+                    // v_permlane32_swap: lower.(group 1) <-> upper.(group 0), lower.(group 3) <-> upper.(group 2), so
+                    // the lower half-wave holds channels 0-7 and 16-23 of its pixel, the upper half 8-15 and 24-31
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            auto sh = __builtin_amdgcn_permlane32_swap(hd[4 * q + d], hd[4 * q + 2 + d], false, false);
+                            hd[4 * q + d] = sh[0]; hd[4 * q + 2 + d] = sh[1];
+                            auto sl = __builtin_amdgcn_permlane32_swap(ld[4 * q + d], ld[4 * q + 2 + d], false, false);
+                            ld[4 * q + d] = sl[0]; ld[4 * q + 2 + d] = sl[1];
+                        }
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {     // park the packed words in the accumulator registers
+                        acc[mt][nt][d] = __builtin_bit_cast(float, hd[d]);
+                        acc[mt][nt][8 + d] = __builtin_bit_cast(float, ld[d]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mt][nt][e] = v[e];
+                }
+            }
+        }
+        // ---- phase 2: the next image's first chunk has landed ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- phase 3: stores ----
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int cob = (by_e * NT + wn * NTW + nt) * 32;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (MODE != 2) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        bool pok;
+                        const size_t po = pix_off(mt, nt, q, pok);
+                        if (pok && cob + 16 * q + 8 * kh < a.c_out) {       // 8 consecutive channels
+                            const int cc = cbase[nt][q] + 8 * kh;
+                            f16* o = a.out + po + (size_t)(cc >> 4) * oblk + (cc & 15);
+                            const f32x16& t = acc[mt][nt];
+                            *reinterpret_cast<float4*>(o) = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+                            *reinterpret_cast<float4*>(o + a.out_plane) = make_float4(t[8 + 4 * q], t[8 + 4 * q + 1], t[8 + 4 * q + 2], t[8 + 4 * q + 3]);
+                        }
+                    }
+                } else {
+                    const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
+                    const int oy = oy0_e + py, ox = ox0_e + px;
+                    if (oy >= a.h_out || ox >= a.w_out) continue;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                        if (co < a.c_out) a.out_f32[(((size_t)n * a.c_out + co) * a.h_out + oy) * a.w_out + ox] = acc[mt][nt][e];
+                    }
+                }
+            }
+        }
     };
-    // ---- phase 1: math ----
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int cob = (by_e * NT + wn * NTW + nt) * 32;      // first channel of this N block
-        float bias[16], bsc[16], bsh[16];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {                        // channels c(e) = (e&3) + 8*(e>>2) + 4*kh: 4 groups of 4
-            const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
-            const float4 b4 = *reinterpret_cast<const float4*>(par_e + cl);
-            const float4 s4 = *reinterpret_cast<const float4*>(par_e + 32 * NT + cl);
-            const float4 h4 = *reinterpret_cast<const float4*>(par_e + 64 * NT + cl);
-            bias[g4 * 4] = b4.x; bias[g4 * 4 + 1] = b4.y; bias[g4 * 4 + 2] = b4.z; bias[g4 * 4 + 3] = b4.w;
-            bsc[g4 * 4] = s4.x; bsc[g4 * 4 + 1] = s4.y; bsc[g4 * 4 + 2] = s4.z; bsc[g4 * 4 + 3] = s4.w;
-            bsh[g4 * 4] = h4.x; bsh[g4 * 4 + 1] = h4.y; bsh[g4 * 4 + 2] = h4.z; bsh[g4 * 4 + 3] = h4.w;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
-            const int oy = oy0_e + py, ox = ox0_e + px;
-            const bool pok = oy < a.h_out && ox < a.w_out;
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = acc[mt][nt][e] + bias[e];
-            if (a.res && pok) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = cob + 8 * g4 + 4 * kh;
-                    if (co < a.c_out) {
-                        const f16* rp = a.res + elem(co, oy, ox);
-                        const f16x4 rh = *reinterpret_cast<const f16x4*>(rp);
-                        const f16x4 rl = *reinterpret_cast<const f16x4*>(rp + a.res_plane);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[g4 * 4 + j] += (float)rh[j] + (float)rl[j];
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float t = v[e];
-                if (a.act == DISCO_ACT_RELU) t = fmaxf(t, 0.f);
-                else if (a.act == DISCO_ACT_LRELU) t = t >= 0.f ? t : t * a.slope;
-                else if (a.act == DISCO_ACT_TANH) t = tanhf(t);
-                v[e] = t * bsc[e] + bsh[e];
-            }
-            if (vec_ok) {
-                // pack to fp16 pairs: dword d holds channels c(2d), c(2d+1)
-                unsigned hd[8], ld[8];
-#pragma unroll
-                for (int d = 0; d < 8; ++d) {
-                    const f16 h0 = (f16)v[2 * d], h1 = (f16)v[2 * d + 1];
-                    const f16 l0 = (f16)(v[2 * d] - (float)h0), l1 = (f16)(v[2 * d + 1] - (float)h1);
-                    hd[d] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                    ld[d] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-                }
-                // v_permlane32_swap: lower.(group 1) <-> upper.(group 0), lower.(group 3) <-> upper.(group 2), so the
-                // lower half-wave holds channels 0-7 and 16-23 of its pixel, the upper half 8-15 and 24-31
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        auto sh = __builtin_amdgcn_permlane32_swap(hd[4 * q + d], hd[4 * q + 2 + d], false, false);
-                        hd[4 * q + d] = sh[0]; hd[4 * q + 2 + d] = sh[1];
-                        auto sl = __builtin_amdgcn_permlane32_swap(ld[4 * q + d], ld[4 * q + 2 + d], false, false);
-                        ld[4 * q + d] = sl[0]; ld[4 * q + 2 + d] = sl[1];
-                    }
-#pragma unroll
-                for (int d = 0; d < 8; ++d) {     // park the packed words in the accumulator registers
-                    acc[mt][nt][d] = __builtin_bit_cast(float, hd[d]);
-                    acc[mt][nt][8 + d] = __builtin_bit_cast(float, ld[d]);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = v[e];
-            }
-        }
-    }
-    // ---- phase 2: the next image's first chunk has landed ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.out_f32) epilogue(std::integral_constant<int, 2>{});
+    else if (a.d2s_c > 0) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 0>{});
     dma_waited = true;
-    // ---- phase 3: stores ----
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int cob = (by_e * NT + wn * NTW + nt) * 32;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
-            const int oy = oy0_e + py, ox = ox0_e + px;
-            if (!(oy < a.h_out && ox < a.w_out)) continue;
-            if (vec_ok) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int co = cob + 16 * q + 8 * kh;     // 8 consecutive channels
-                    if (co < a.c_out) {
-                        f16* o = a.out + elem(co, oy, ox);
-                        const f32x16& t = acc[mt][nt];
-                        *reinterpret_cast<float4*>(o) = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
-                        *reinterpret_cast<float4*>(o + a.out_plane) = make_float4(t[8 + 4 * q], t[8 + 4 * q + 1], t[8 + 4 * q + 2], t[8 + 4 * q + 3]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                    if (co >= a.c_out) continue;
-                    const float val = acc[mt][nt][e];
-                    if (a.out_f32) {
-                        a.out_f32[(((size_t)n * a.c_out + co) * a.h_out + oy) * a.w_out + ox] = val;
-                    } else {
-                        const size_t idx = elem(co, oy, ox);
-                        const f16 hi = (f16)val;
-                        a.out[idx] = hi;
-                        a.out[idx + a.out_plane] = (f16)(val - (float)hi);
-                    }
-                }
-            }
-        }
-    }
 
     n = next_n;
     if (n >= a.n) break;
@@ -557,6 +583,8 @@ int launch_conv3x3_v2(const ConvArgs& a_in, hipStream_t s) {
         set_error("conv3x3: input channels must be multiples of 16 (got %d)", a.c_in);
         return DISCO_ESHAPE;
     }
+    if (a.d2s_c > 0 && (a.d2s_c % 16 || a.out_f32)) { set_error("conv3x3: depth-to-space needs a multiple of 16 channels (got %d) and an activation output", a.d2s_c); return DISCO_ESHAPE; }
+    if (a.act == DISCO_ACT_LRELU && !(a.slope >= 0.f && a.slope <= 1.f)) { set_error("conv3x3: LeakyReLU slope %g outside [0, 1]", (double)a.slope); return DISCO_ESHAPE; }
     if (a.c_out > 32 && a.c_out % 64) { set_error("conv3x3: c_out %d (>32) must be a multiple of 64", a.c_out); return DISCO_ESHAPE; }
     for (int i = 0; i < a.nsrc; ++i)
         if ((size_t)a.src[i].h * a.src[i].w * 16 >= (1u << 30)) {
