@@ -132,9 +132,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # registers-only MFMA loop on the same operand mix (after the timed region): the rate the power-managed clock
+    # sustains for this data, i.e. the practical ceiling under the 2.5 PFLOP/s datasheet peak
+    sustained = None
+    if rank == 0:
+        import ctypes
+        from disentangledcolorization_amd import _ffi
+        tf = ctypes.c_double(0.0)
+        _ffi.check(_ffi.lib().disco_diag_mfma_rate(2 if args.precision == "f16x3" else 1, 8000, ctypes.byref(tf)))
+        sustained = tf.value
+
     if rank == 0:
         ips = n_global * args.steps / elapsed
         achieved = conv_fl / (conv_ms * 1e-3) if conv_ms > 0 else 0.0
+        executed = (3 if args.precision == "f16x3" else 1) * achieved / 1e12
         out = {
             "metric": "colorized 256x256 images/sec", "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,7 +164,9 @@ def main():
                 "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_fl / max(conv_launches, 1) / 1e9, 3),
                 "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK, 4),
-                "executed_mfma_tflops": round((3 if args.precision == "f16x3" else 1) * achieved / 1e12, 2),
+                "executed_mfma_tflops": round(executed, 2),
+                "sustained_mfma_tflops_same_operand_mix": round(sustained, 1),
+                "executed_frac_of_sustained": round(executed / sustained, 4) if sustained else None,
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
             },
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},

@@ -68,6 +68,7 @@ SIGNATURES = {
     "disco_op_conv3x3_pack": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_conv3x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "disco_op_conv3x3_set_probe": (_I, [_P]),
+    "disco_diag_mfma_rate": (_I, [_I, _I, C.POINTER(C.c_double)]),
     "disco_op_deconv4x4_pack": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_deconv4x4": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "disco_op_poolfeat": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),

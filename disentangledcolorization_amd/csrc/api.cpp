@@ -948,6 +948,8 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
 
 int disco_op_conv3x3_set_probe(void* d_buf) { g_conv_probe = (unsigned long long*)d_buf; return DISCO_OK; }
 
+int disco_diag_mfma_rate(int mode, int iters, double* tflops) { return diag_mfma_rate(mode, iters, tflops); }
+
 int disco_op_deconv4x4_pack(const float* h_w, int c_in, int c_out, void* d_packed, size_t* bytes) {
     if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }
     const int cpad = round_up(c_in, 16);

@@ -1,0 +1,92 @@
+// Diagnostics: the sustained MFMA rate of the device under a given operand data mix (include/disco_hip.h,
+// disco_diag_mfma_rate).  Registers only - no LDS, no memory traffic in the timed loop - so what it measures is the
+// matrix pipe at the clock the power manager sustains for that data, the practical ceiling of conv3x3_mfma2_kernel.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <vector>
+#include "common.h"
+
+namespace disco {
+namespace {
+
+__global__ __launch_bounds__(512) void mfma_rate_kernel(const f16x8* __restrict__ ops, float* __restrict__ out, int iters, int mix) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63;
+    f16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = ops[i * 64 + lane]; b[i] = ops[(4 + i) * 64 + lane]; }
+    const f16x8 al = ops[8 * 64 + lane], bl = ops[9 * 64 + lane];
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        // 12 MFMAs over 4 independent accumulators, product-major like the conv kernel's inner loop
+        if (mix) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, a[i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[i], al, acc[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[(i + 1) & 3], a[i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[i], a[(i + 2) & 3], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[i], a[i], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 123.456f) out[0] = s;     // keeps the chains alive
+#endif
+}
+
+float gauss(unsigned& st) {           // sum of 12 uniforms - 6
+    float u = 0.f;
+    for (int i = 0; i < 12; ++i) { st = st * 1664525u + 1013904223u; u += (st >> 8) * (1.f / 16777216.f); }
+    return u - 6.f;
+}
+
+}  // namespace
+
+int diag_mfma_rate(int mode, int iters, double* tflops) {
+    if (mode < 0 || mode > 2 || iters <= 0 || !tflops) { set_error("diag_mfma_rate: mode %d iters %d", mode, iters); return DISCO_EINVAL; }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        set_error("diag_mfma_rate: no HIP device"); return DISCO_EHIP;
+    }
+    std::vector<f16> h(10 * 64 * 8);
+    unsigned st = 12345u;
+    for (size_t i = 0; i < h.size(); ++i) {
+        float v = mode == 0 ? 0.f : gauss(st);
+        if (mode == 2 && i >= (size_t)8 * 64 * 8) v *= 4.8e-4f;     // lo planes: ~2^-11 of the hi magnitude
+        h[i] = (f16)v;
+    }
+    f16x8* d_ops = nullptr; float* d_out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = DISCO_OK;
+    float ms = 0.f;
+    const int blocks = cus * 4;
+    if (hipMalloc(&d_ops, h.size() * sizeof(f16)) != hipSuccess || hipMalloc(&d_out, sizeof(float)) != hipSuccess ||
+        hipMemcpy(d_ops, h.data(), h.size() * sizeof(f16), hipMemcpyHostToDevice) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { set_error("diag_mfma_rate: HIP allocation failed"); rc = DISCO_EHIP; }
+    for (int rep = 0; rep < 2 && rc == DISCO_OK; ++rep) {          // rep 0 settles clocks / power state
+        hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(512), 0, nullptr, d_ops, d_out, iters, mode == 2 ? 1 : 0);
+        hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { set_error("diag_mfma_rate: kernel failed"); rc = DISCO_EHIP; }
+    }
+    if (rc == DISCO_OK) *tflops = (double)blocks * 8 * iters * 12 * 2.0 * 32 * 32 * 16 / ((double)ms * 1e9);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (d_ops) hipFree(d_ops);
+    if (d_out) hipFree(d_out);
+    return rc;
+}
+
+}  // namespace disco

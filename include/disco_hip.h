@@ -165,6 +165,13 @@ int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d
  * NULL switches it off. */
 int disco_op_conv3x3_set_probe(void *d_buf);
 
+/* Diagnostic: sustained v_mfma_f32_32x32x16_f16 rate of the current device on a registers-only loop (no LDS, no
+ * memory), 2 waves per SIMD on every CU, operands: mode 0 = zeros, 1 = N(0,1) fp16, 2 = the f16x3 product mix
+ * (hi*lo, lo*hi, hi*hi) the conv kernel issues.  The MI355X clock is power-managed and MFMA power depends on operand
+ * toggling, so this - not the 2.5 PFLOP/s datasheet peak - is what a kernel with this data can reach.  Blocking;
+ * *tflops = executed TFLOP/s of the second (warm) run of `iters` iterations x 12 MFMAs per wave. */
+int disco_diag_mfma_rate(int mode, int iters, double *tflops);
+
 /* ConvTranspose2d 4x4 s2 p1 + bias + LeakyReLU(slope): h_w_iohw is the (c_in,c_out,4,4) fp32 weight */
 int disco_op_deconv4x4_pack(const float *h_w_iohw, int c_in, int c_out, void *d_packed, size_t *bytes);
 int disco_op_deconv4x4(const void *d_src, const void *d_packed_w, const float *d_bias, void *d_out, int n,
