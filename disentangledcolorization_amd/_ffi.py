@@ -21,12 +21,14 @@ class DiscoError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("sp_size", C.c_int32), ("n_clusters", C.c_int32), ("random_hint", C.c_int32),
-                ("precision", C.c_int32), ("segnet_only", C.c_int32)]
+                ("precision", C.c_int32), ("segnet_only", C.c_int32), ("hint2regress", C.c_int32),
+                ("spix_pos", C.c_int32)]
 
 
 class ForwardArgs(C.Structure):
     _fields_ = [
         ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("sampled_T", C.c_int32),
+        ("test_mode", C.c_int32),
         ("d_gray", C.c_void_p), ("d_ab", C.c_void_p),
         ("h_init_idx", C.c_void_p), ("h_fallback_rows", C.c_void_p), ("max_fallback", C.c_int32),
         ("h_hint_pos", C.c_void_p),
@@ -53,6 +55,7 @@ SIGNATURES = {
     "disco_load_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
     "disco_finalize": (_I, [_P]),
     "disco_expected_tensors": (_I, []),
+    "disco_expected_tensor_ctx": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "disco_expected_tensor": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(_I)]),
     "disco_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "disco_forward": (_I, [_P, C.POINTER(ForwardArgs)]),
@@ -75,7 +78,7 @@ SIGNATURES = {
     "disco_op_upfeat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_encoder_weight_floats": (_SZ, []),
     "disco_op_encoder_stack": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
-    "disco_op_kmeans_anchors": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "disco_op_kmeans_anchors": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_select_colors": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "disco_op_nearest_bin": (_I, [_P, _P, _I, _I, _P]),
     "disco_op_position_encoding": (_I, [_P, _I, _I, _P]),

@@ -46,7 +46,7 @@ struct Layout {
         add(k + ".weight", {c}); add(k + ".bias", {c}); add(k + ".running_mean", {c}); add(k + ".running_var", {c});
         add(k + ".num_batches_tracked", {}, true);
     }
-    Layout() {
+    explicit Layout(bool hint2regress) {
         const std::string s = "segnet.net.";
         const char* seg[10] = {"conv0a", "conv0b", "conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"};
         const int seg_ci[10] = {1, 16, 16, 32, 32, 64, 64, 128, 128, 256}, seg_co[10] = {16, 16, 32, 32, 64, 64, 128, 128, 256, 256};
@@ -95,10 +95,15 @@ struct Layout {
                 add(q + "linear2.weight", {64, 256}); add(q + "linear2.bias", {64});
                 add(q + "norm1.weight", {64}); add(q + "norm1.bias", {64}); add(q + "norm2.weight", {64}); add(q + "norm2.bias", {64});
             }
-        add("mid_word_prj.weight", {313, 64}); add("trg_word_emb.weight", {64, 378}); add("trg_word_prj.weight", {313, 64});
+        add("mid_word_prj.weight", {313, 64});
+        if (hint2regress) { add("trg_word_emb.weight", {64, 67}); add("trg_word_prj.weight", {2, 64}); }   // model.py:63-64
+        else { add("trg_word_emb.weight", {64, 378}); add("trg_word_prj.weight", {313, 64}); }          // model.py:66-67
     }
 };
-const Layout& layout() { static Layout l; return l; }
+const Layout& layout(bool hint2regress = false) {
+    static Layout plain(false), h2r(true);
+    return hint2regress ? h2r : plain;
+}
 
 // the 313 in-gamut ab bins as (a, b_min, b_max) runs (utils/gamut_pts.npy; same table as gamut.py)
 const int GAMUT_RUNS[20][3] = {{-90, 50, 90}, {-80, 20, 90}, {-70, 0, 90}, {-60, -20, 90}, {-50, -30, 100}, {-40, -40, 100},
@@ -505,7 +510,8 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     Plan P(c, a, cap, dry);
     const int n = a->n, H = a->h, W = a->w, sp = c->opt.sp_size, K = c->opt.n_clusters;
     const int hs = H / sp, ws = W / sp, L = hs * ws;
-    const int rep = a->sampled_T > 0 ? 3 : 1, n2 = n * rep;
+    const bool test = a->test_mode != 0, h2r = c->opt.hint2regress != 0, spos = c->opt.spix_pos != 0;
+    const int rep = (test && a->sampled_T > 0) ? 3 : 1, n2 = n * rep;
     const double px = (double)n * H * W;
     hipStream_t s = P.s;
     if (!dry) {
@@ -548,25 +554,32 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     float* src = (float*)P.raw((size_t)n * L * 64 * 4);
     float* spix_ab = (float*)P.raw((size_t)n * 2 * L * 4);
     float* sizes = (float*)P.raw((size_t)n * L * 4);
-    void* pool_ws = P.raw(poolfeat_ws_bytes(n, 66, H, W, sp));
+    // --spix_pos (model.py:106-112): the sine encoding of every PIXEL is pooled with the features (64 more channels,
+    // the same (H*W,64) table for every image), so each image gets its own position sequence (n,L,64)
+    const int cpool = spos ? 130 : 66;
+    float* pos_img = spos ? (float*)P.raw((size_t)n * L * 64 * 4) : nullptr;
+    void* pool_ws = P.raw(poolfeat_ws_bytes(n, cpool, H, W, sp));
+    float* pos = nullptr;
+    if (!dry && P.ok()) P.rc = spos ? get_pos(c, H, W, &pos) : get_pos(c, hs, ws, &pos);
     if (!dry && P.ok()) {
         PoolArgs pa{};
         pa.feat_act = feats.p; pa.feat_plane = (long)feats.plane; pa.c_act = 64;
         pa.feat_nchw = a->d_ab; pa.c_nchw = 2; pa.prob = a->d_affinity;
-        pa.partial = (float*)pool_ws; pa.cnt = (float*)pool_ws + (size_t)n * L * 9 * 67;
+        if (spos) { pa.feat_bc = pos; pa.c_bc = 64; pa.bc_out = pos_img; }
+        pa.partial = (float*)pool_ws; pa.cnt = (float*)pool_ws + (size_t)n * L * 9 * (cpool + 1);
         pa.tok_out = src; pa.c_tok = 64; pa.nchw_out = spix_ab; pa.c_from = 64;
         pa.conf = nullptr; pa.sizes = sizes; pa.n = n; pa.H = H; pa.W = W; pa.sp = sp;
         P.rc = launch_poolfeat(pa, s);
     }
     P.drop(pool_ws); P.drop(feats);
-    float* pos = nullptr;
-    if (!dry && P.ok()) P.rc = get_pos(c, hs, ws, &pos);
+    if (spos) pos = pos_img;
+    const int pos_rep = spos ? 1 : 0;       // wild path: one position sequence per image; hint path: per virtual image / rep
     P.mark("poolfeat");
 
     // ---- a6/a7 wild path + palette logits (model.py:133-135) -------------------------------------------------
     float* enc = (float*)P.raw((size_t)n * L * 64 * 4);
     void* enc_ws = P.raw(encoder_ws_bytes(n2, L));
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, c->d_enc[0], enc, n, L, enc_ws, s);
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s);
     if (!dry && P.ok()) P.rc = launch_logits(enc, c->d_mid_w, a->d_pal_logit, n, L, s);
     P.mark("wildpath", 2.0 * 0.134e9 * n);
 
@@ -590,7 +603,10 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
             else {
                 P.rc = staged_h2d(c, d_idx, a->h_init_idx, (size_t)n * K * 4, s);
                 if (P.ok() && mf) P.rc = staged_h2d(c, d_fb, a->h_fallback_rows, (size_t)n * mf * 4, s);
-                if (P.ok()) P.rc = launch_kmeans_anchors(enc, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s);
+                // inference clusters the wild-path tokens (model.py:140-141); the validation forward clusters the pooled
+                // GT colours (N,2,h,w) (model.py:169-171)
+                if (P.ok()) P.rc = test ? launch_kmeans_anchors(enc, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s)
+                                        : launch_kmeans_anchors(spix_ab, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s, 2, 1);
             }
         }
     }
@@ -599,7 +615,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     // ---- a10/a11 anchor colours + labels (model.py:142-168) ----------------------------------------------------
     int32_t* labels = (int32_t*)P.raw((size_t)n2 * L * 4);
     if (!dry && P.ok()) {
-        if (a->sampled_T < 0) {
+        if (!test || a->sampled_T < 0) {
             if (hipMemcpyAsync(a->d_spix_colors, spix_ab, (size_t)n * 2 * L * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) P.rc = DISCO_EHIP;
             if (P.ok()) P.rc = launch_nearest_bin(spix_ab, c->d_q_to_ab, labels, n, L, s);
         } else {
@@ -609,11 +625,11 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     // ---- hint tokens + hint path + refined logits (model.py:175-189) -------------------------------------------
     float* hint = (float*)P.raw((size_t)n2 * L * 64 * 4);
     float* dec = (float*)P.raw((size_t)n2 * L * 64 * 4);
-    if (!dry && P.ok()) P.rc = launch_hint_embed(src, rep, labels, a->d_hint_mask, rep, c->d_emb_w, hint, n2, L, s);
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(hint, pos, c->d_enc[1], dec, n2, L, enc_ws, s);
-    if (!dry && P.ok()) P.rc = launch_logits(dec, c->d_trg_w, a->d_ref_logit, n2, L, s);
+    if (!dry && P.ok()) P.rc = launch_hint_embed(src, rep, h2r ? nullptr : labels, h2r ? a->d_spix_colors : nullptr, a->d_hint_mask, rep, c->d_emb_w, hint, n2, L, s);
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(hint, pos, pos_rep ? rep : 0, c->d_enc[1], dec, n2, L, enc_ws, s);
+    if (!dry && P.ok()) P.rc = launch_logits(dec, c->d_trg_w, a->d_ref_logit, n2, L, s, h2r ? 2 : N_VOCAB);
     P.drop(enc_ws); P.drop(hint); P.drop(labels); P.drop(d_idx); P.drop(d_fb); P.drop(d_assign); P.drop(d_anchor);
-    P.drop(enc); P.drop(src); P.drop(spix_ab); P.drop(sizes);
+    P.drop(enc); P.drop(src); P.drop(spix_ab); P.drop(sizes); if (pos_img) P.drop(pos_img);
     P.mark("hintpath", 2.0 * 0.134e9 * n2);
 
     // ---- a12 upfeat + a13 HourGlass2 + tanh (model.py:194-197) --------------------------------------------------
@@ -668,6 +684,9 @@ int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
     if (a->n < 1 || a->h < sp || a->w < sp || a->h % sp || a->w % sp) { set_error("bad input size %dx%dx%d (multiples of %d)", a->n, a->h, a->w, sp); return DISCO_ESHAPE; }
     if (!c->opt.segnet_only && (a->h / sp) * (a->w / sp) < c->opt.n_clusters) { set_error("fewer tokens than clusters"); return DISCO_ESHAPE; }
     if (a->max_fallback > c->opt.n_clusters * 20) { set_error("max_fallback %d > K*20", a->max_fallback); return DISCO_EINVAL; }
+    if (a->test_mode & ~1) { set_error("test_mode must be 0 or 1"); return DISCO_EINVAL; }
+    // model.py:178 reads the undefined name `spix_color` when hint2regress meets test_mode=False: the reference raises
+    if (!a->test_mode && c->opt.hint2regress) { set_error("hint2regress has no validation forward (models/model.py:178 raises NameError)"); return DISCO_EUNSUPPORTED; }
     return DISCO_OK;
 }
 
@@ -680,13 +699,20 @@ extern "C" {
 
 int disco_expected_tensors(void) { return (int)layout().t.size(); }
 
-int disco_expected_tensor(int i, const char** key, int64_t shape[4], int* ndim) {
-    if (i < 0 || i >= (int)layout().t.size() || !key || !shape || !ndim) { set_error("bad index"); return DISCO_EINVAL; }
-    const ExpectedTensor& e = layout().t[i];
+static int expected_tensor(const Layout& l, int i, const char** key, int64_t shape[4], int* ndim) {
+    if (i < 0 || i >= (int)l.t.size() || !key || !shape || !ndim) { set_error("bad index"); return DISCO_EINVAL; }
+    const ExpectedTensor& e = l.t[i];
     *key = e.key.c_str();
     *ndim = (int)e.shape.size();
     for (int d = 0; d < *ndim; ++d) shape[d] = e.shape[d];
     return DISCO_OK;
+}
+
+int disco_expected_tensor(int i, const char** key, int64_t shape[4], int* ndim) { return expected_tensor(layout(), i, key, shape, ndim); }
+
+int disco_expected_tensor_ctx(disco_ctx* c, int i, const char** key, int64_t shape[4], int* ndim) {
+    if (!c) { set_error("null context"); return DISCO_EINVAL; }
+    return expected_tensor(layout(c->opt.hint2regress != 0), i, key, shape, ndim);
 }
 
 int disco_create(int device, const disco_options* opt, disco_ctx** out) {
@@ -694,6 +720,8 @@ int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (opt->sp_size != 16) { set_error("sp_size %d unsupported (16 only, inference.py:146)", opt->sp_size); return DISCO_EUNSUPPORTED; }
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
     if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_F16X1) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
+    if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }
+    if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("segnet_only context takes no colorizer flags"); return DISCO_EINVAL; }
     int ndev = 0;
     DISCO_HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) { set_error("device %d of %d", device, ndev); return DISCO_EINVAL; }
@@ -732,7 +760,8 @@ int disco_finalize(disco_ctx* c) {
     const bool seg_only = c->opt.segnet_only != 0;
     // strict: same key set and shapes as the reference's load_state_dict(strict=True) (utils_train.py:151)
     size_t n_expected = 0;
-    for (const ExpectedTensor& e : layout().t) {
+    const Layout& lay = layout(c->opt.hint2regress != 0);
+    for (const ExpectedTensor& e : lay.t) {
         if (seg_only && e.key.compare(0, 11, "segnet.net.") != 0) continue;
         ++n_expected;
         auto it = c->sd.find(e.key);
@@ -743,7 +772,7 @@ int disco_finalize(disco_ctx* c) {
     if (c->sd.size() != n_expected) {
         for (auto& kv : c->sd) {
             bool found = false;
-            for (const ExpectedTensor& e : layout().t)
+            for (const ExpectedTensor& e : lay.t)
                 if (e.key == kv.first && (!seg_only || e.key.compare(0, 11, "segnet.net.") == 0)) { found = true; break; }
             if (!found) { set_error("unexpected key in state_dict: %s", kv.first.c_str()); return DISCO_ESTATE; }
         }
@@ -813,7 +842,7 @@ int disco_finalize(disco_ctx* c) {
 int disco_workspace_bytes(disco_ctx* c, int n, int h, int w, int sampled_T, size_t* bytes) {
     if (!bytes) { set_error("null argument"); return DISCO_EINVAL; }
     disco_forward_args a{};
-    a.n = n; a.h = h; a.w = w; a.sampled_T = sampled_T;
+    a.n = n; a.h = h; a.w = w; a.sampled_T = sampled_T; a.test_mode = 1;   // inference needs at least what validation does
     int rc = check_forward_args(c, &a);
     if (rc) return rc;
     size_t peak = 0;
@@ -1001,15 +1030,15 @@ int disco_op_encoder_stack(const float* d_x, const float* d_pos, const float* d_
                            size_t ws_bytes, void* stream) {
     if (!d_x || !d_pos || !d_weights || !d_out || !d_ws) { set_error("null argument"); return DISCO_EINVAL; }
     if (ws_bytes < encoder_ws_bytes(n, l)) { set_error("encoder workspace too small (%zu < %zu)", ws_bytes, encoder_ws_bytes(n, l)); return DISCO_ENOMEM; }
-    return launch_encoder_stack(d_x, d_pos, d_weights, d_out, n, l, d_ws, (hipStream_t)stream);
+    return launch_encoder_stack(d_x, d_pos, 0, d_weights, d_out, n, l, d_ws, (hipStream_t)stream);
 }
 
 int disco_op_kmeans_anchors(const float* d_x, const float* d_sizes, const int32_t* d_init_idx, const int32_t* d_fallback_rows,
                             int max_fallback, int32_t* d_assign, int32_t* d_anchor, float* d_hint_mask, int32_t* d_info, int n,
-                            int l, int k, void* stream) {
+                            int l, int k, int d, int channel_major, void* stream) {
     if (!d_x || !d_sizes || !d_init_idx || !d_assign || !d_anchor || !d_hint_mask) { set_error("null argument"); return DISCO_EINVAL; }
     return launch_kmeans_anchors(d_x, d_sizes, d_init_idx, d_fallback_rows, max_fallback, d_assign, d_anchor, d_hint_mask, d_info,
-                                 n, l, k, (hipStream_t)stream);
+                                 n, l, k, (hipStream_t)stream, d, channel_major);
 }
 
 static int gamut_device(float** out) {

@@ -112,12 +112,15 @@ int launch_act_to_nchw(const f16* src, long plane, float* dst, int n, int c, int
 // feature source for pooling: either act planes (c_act channels) and/or extra fp32 NCHW channels
 struct PoolArgs {
     const f16* feat_act; long feat_plane; int c_act;   // NHWC act features, channels [0,c_act)   (may be null)
-    const float* feat_nchw; int c_nchw;                 // fp32 NCHW features, channels [c_act, C)  (may be null)
+    const float* feat_nchw; int c_nchw;                 // fp32 NCHW features, channels [c_act, c_act+c_nchw)  (may be null)
+    const float* feat_bc; int c_bc;                     // fp32 (H*W, c_bc) pixel-major features shared by every image of
+                                                        // the batch (the per-pixel position encoding of --spix_pos); last
     const float* prob;                                  // (n,9,H,W) fp32
     float* partial;                                     // workspace (cells,9,C+1)
     float* cnt;                                         // workspace (cells,9)
     float* tok_out; int c_tok;                          // channels [0,c_tok) as tokens (n,L,c_tok)  (may be null)
-    float* nchw_out; int c_from;                        // channels [c_from,C) as NCHW (n,C-c_from,h,w) (may be null)
+    float* nchw_out; int c_from;                        // channels [c_from,c_act+c_nchw) as NCHW (n,.,h,w) (may be null)
+    float* bc_out;                                      // the pooled feat_bc channels as tokens (n,L,c_bc) (may be null)
     float* conf;                                        // (n,1,h,w) or null
     float* sizes;                                       // (n,h*w) or null
     int n, H, W, sp;
@@ -140,11 +143,12 @@ constexpr int ENC_LAYERS = 6;
 //                              l2_w(64x256) l2_b(64) n1_w n1_b n2_w n2_b (64 each)
 constexpr size_t ENC_LAYER_FLOATS = 192 * 64 + 192 + 64 * 64 + 64 + 256 * 64 + 256 + 64 * 256 + 64 + 4 * 64;
 size_t encoder_ws_bytes(int n, int l);
-int launch_encoder_stack(const float* x, const float* pos, const float* weights, float* out, int n, int l, void* ws,
-                         hipStream_t s);
+// pos: (l,64) shared by all images (pos_rep = 0) or (n/pos_rep, l, 64), virtual image i using image i/pos_rep
+int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
+                         void* ws, hipStream_t s);
 void position_encoding_host(float* h_pos /*(h*w,64)*/, int h, int w);
-// logits: (n,L,64) x (313,64)^T -> NCHW (n,313,L)
-int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s);
+// logits: (n,L,64) x (n_out,64)^T -> NCHW (n,n_out,L)
+int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s, int n_out = N_VOCAB);
 int launch_select_colors(const float* logit_nchw, const float* q_to_ab, float* colors, int32_t* labels, int n, int l,
                          int t_first, int t_count, hipStream_t s, int plain_rank = -1);
 // colour space (models/basic.py:395-475): rgb in [0,1] <-> normalised Lab ((L-50)/50, a/110, b/110), fp32 NCHW
@@ -153,10 +157,11 @@ int launch_lab2rgb(const float* lab, float* rgb, long npix_total, long hw, hipSt
 int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labels, int n, int l, hipStream_t s);
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,
-                          int l, int k, hipStream_t s);
+                          int l, int k, hipStream_t s, int d = 64, int channel_major = 0);   // x: (n,l,d) or (n,d,l)
 int launch_hint_mask_from_pos(const int32_t* pos, float* hint_mask, int n, int l, int k, hipStream_t s);
-// hint[t] = W[:, :64] src + m W[:, 64+label] + m W[:, 377]
-int launch_hint_embed(const float* src, int src_rep, const int32_t* labels, const float* mask, int mask_rep,
-                      const float* w_emb, float* out, int n, int l, hipStream_t s);
+// hint[t] = W[:, :64] src + m W[:, 64+label] + m W[:, 377]           (labels, W (64,378))
+//         = W[:, :64] src + m a W[:, 64] + m b W[:, 65] + m W[:, 66]  (hint2regress: colors (n,2,l), W (64,67))
+int launch_hint_embed(const float* src, int src_rep, const int32_t* labels, const float* colors, const float* mask,
+                      int mask_rep, const float* w_emb, float* out, int n, int l, hipStream_t s);
 
 }  // namespace disco

@@ -17,7 +17,7 @@ namespace {
 
 // blockDim = 256; grid = n*h*w cells
 __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
-    const int C = a.c_act + a.c_nchw;  // feature channels (ones channel is index C)
+    const int C = a.c_act + a.c_nchw + a.c_bc;  // feature channels (ones channel is index C)
     const int hs = a.H / a.sp, ws = a.W / a.sp;
     const int cell = blockIdx.x;
     const int cx = cell % ws, cy = (cell / ws) % hs, n = cell / (ws * hs);
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
                         else if (ch < a.c_act) {
                             const long idx = (((long)n * (a.c_act >> 4) + (ch >> 4)) * HW + pix) * 16 + (ch & 15);
                             f[u] = (float)a.feat_act[idx] + (float)a.feat_act[idx + a.feat_plane];
-                        } else f[u] = a.feat_nchw[((long)n * a.c_nchw + (ch - a.c_act)) * HW + pix];
+                        } else if (ch < a.c_act + a.c_nchw) f[u] = a.feat_nchw[((long)n * a.c_nchw + (ch - a.c_act)) * HW + pix];
+                        else f[u] = a.feat_bc[pix * a.c_bc + (ch - a.c_act - a.c_nchw)];
                     }
                 }
 #pragma unroll
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
 }
 
 __global__ void pool_gather_kernel(PoolArgs a) {
-    const int C = a.c_act + a.c_nchw;
+    const int C = a.c_act + a.c_nchw + a.c_bc, C2 = a.c_act + a.c_nchw;
     const int hs = a.H / a.sp, ws = a.W / a.sp, L = hs * ws;
     const long total = (long)a.n * L * (C + 1);
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -124,7 +125,8 @@ __global__ void pool_gather_kernel(PoolArgs a) {
         } else {
             const float v = num / (den + 1e-8f);
             if (a.tok_out && ch < a.c_tok) a.tok_out[((long)n * L + tok) * a.c_tok + ch] = v;
-            if (a.nchw_out && ch >= a.c_from) a.nchw_out[((long)n * (C - a.c_from) + (ch - a.c_from)) * L + tok] = v;
+            if (a.nchw_out && ch >= a.c_from && ch < C2) a.nchw_out[((long)n * (C2 - a.c_from) + (ch - a.c_from)) * L + tok] = v;
+            if (a.bc_out && ch >= C2) a.bc_out[((long)n * L + tok) * a.c_bc + (ch - C2)] = v;
         }
     }
 }
@@ -249,7 +251,7 @@ size_t poolfeat_ws_bytes(int n, int c, int H, int W, int sp) {
 }
 
 int launch_poolfeat(const PoolArgs& a, hipStream_t s) {
-    const int C = a.c_act + a.c_nchw;
+    const int C = a.c_act + a.c_nchw + a.c_bc;
     if (a.H % a.sp || a.W % a.sp) { set_error("poolfeat: %dx%d not a multiple of sp=%d", a.H, a.W, a.sp); return DISCO_ESHAPE; }
     const int cells = a.n * (a.H / a.sp) * (a.W / a.sp);
     const size_t smem = ((size_t)a.sp * a.sp * 9 + 4 * 9 * 64) * sizeof(float);

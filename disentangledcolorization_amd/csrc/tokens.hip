@@ -24,7 +24,8 @@ enum { EPI_QKV = 0, EPI_RELU = 1, EPI_RES_LN = 2, EPI_LOGIT = 3, EPI_HINT = 4 };
 struct GemmArgs {
     const float* A;      // (rows_a, K)
     int a_rep;           // virtual image i reads A image i / a_rep
-    const float* pos;    // (L,64) added to A for EPI_QKV q,k tiles
+    const float* pos;    // (L,64) added to A for EPI_QKV q,k tiles; pos_rep > 0: (n/pos_rep, L, 64), one per image
+    int pos_rep;
     const float* W;      // (O, ldw) row-major; the first K columns are contracted
     int ldw;
     const float* bias;   // (O) or null
@@ -34,7 +35,8 @@ struct GemmArgs {
     const float* ln_w;
     const float* ln_b;
     float q_scale;
-    const int32_t* labels;  // HINT: (T)
+    const int32_t* labels;  // HINT: (T); null = hint2regress, the anchors' ab values are embedded instead
+    const float* colors;    // HINT (hint2regress): (n,2,L) NCHW ab/110 of every virtual image
     const float* mask;      // HINT: (T / mask_rep ...) indexed like A with mask_rep
     int mask_rep;
 };
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256) void token_gemm_kernel(const GemmArgs g) {
                 const float* ap = g.A + ((size_t)(img / g.a_rep) * g.L + t) * g.K + k0 + c4;
                 v = *reinterpret_cast<const float4*>(ap);
                 if (add_pos) {
-                    const float4 p = *reinterpret_cast<const float4*>(g.pos + (size_t)t * 64 + c4);
+                    const size_t pimg = g.pos_rep > 0 ? (size_t)(img / g.pos_rep) * g.L : 0;
+                    const float4 p = *reinterpret_cast<const float4*>(g.pos + (pimg + t) * 64 + c4);
                     v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
                 }
             }
@@ -126,12 +129,21 @@ __global__ __launch_bounds__(256) void token_gemm_kernel(const GemmArgs g) {
     } else if (EPI == EPI_HINT) {
         if (rok) {
             const float m = g.mask[(size_t)(img / g.mask_rep) * g.L + t];
-            const int lab = g.labels[row];
             float* o = g.out + (size_t)row * 64 + cq;
+            if (g.labels) {
+                const int lab = g.labels[row];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float* wr = g.W + (size_t)(cq + j) * g.ldw;
-                o[j] = v[j] + m * wr[64 + lab] + m * wr[64 + N_VOCAB];
+                for (int j = 0; j < 16; ++j) {
+                    const float* wr = g.W + (size_t)(cq + j) * g.ldw;
+                    o[j] = v[j] + m * wr[64 + lab] + m * wr[64 + N_VOCAB];
+                }
+            } else {   // hint2regress (model.py:177-181): [src ; m*a ; m*b ; m] x trg_word_emb (64,67)
+                const float ca = m * g.colors[((size_t)img * 2) * g.L + t], cb = m * g.colors[((size_t)img * 2 + 1) * g.L + t];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float* wr = g.W + (size_t)(cq + j) * g.ldw;
+                    o[j] = v[j] + ca * wr[64] + cb * wr[65] + m * wr[66];
+                }
             }
         }
     } else {  // EPI_RES_LN: y = LayerNorm(res + v), biased variance, eps 1e-5
@@ -232,12 +244,15 @@ constexpr int KMAX = 32;
 constexpr int KM_LDS_TOKENS = 384;
 constexpr int KM_PITCH = 65;
 template <bool XLDS>
-__global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
+__global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restrict__ x, int D, long img_stride, int t_stride,
+                                                            int c_stride, const float* __restrict__ sizes,
                                                             const int32_t* __restrict__ init_idx,
                                                             const int32_t* __restrict__ fallback, int max_fallback,
                                                             int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
                                                             int32_t* info, int L, int K) {
-    extern __shared__ float dyn[];          // XLDS: [L][KM_PITCH] tokens, then [L] assignments (as int)
+    // point t, feature c of image img: x[img*img_stride + t*t_stride + c*c_stride]; D <= 64 features.
+    // (L,64) token rows: t_stride 64, c_stride 1;  NCHW (2,L) colours (validation forward): t_stride 1, c_stride L
+    extern __shared__ float dyn[];          // XLDS: [L][D+1] points, then [L] assignments (as int)
     __shared__ float cen[KMAX * 64];
     __shared__ float cnew[KMAX * 64];
     __shared__ int cnt[KMAX];
@@ -246,16 +261,18 @@ __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restr
     __shared__ float red_v[256];
     __shared__ int red_i[256];
     const int img = blockIdx.x, tid = threadIdx.x;
-    const float* X = x + (size_t)img * L * 64;
+    const int pitch = D + 1;                // odd for D = 64 and D = 2: conflict-free row-per-thread reads
+    const float* X = x + (size_t)img * img_stride;
     float* xs = dyn;
-    int* asg = reinterpret_cast<int*>(dyn + (XLDS ? L * KM_PITCH : 0));
+    int* asg = reinterpret_cast<int*>(dyn + (XLDS ? L * pitch : 0));
     int32_t* assign = assign_out + (size_t)img * L;
+    auto xg = [&](int t, int c) -> float { return X[(size_t)t * t_stride + (size_t)c * c_stride]; };
     if (XLDS)
-        for (int u = tid; u < L * 64; u += 256) xs[(u >> 6) * KM_PITCH + (u & 63)] = X[u];
-    for (int u = tid; u < K * 64; u += 256) cen[u] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
+        for (int u = tid; u < L * D; u += 256) { const int t = c_stride == 1 ? u / D : u % L, c = c_stride == 1 ? u % D : u / L; xs[t * pitch + c] = xg(t, c); }
+    for (int u = tid; u < K * D; u += 256) cen[(u / D) * 64 + (u % D)] = xg(init_idx[img * K + (u / D)], u % D);
     if (tid == 0) { s_events = 0; s_stop = 0; }
     __syncthreads();
-    auto xat = [&](int t, int c) -> float { return XLDS ? xs[t * KM_PITCH + c] : X[(size_t)t * 64 + c]; };
+    auto xat = [&](int t, int c) -> float { return XLDS ? xs[t * pitch + c] : xg(t, c); };
     int passes = 0;
     while (true) {
         // assignment: first minimum of sum_c (x - c)^2
@@ -263,8 +280,12 @@ __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restr
             float best = INFINITY; int bi = 0;
             for (int j = 0; j < K; ++j) {
                 float d = 0.f;
+                if (D == 64) {
 #pragma unroll 16
-                for (int c = 0; c < 64; ++c) { const float df = xat(t, c) - cen[j * 64 + c]; d = fmaf(df, df, d); }
+                    for (int c = 0; c < 64; ++c) { const float df = xat(t, c) - cen[j * 64 + c]; d = fmaf(df, df, d); }
+                } else {    // few features: plain mul + add like the reference's ((A-B)**2).sum(-1) (clusterkit.py:253-269)
+                    for (int c = 0; c < D; ++c) { const float df = xat(t, c) - cen[j * 64 + c]; d = __fadd_rn(d, __fmul_rn(df, df)); }
+                }
                 if (d < best) { best = d; bi = j; }
             }
             asg[t] = bi;
@@ -284,23 +305,23 @@ __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restr
         }
         __syncthreads();
         // update: thread = (cluster, channel); unconditional loads so they pipeline, ascending-token sum order
-        for (int u = tid; u < K * 64; u += 256) {
-            const int j = u >> 6, c = u & 63;
+        for (int u = tid; u < K * D; u += 256) {
+            const int j = u / D, c = u % D;
             float s;
-            if (cnt[j] < 0) s = X[(size_t)(-cnt[j] - 1) * 64 + c];
+            if (cnt[j] < 0) s = xg(-cnt[j] - 1, c);
             else {
                 s = 0.f;
 #pragma unroll 8
                 for (int t = 0; t < L; ++t) { const float v = xat(t, c); s += (asg[t] == j) ? v : 0.f; }
                 s = s / (float)cnt[j];
             }
-            cnew[u] = s;
+            cnew[j * 64 + c] = s;
         }
         __syncthreads();
         // centre shift = sum_j sqrt(sum_c (new-old)^2)
         if (tid < K) {
             float q = 0.f;
-            for (int c = 0; c < 64; ++c) { const float d = cnew[tid * 64 + c] - cen[tid * 64 + c]; q += d * d; }
+            for (int c = 0; c < D; ++c) { const float d = cnew[tid * 64 + c] - cen[tid * 64 + c]; q += d * d; }
             shift_part[tid] = sqrtf(q);
         }
         __syncthreads();
@@ -310,7 +331,7 @@ __global__ __launch_bounds__(256) void kmeans_anchor_kernel(const float* __restr
             for (int j = 0; j < K; ++j) sh += shift_part[j];
             s_stop = (sh * sh < 1e-4f) || passes >= 20;
         }
-        for (int u = tid; u < K * 64; u += 256) cen[u] = cnew[u];
+        for (int u = tid; u < K * D; u += 256) cen[(u / D) * 64 + (u % D)] = cnew[(u / D) * 64 + (u % D)];
         __syncthreads();
         if (s_stop) break;
     }
@@ -444,8 +465,8 @@ __global__ void nearest_bin_kernel(const float* __restrict__ ab, const float* __
 // workspace of one encoder stack: q,k,v (3 T 64), attn, LN1 out, two ping-pong layer outputs (4 T 64), ffn (T 256)
 size_t encoder_ws_bytes(int n, int l) { return (size_t)n * l * (3 * 64 + 4 * 64 + 256) * sizeof(float); }
 
-int launch_encoder_stack(const float* x, const float* pos, const float* weights, float* out, int n, int l, void* ws,
-                         hipStream_t s) {
+int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
+                         void* ws, hipStream_t s) {
     const int T = n * l;
     float* qkv = reinterpret_cast<float*>(ws);
     float* att = qkv + (size_t)3 * T * 64;
@@ -464,7 +485,7 @@ int launch_encoder_stack(const float* x, const float* pos, const float* weights,
         GemmArgs g{};
         g.a_rep = 1; g.T = T; g.L = l; g.mask_rep = 1;
         // q,k,v
-        g.A = cur; g.pos = pos; g.W = in_w; g.ldw = 64; g.bias = in_b; g.K = 64; g.O = 192; g.out = qkv;
+        g.A = cur; g.pos = pos; g.pos_rep = pos_rep; g.W = in_w; g.ldw = 64; g.bias = in_b; g.K = 64; g.O = 192; g.out = qkv;
         g.q_scale = (float)std::sqrt(1.0 / 8.0);
         int rc = launch_gemm<EPI_QKV>(g, s);
         if (rc) return rc;
@@ -506,18 +527,20 @@ void position_encoding_host(float* h_pos, int h, int w) {
         }
 }
 
-int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s) {
+int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s, int n_out) {
     GemmArgs g{};
-    g.A = x; g.a_rep = 1; g.W = w; g.ldw = 64; g.bias = nullptr; g.T = n * l; g.L = l; g.K = 64; g.O = N_VOCAB;
+    g.A = x; g.a_rep = 1; g.W = w; g.ldw = 64; g.bias = nullptr; g.T = n * l; g.L = l; g.K = 64; g.O = n_out;
     g.out = out_nchw; g.mask_rep = 1;
     return launch_gemm<EPI_LOGIT>(g, s);
 }
 
-int launch_hint_embed(const float* src, int src_rep, const int32_t* labels, const float* mask, int mask_rep,
-                      const float* w_emb, float* out, int n, int l, hipStream_t s) {
+int launch_hint_embed(const float* src, int src_rep, const int32_t* labels, const float* colors, const float* mask,
+                      int mask_rep, const float* w_emb, float* out, int n, int l, hipStream_t s) {
+    if (!labels == !colors) { set_error("hint_embed: exactly one of labels / colors"); return DISCO_EINVAL; }
     GemmArgs g{};
-    g.A = src; g.a_rep = src_rep; g.W = w_emb; g.ldw = 64 + N_VOCAB + 1; g.bias = nullptr; g.T = n * l; g.L = l;
-    g.K = 64; g.O = 64; g.out = out; g.labels = labels; g.mask = mask; g.mask_rep = mask_rep;
+    g.A = src; g.a_rep = src_rep; g.W = w_emb; g.ldw = labels ? 64 + N_VOCAB + 1 : 64 + 2 + 1; g.bias = nullptr;
+    g.T = n * l; g.L = l; g.K = 64; g.O = 64; g.out = out; g.labels = labels; g.colors = colors; g.mask = mask;
+    g.mask_rep = mask_rep;
     return launch_gemm<EPI_HINT>(g, s);
 }
 
@@ -538,11 +561,14 @@ int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labe
 
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,
-                          int l, int k, hipStream_t s) {
+                          int l, int k, hipStream_t s, int d, int channel_major) {
     if (k < 1 || k > KMAX) { set_error("kmeans: K=%d outside [1,%d]", k, KMAX); return DISCO_ESHAPE; }
     if (k > l) { set_error("kmeans: K=%d larger than %d tokens", k, l); return DISCO_ESHAPE; }
+    if (d < 1 || d > 64) { set_error("kmeans: %d features outside [1,64]", d); return DISCO_ESHAPE; }
+    const long img_stride = (long)l * d;
+    const int t_stride = channel_major ? 1 : d, c_stride = channel_major ? l : 1;
     if (l <= KM_LDS_TOKENS) {
-        const size_t smem = (size_t)l * KM_PITCH * sizeof(float) + (size_t)l * sizeof(int);
+        const size_t smem = (size_t)l * (d + 1) * sizeof(float) + (size_t)l * sizeof(int);
         auto kern = kmeans_anchor_kernel<true>;
         static bool attr_set = false;
         if (!attr_set) {
@@ -550,11 +576,11 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
                                                 (int)(KM_LDS_TOKENS * (KM_PITCH + 1) * sizeof(float))));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(n), dim3(256), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
-                           hint_mask, info, l, k);
-    } else {
-        hipLaunchKernelGGL(kmeans_anchor_kernel<false>, dim3(n), dim3(256), (size_t)l * sizeof(int), s, x, sizes, init_idx,
+        hipLaunchKernelGGL(kern, dim3(n), dim3(256), smem, s, x, d, img_stride, t_stride, c_stride, sizes, init_idx,
                            fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
+    } else {
+        hipLaunchKernelGGL(kmeans_anchor_kernel<false>, dim3(n), dim3(256), (size_t)l * sizeof(int), s, x, d, img_stride,
+                           t_stride, c_stride, sizes, init_idx, fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
     }
     DISCO_LAUNCH_CHECK("kmeans_anchor_kernel");
     return DISCO_OK;

@@ -62,7 +62,8 @@ def _bn(spec, key, c):
     spec.append((key + ".num_batches_tracked", (), "int64", "bn_count"))
 
 
-def state_dict_spec():
+def state_dict_spec(hint2regress=False):
+    """hint2regress: --hint2regress checkpoints carry trg_word_emb (64,67) and trg_word_prj (2,64) (model.py:63-64)."""
     s = []
     # ---- segnet (SpixelSeg.net = SpixelNet) ----
     p = "segnet.net."
@@ -127,8 +128,8 @@ def state_dict_spec():
                 s.append((q + n + ".weight", (D_MODEL,), "float32", "ln_w"))
                 s.append((q + n + ".bias", (D_MODEL,), "float32", "ln_b"))
     s.append(("mid_word_prj.weight", (N_VOCAB, D_MODEL), "float32", "lin_w"))
-    s.append(("trg_word_emb.weight", (D_MODEL, D_MODEL + N_VOCAB + 1), "float32", "lin_w"))
-    s.append(("trg_word_prj.weight", (N_VOCAB, D_MODEL), "float32", "lin_w"))
+    s.append(("trg_word_emb.weight", (D_MODEL, D_MODEL + (2 if hint2regress else N_VOCAB) + 1), "float32", "lin_w"))
+    s.append(("trg_word_prj.weight", (2 if hint2regress else N_VOCAB, D_MODEL), "float32", "lin_w"))
     return s
 
 

@@ -7,9 +7,12 @@ plumbing only: tensor allocation, checkpoint hand-over to the C ABI and the host
 the reference makes (NumPy k-means initialisation, Python `random` hints, torch CPU fallback rows).
 All arithmetic runs in hand-written HIP kernels; without the library this module raises.
 
-Supported configuration = the only one inference.py can produce (inference.py:71-74,165):
-test_mode=True, enhanced=True, use_dense_pos=True, hint2regress=False, spix_pos=False,
-use_mask=False, sp_size=16, d_model=64.  Anything else raises NotImplementedError.
+Supported: every configuration main/colorizer/inference.py can produce (inference.py:71-74,156-165) -
+enhanced=True, use_dense_pos=True, sp_size=16, d_model=64, clustering or random hints, --diverse, --spix_pos,
+--hint2regress - plus the validation forward of train_colorizer.py:206 (model.eval(), test_mode=False).
+Not supported (NotImplementedError): use_mask=True (never enabled by any caller; the float key_padding_mask it
+builds, model.py:122-124, is rejected by the pinned torch 1.8 `masked_fill`), test_mode=False together with
+hint2regress (model.py:178 reads an undefined name there), training (set_train / gradients).
 """
 import ctypes as C
 import random
@@ -130,15 +133,13 @@ class AnchorColorProb(nn.Module):
         if sp_size != 16: unsupported.append("sp_size=%r" % sp_size)
         if d_model != 64: unsupported.append("d_model=%r" % d_model)
         if not use_dense_pos: unsupported.append("use_dense_pos=False")
-        if spix_pos: unsupported.append("spix_pos=True")
-        if hint2regress: unsupported.append("hint2regress=True")
         if not enhanced: unsupported.append("enhanced=False")
         if use_mask: unsupported.append("use_mask=True")
         if unsupported:
             raise NotImplementedError("outside the MI355X hot path (SURVEY §8b): " + ", ".join(unsupported))
         # learning_pos is accepted and ignored exactly like the reference (model.py:59 hard-codes is_learned=False)
         self.sp_size, self.hint_num, self.random_hint = sp_size, int(n_clusters), bool(random_hint)
-        self.enhanced, self.hint2regress, self.spix_pos, self.use_token_mask = True, False, False, False
+        self.enhanced, self.hint2regress, self.spix_pos, self.use_token_mask = True, bool(hint2regress), bool(spix_pos), False
         self.n_vocab = 313
         self.rank = rank
         self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1}[precision]
@@ -151,11 +152,11 @@ class AnchorColorProb(nn.Module):
         self._keep = None
         if init_weights:
             from .synth import synth_state_dict
-            super().load_state_dict(synth_state_dict(130), strict=True)
+            super().load_state_dict(synth_state_dict(130, hint2regress=self.hint2regress), strict=True)
 
     # ---- checkpoint layout ------------------------------------------------------------------------
     def _build_tree(self):
-        for key, shape, dt, kind in state_dict_spec():
+        for key, shape, dt, kind in state_dict_spec(self.hint2regress):
             parts = key.split(".")
             node = self
             for p in parts[:-1]:
@@ -198,7 +199,8 @@ class AnchorColorProb(nn.Module):
             return self._ctx
         self._drop_ctx()
         L = _ffi.lib()
-        opt = _ffi.Options(self.sp_size, self.hint_num, int(self.random_hint), self.precision, 0)
+        opt = _ffi.Options(self.sp_size, self.hint_num, int(self.random_hint), self.precision, 0, int(self.hint2regress),
+                           int(self.spix_pos))
         ctx = C.c_void_p()
         _ffi.check(L.disco_create(device.index if device.index is not None else torch.cuda.current_device(),
                                   C.byref(opt), C.byref(ctx)))
@@ -280,8 +282,9 @@ class AnchorColorProb(nn.Module):
         """forward() with the host-side draws supplied by the caller (runner.py draws them once for the
         global batch so that results do not depend on the number of GPUs): init_idx (n,K) k-means rows,
         hint_pos (n,K) random-hint tokens.  None = draw from the global generators like the reference."""
-        if not test_mode:
-            raise NotImplementedError("test_mode=False (training forward) is outside the MI355X hot path")
+        test_mode = bool(test_mode)
+        if not test_mode and self.hint2regress:
+            raise NotImplementedError("hint2regress has no test_mode=False forward: models/model.py:178 raises NameError")
         if not input_grays.is_cuda:
             raise _ffi.DiscoError("AnchorColorProb needs CUDA/HIP tensors: the HIP path has no CPU fallback")
         dev = input_grays.device
@@ -295,7 +298,7 @@ class AnchorColorProb(nn.Module):
             raise ValueError("H and W must be multiples of %d" % sp)
         h, w = H // sp, W // sp
         l = h * w
-        T = int(sampled_T)
+        T = int(sampled_T) if test_mode else 0      # the validation forward ignores sampled_T (model.py:169-171)
         rep = 3 if T > 0 else 1
         n2 = n * rep
         L = _ffi.lib()
@@ -304,7 +307,7 @@ class AnchorColorProb(nn.Module):
             L.disco_set_profiling(ctx, int(getattr(self, "_profiling", 0)))
             f32 = dict(device=dev, dtype=torch.float32)
             pal = torch.empty(n, 313, h, w, **f32)
-            ref = torch.empty(n2, 313, h, w, **f32)
+            ref = torch.empty(n2, 2 if self.hint2regress else 313, h, w, **f32)
             pred = torch.empty(n2, 2, H, W, **f32)
             aff = torch.empty(n, 9, H, W, **f32)
             spix = torch.empty(n2, 2, h, w, **f32)
@@ -319,7 +322,7 @@ class AnchorColorProb(nn.Module):
                 self._workspace = None
                 self._workspace = torch.empty(need_bytes, device=dev, dtype=torch.uint8)
             a = _ffi.ForwardArgs()
-            a.n, a.h, a.w, a.sampled_T = n, H, W, T
+            a.n, a.h, a.w, a.sampled_T, a.test_mode = n, H, W, T, int(test_mode)
             a.d_gray, a.d_ab = gray.data_ptr(), ab.data_ptr()
             a.d_pal_logit, a.d_ref_logit, a.d_pred_colors = pal.data_ptr(), ref.data_ptr(), pred.data_ptr()
             a.d_affinity, a.d_spix_colors, a.d_hint_mask = aff.data_ptr(), spix.data_ptr(), mask.data_ptr()

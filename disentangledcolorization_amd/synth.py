@@ -83,13 +83,13 @@ def bn_running_stats(bn_key: str, channels: int, mean: float, var: float, seed: 
     return rm.astype(np.float32), rv.astype(np.float32)
 
 
-def synth_numpy(seed: int = 130, bn_stats=None) -> "OrderedDict[str, np.ndarray]":
+def synth_numpy(seed: int = 130, bn_stats=None, hint2regress: bool = False) -> "OrderedDict[str, np.ndarray]":
     """The checkpoint as NumPy arrays (float32, int64 for num_batches_tracked)."""
     bn_stats = _BN_STATS if bn_stats is None else bn_stats
     rs = np.random.RandomState(seed)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     pending_sn = None
-    for key, shape, dt, kind in state_dict_spec():
+    for key, shape, dt, kind in state_dict_spec(hint2regress):
         if kind in ("conv_w", "sn_w"):
             cout, cin, kh, kw = shape
             a = rs.standard_normal(shape) * np.sqrt(2.0 / (cin * kh * kw))
@@ -137,15 +137,17 @@ def synth_numpy(seed: int = 130, bn_stats=None) -> "OrderedDict[str, np.ndarray]
             raise AssertionError(kind)
         out[key] = np.ascontiguousarray(a, dtype=np.float32)
     # restore layout order (weight_v was inserted right after weight_u already)
-    ordered = OrderedDict((k, out[k]) for k, _, _, _ in state_dict_spec())
+    ordered = OrderedDict((k, out[k]) for k, _, _, _ in state_dict_spec(hint2regress))
     return ordered
 
 
-def synth_state_dict(seed: int = 130, bn_stats=None):
-    """The checkpoint as an OrderedDict of torch CPU tensors, loadable (strict) by the reference."""
+def synth_state_dict(seed: int = 130, bn_stats=None, hint2regress: bool = False):
+    """The checkpoint as an OrderedDict of torch CPU tensors, loadable (strict) by the reference.
+    hint2regress: the two head tensors take their --hint2regress shapes; they are drawn last, so every other
+    tensor is identical to the plain checkpoint of the same seed."""
     import torch
 
-    return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in synth_numpy(seed, bn_stats).items())
+    return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in synth_numpy(seed, bn_stats, hint2regress).items())
 
 
 def synth_inputs(n: int, h: int = 256, w: int = 256, seed: int = 5, ab_scale: float = 0.0):

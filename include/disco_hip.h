@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 2
+#define DISCO_ABI_VERSION 3
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -73,6 +73,12 @@ typedef struct disco_options {
     int32_t precision;   /* DISCO_PREC_* for the conv stacks */
     int32_t segnet_only; /* 1: the context holds only the SpixelSeg weights ("segnet.net.*", 94 tensors) and serves
                             disco_forward_segnet (models/model.py:12-29, main/spixelseg/inference.py:89) */
+    int32_t hint2regress; /* 1: --hint2regress (inference.py:158): the hint embedding takes the anchors' ab values instead
+                             of their one-hot bins, trg_word_emb is (64,67), trg_word_prj (2,64) and ref_logit has 2
+                             channels (model.py:63-64,177-181,188) */
+    int32_t spix_pos;     /* 1: --spix_pos (inference.py:156): the sine position encoding is evaluated per PIXEL and
+                             pooled into the superpixels together with the features, so every image has its own
+                             position sequence (model.py:106-112) */
 } disco_options;
 
 int disco_create(int device, const disco_options *opt, disco_ctx **out);
@@ -86,15 +92,21 @@ int disco_load_tensor(disco_ctx *ctx, const char *key, const float *h_data, cons
  * spectral-norm / batch-norm, split to fp16 hi/lo, pack into MFMA fragment order and upload. */
 int disco_finalize(disco_ctx *ctx);
 
-/* Number of state_dict entries the context expects and the i-th expected key/shape. */
+/* Number of state_dict entries a default context expects and the i-th expected key/shape; the _ctx variant answers
+ * for the options of a given context (hint2regress changes the shapes of trg_word_emb / trg_word_prj). */
 int disco_expected_tensors(void);
 int disco_expected_tensor(int i, const char **key, int64_t shape[4], int *ndim);
+int disco_expected_tensor_ctx(disco_ctx *ctx, int i, const char **key, int64_t shape[4], int *ndim);
 
 /* ---- forward ------------------------------------------------------------------------- */
 
 typedef struct disco_forward_args {
     int32_t n, h, w;          /* input batch; h, w multiples of sp_size */
     int32_t sampled_T;        /* 0: top-1 anchors; >0: diverse (3 outputs per image); <0: GT anchor colours */
+    int32_t test_mode;        /* 1: inference (model.py:138-168).  0: the validation forward of train_colorizer.py:206
+                                 (model.eval(), test_mode=False): anchors from k-means on the pooled GT colours
+                                 (model.py:169-171), hint labels = GT token labels, spix_colors = pooled GT colours,
+                                 sampled_T ignored */
     const float *d_gray;      /* (n,1,h,w) fp32 NCHW, L in [-1,1] */
     const float *d_ab;        /* (n,2,h,w) fp32 NCHW, ab/110 */
     const int32_t *h_init_idx;      /* (n,K) k-means initial rows (np.random.choice per image, clusterkit.py:107) */
@@ -103,7 +115,7 @@ typedef struct disco_forward_args {
     const int32_t *h_hint_pos;      /* (n,K) anchor tokens when random_hint (basic.py:42-47); else NULL */
     /* outputs, fp32 NCHW, n' = n (or 3n when sampled_T>0, image-major [n][t]) */
     float *d_pal_logit;   /* (n ,313,h/sp,w/sp) */
-    float *d_ref_logit;   /* (n',313,h/sp,w/sp) */
+    float *d_ref_logit;   /* (n',313,h/sp,w/sp); (n',2,h/sp,w/sp) when hint2regress */
     float *d_pred_colors; /* (n',2,h,w) */
     float *d_affinity;    /* (n ,9,h,w)  (the reference returns the expanded n' copies; rows repeat) */
     float *d_spix_colors; /* (n',2,h/sp,w/sp) */
@@ -189,11 +201,13 @@ size_t disco_op_encoder_weight_floats(void);
 int disco_op_encoder_stack(const float *d_x, const float *d_pos, const float *d_weights, float *d_out, int n,
                            int l, void *d_ws, size_t ws_bytes, void *stream);
 
-/* k-means (clusterkit.py:112-208) + anchors (anchor_gen.py:96-101) on (n,L,64) tokens */
+/* k-means (clusterkit.py:112-208) + anchors (anchor_gen.py:96-101) on n point sets of l points with d <= 64
+ * features: d_x is (n,l,d) row-major, or (n,d,l) when channel_major (NCHW maps such as the pooled colours that the
+ * validation forward clusters, model.py:169-171) */
 int disco_op_kmeans_anchors(const float *d_x, const float *d_sizes, const int32_t *d_init_idx,
                             const int32_t *d_fallback_rows, int max_fallback, int32_t *d_assign,
-                            int32_t *d_anchor, float *d_hint_mask, int32_t *d_info, int n, int l, int k,
-                            void *stream);
+                            int32_t *d_anchor, float *d_hint_mask, int32_t *d_info, int n, int l, int k, int d,
+                            int channel_major, void *stream);
 
 /* softmax(313) -> stable top-10 -> colour pick (anchor_gen.py:54-90) and nearest-bin label (basic.py:177-194) */
 int disco_op_select_colors(const float *d_logit_nchw, float *d_colors, int32_t *d_labels, int n, int hw, int t,

@@ -457,23 +457,32 @@ class DiscoOracle:
     """Holds a checkpoint `state_dict` and replays AnchorColorProb.forward on the CPU."""
 
     def __init__(self, state_dict: SD, q_to_ab: np.ndarray, sp_size: int = 16, n_clusters: int = 8,
-                 random_hint: bool = False):
+                 random_hint: bool = False, hint2regress: bool = False, spix_pos: bool = False):
         self.sd = {k: v.detach().clone() for k, v in state_dict.items()}
         self.q_to_ab = torch.as_tensor(np.asarray(q_to_ab), dtype=torch.float32)
         self.sp = sp_size
         self.k = n_clusters
         self.random_hint = random_hint
+        self.hint2regress = hint2regress      # model.py:63-64,177-181,188
+        self.spix_pos = spix_pos              # model.py:106-112
 
     # -- stages ---------------------------------------------------------------------
     def tokens(self, gray: Tensor, ab: Tensor, observer=None, taps=None):
         """steps 1-6 of SURVEY §3.2: affinity, pooled tokens, colours, sizes, pos."""
         aff = segnet_forward(self.sd, gray, observer)
         feats = repnet_forward(self.sd, gray, observer, taps)
-        pooled, _ = poolfeat(torch.cat((feats, ab), 1), aff, self.sp)
-        tok, spix_ab = pooled[:, :64], pooled[:, 64:]
+        if self.spix_pos:     # the per-pixel encoding is pooled like a feature: one position sequence per image
+            full_pos = position_encoding(gray.shape[2], gray.shape[3])[None].expand(gray.shape[0], -1, -1, -1)
+            pooled, _ = poolfeat(torch.cat((feats, ab, full_pos), 1), aff, self.sp)
+            tok, spix_ab = pooled[:, :64], pooled[:, 64:66]
+            pos = pooled[:, 66:].flatten(2).transpose(1, 2)                            # (N,L,64)
+        else:
+            pooled, _ = poolfeat(torch.cat((feats, ab), 1), aff, self.sp)
+            tok, spix_ab = pooled[:, :64], pooled[:, 64:]
         sizes = spixel_size(aff, self.sp)
         n, _, h, w = tok.shape
-        pos = position_encoding(h, w).flatten(1).t()[None].expand(n, -1, -1)          # (N,L,64)
+        if not self.spix_pos:
+            pos = position_encoding(h, w).flatten(1).t()[None].expand(n, -1, -1)      # (N,L,64)
         src = tok.flatten(2).transpose(1, 2)                                         # (N,L,64), t=y*w+x
         return aff, feats, src, pos, spix_ab, sizes
 
@@ -495,18 +504,24 @@ class DiscoOracle:
         info.update(assign=assign, anchor=anchor, init_idx=np.asarray(init_idx))
         return mask, info
 
-    def hint_tokens(self, src: Tensor, labels: Tensor, mask: Tensor) -> Tensor:
-        """trg_word_emb(cat[src, mask*onehot313(label), mask])  (model.py:175,183-185)."""
-        onehot = F.one_hot(labels, 313).float()
+    def hint_tokens(self, src: Tensor, labels: Tensor, mask: Tensor, colors: Tensor = None) -> Tensor:
+        """trg_word_emb(cat[src, mask*onehot313(label), mask])  (model.py:175,183-185);
+        hint2regress: trg_word_emb(cat[src, mask*ab, mask]) with the anchors' ab values (model.py:177-180)."""
         m = mask[..., None]
+        if self.hint2regress:
+            gt = colors.flatten(2).transpose(1, 2)                                     # (N,L,2)
+            return F.linear(torch.cat((src, m * gt, m), dim=-1), self.sd["trg_word_emb.weight"])
+        onehot = F.one_hot(labels, 313).float()
         return F.linear(torch.cat((src, m * onehot, m), dim=-1), self.sd["trg_word_emb.weight"])
 
     # -- full forward ---------------------------------------------------------------
     @torch.no_grad()
     def forward(self, gray: Tensor, ab: Tensor, sampled_T: int = 0, init_idx=None, fallback_rows=None,
-                hint_mask=None, observer=None, return_info: bool = False):
+                hint_mask=None, observer=None, return_info: bool = False, test_mode: bool = True):
         """Returns the reference's 6-tuple (pal_logit, ref_logit, pred_colors, affinity_map,
-        spix_colors, hint_mask); with return_info also a dict of intermediates."""
+        spix_colors, hint_mask); with return_info also a dict of intermediates.
+        test_mode=False is the validation forward (train_colorizer.py:206 under model.eval(); model.py:169-171):
+        anchors from k-means on the pooled GT colours, GT token labels, sampled_T ignored."""
         sd = self.sd
         n0 = gray.shape[0]
         aff, feats, src, pos, spix_ab, sizes = self.tokens(gray, ab, observer)
@@ -517,9 +532,12 @@ class DiscoOracle:
         pal_logit = to_map(F.linear(enc, sd["mid_word_prj.weight"]))
         if self.random_hint and hint_mask is None:
             hint_mask = random_anchor_mask(n, h, w, self.k)
-        mask, info = self.anchors(enc, sizes, init_idx, fallback_rows, hint_mask)
+        if not test_mode and self.hint2regress:
+            raise NameError("name 'spix_color' is not defined (models/model.py:178)")
+        cluster_on = enc if test_mode else spix_ab.flatten(2).transpose(1, 2)        # (N,L,64) | (N,L,2)
+        mask, info = self.anchors(cluster_on, sizes, init_idx, fallback_rows, hint_mask)
         prob = torch.softmax(pal_logit, dim=1)
-        if sampled_T < 0:          # ground-truth anchor colours (model.py:145-147)
+        if not test_mode or sampled_T < 0:   # ground-truth anchor colours (model.py:145-147) / validation forward
             colors = spix_ab
         elif sampled_T > 0:        # diverse: three variants of a single image (model.py:148-159)
             if n != 1:
@@ -530,7 +548,7 @@ class DiscoOracle:
         else:
             colors = sample_anchor_colors(prob, self.q_to_ab, 0)
         labels = color_labels(colors, self.q_to_ab).reshape(n, l)
-        hint = self.hint_tokens(src, labels, mask)
+        hint = self.hint_tokens(src, labels, mask, colors)
         dec = encoder_stack(sd, "hintpath", hint, pos)
         ref_logit = to_map(F.linear(dec, sd["trg_word_prj.weight"]))
         full = upfeat(to_map(dec), aff, self.sp)

@@ -27,10 +27,14 @@ def npy(t):
 
 
 def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed=5, full=True, sub=1,
-             feat_stride=8, aff_stride=4):
+             feat_stride=8, aff_stride=4, test_mode=True, hint2regress=False, spix_pos=False):
+    ref_harness.install()
     import clusterkit  # reference module
 
-    m = ref_harness.build_reference_model(sd, n_clusters=k, random_hint=random_hint)
+    if hint2regress:
+        sd = synth.synth_state_dict(SEED, hint2regress=True)
+    m = ref_harness.build_reference_model(sd, n_clusters=k, random_hint=random_hint, hint2regress=hint2regress,
+                                          spix_pos=spix_pos)
     gray, ab = synth.synth_inputs(n, h, w, seed=input_seed, ab_scale=0.5)
     cap = {}
     orig_km = clusterkit.batch_kmeans_pytorch
@@ -51,13 +55,14 @@ def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed
     # seeding exactly like main/colorizer/inference.py:58-60 (+ python random for random_hint)
     np.random.seed(SEED); torch.manual_seed(SEED); random.seed(SEED)
     with torch.no_grad():
-        pal, ref, pred, aff, spix, hint_mask = m(gray, ab, True, sampled_T)
+        pal, ref, pred, aff, spix, hint_mask = m(gray, ab, test_mode, sampled_T)
     for hk in hooks:
         hk.remove()
     clusterkit.batch_kmeans_pytorch = orig_km
     d = dict(
         recipe=np.array([n, h, w, k, sampled_T, int(random_hint), input_seed, SEED], dtype=np.int64),
         sub=np.array(sub, dtype=np.int64),
+        flags=np.array([int(test_mode), int(hint2regress), int(spix_pos)], dtype=np.int64),
         spix_colors=npy(spix), hint_mask=npy(hint_mask),
         enc=npy(cap["enc"]).transpose(1, 0, 2),           # (N,L,64)
         dec=npy(cap["dec"]).transpose(1, 0, 2),
@@ -169,6 +174,15 @@ def spixelseg_case(sd):
 def main():
     os.makedirs(OUT, exist_ok=True)
     sd = synth.synth_state_dict(SEED)
+    # the forward variants beyond inference.py's default flags: the validation forward
+    # (train_colorizer.py:206), --hint2regress, --spix_pos (inference.py:156,158)
+    run_case("fwd_val_128_k8", sd, n=2, h=128, w=128, k=8, input_seed=11, test_mode=False)
+    run_case("fwd_h2r_128_k8", sd, n=2, h=128, w=128, k=8, input_seed=12, hint2regress=True)
+    run_case("fwd_spixpos_128x192_k8", sd, n=2, h=128, w=192, k=8, input_seed=13, spix_pos=True)
+    run_case("fwd_spixpos_h2r_diverse_128_k16", sd, n=1, h=128, w=128, k=16, sampled_T=2, input_seed=14,
+             hint2regress=True, spix_pos=True)
+    if "--variants-only" in sys.argv:
+        return
     spixelseg_case(sd)
     components()
     run_case("fwd_n2_256_k8", sd, n=2, h=256, w=256, k=8)

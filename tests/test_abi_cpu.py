@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.disco_abi_version() == 2
+    assert lib.disco_abi_version() == 3
 
 
 def test_native_layout_matches_python_spec(lib):
@@ -72,7 +72,18 @@ def test_dropin_state_dict_contract(synth_sd):
     with pytest.raises(NotImplementedError):
         AnchorColorProb(enhanced=False)
     with pytest.raises(NotImplementedError):
-        AnchorColorProb(enhanced=True, hint2regress=True)
+        AnchorColorProb(enhanced=True, use_mask=True)
+    # --hint2regress checkpoints carry differently shaped head tensors (model.py:63-64); strict both ways
+    h = AnchorColorProb(enhanced=True, hint2regress=True, spix_pos=True, init_weights=False)
+    assert tuple(h.state_dict()["trg_word_emb.weight"].shape) == (64, 67)
+    assert tuple(h.state_dict()["trg_word_prj.weight"].shape) == (2, 64)
+    with pytest.raises(RuntimeError):
+        h.load_state_dict(synth_sd)
+    from disentangledcolorization_amd import synth
+    sd_h = synth.synth_state_dict(130, hint2regress=True)
+    h.load_state_dict(sd_h)
+    same = [k for k in synth_sd if not k.startswith("trg_word")]
+    assert all(torch.equal(sd_h[k], synth_sd[k]) for k in same)
 
 
 def test_forward_refuses_cpu_tensors(synth_sd):

@@ -25,12 +25,14 @@ def _err(a, b):
 _models = {}
 
 
-def _model(sd, k, random_hint=False):
-    key = (k, random_hint)
+def _model(sd, k, random_hint=False, hint2regress=False, spix_pos=False):
+    key = (k, random_hint, hint2regress, spix_pos)
     if key not in _models:
-        m = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=False,
-                            learning_pos=False, n_clusters=k, random_hint=random_hint, hint2regress=False, enhanced=True,
-                            init_weights=False)
+        m = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=spix_pos,
+                            learning_pos=False, n_clusters=k, random_hint=random_hint, hint2regress=hint2regress,
+                            enhanced=True, init_weights=False)
+        if hint2regress:               # the two head tensors take their --hint2regress shapes; the rest is the same
+            sd = synth.synth_state_dict(130, hint2regress=True)
         m.load_state_dict(sd)          # strict
         _models[key] = m.cuda().eval()
     return _models[key]
@@ -41,23 +43,27 @@ def _seed(seed):
 
 
 CASES = ["fwd_n2_256_k8", "fwd_diverse_256_k16", "fwd_n1_128x192_k8", "fwd_randhint_128_k16", "fwd_gt_128_k8",
-         "fwd_n1_512x768_k8"]
+         "fwd_n1_512x768_k8",
+         # validation forward (test_mode=False), --hint2regress, --spix_pos, and all of them with --diverse
+         "fwd_val_128_k8", "fwd_h2r_128_k8", "fwd_spixpos_128x192_k8", "fwd_spixpos_h2r_diverse_128_k16"]
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_forward_matches_reference_golden(golden_dir, synth_sd, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     n, h, w, k, T, rh, iseed, seed = (int(v) for v in g["recipe"])
+    test_mode, h2r, spos = (bool(v) for v in g["flags"]) if "flags" in g.files else (True, False, False)
     gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
-    m = _model(synth_sd, k, bool(rh))
+    m = _model(synth_sd, k, bool(rh), h2r, spos)
     _seed(seed)
-    pal, ref, pred, aff, spix, mask = m(gray.cuda(), ab.cuda(), True, T)
+    pal, ref, pred, aff, spix, mask = m(gray.cuda(), ab.cuda(), test_mode, T)
     torch.cuda.synchronize()
     assert pred.shape[0] == (3 * n if T > 0 else n) and pred.dtype == torch.float32
+    assert ref.shape[1] == (2 if h2r else 313)
     fs, as_ = (int(v) for v in g["strides"])
     sub = int(g["sub"])
     assert torch.equal(mask.cpu(), torch.from_numpy(g["hint_mask"])), "anchor positions differ from the reference"
-    if T >= 0:
+    if T >= 0 and test_mode:
         assert torch.equal(spix.cpu(), torch.from_numpy(g["spix_colors"])), "anchor colours differ"
     else:
         assert _err(spix, g["spix_colors"]) < 1e-5
@@ -162,6 +168,36 @@ def test_ragged_sizes_match_oracle(synth_sd, q_to_ab, hw):
     assert _err(got[2], want[2]) <= AB_TOL
 
 
+@pytest.mark.parametrize("variant", ["val", "val_degenerate", "h2r", "spix_pos", "spix_pos_h2r_512x768"])
+def test_forward_variants_match_oracle(synth_sd, q_to_ab, variant):
+    """SURVEY §8f-3 variants on inputs the golden files do not contain, HIP vs CPU oracle (itself pinned to the
+    reference for each variant by tests/test_oracle_golden.py).  val_degenerate: ab = 0, so every pooled colour is
+    identical, k-means collapses to one cluster and every pass draws K-1 empty-cluster fallback rows
+    (clusterkit.py:181-182) - the host-side torch.randint emulation must hand over exactly those rows."""
+    test_mode = not variant.startswith("val")
+    h2r, spos = "h2r" in variant, "spix_pos" in variant
+    h, w = (512, 768) if "512x768" in variant else (256, 256)
+    n, k = (1, 8) if "512x768" in variant else (3, 8)
+    gray, ab = synth.synth_inputs(n, h, w, seed=len(variant) * 13, ab_scale=0.0 if variant == "val_degenerate" else 0.4)
+    m = _model(synth_sd, k, False, h2r, spos)
+    sd = synth.synth_state_dict(130, hint2regress=True) if h2r else synth_sd
+    _seed(11)
+    got = m(gray.cuda(), ab.cuda(), test_mode, 0)
+    torch.cuda.synchronize()
+    after_gpu = torch.randint(1 << 30, (1,)).item()          # the generators must have advanced identically
+    _seed(11)
+    want = R.DiscoOracle(sd, q_to_ab, n_clusters=k, hint2regress=h2r, spix_pos=spos).forward(gray, ab, test_mode=test_mode)
+    assert torch.randint(1 << 30, (1,)).item() == after_gpu
+    assert torch.equal(got[5].cpu(), want[5]), "anchors differ"
+    if test_mode:
+        assert torch.equal(got[4].cpu(), want[4])
+    else:
+        assert _err(got[4], want[4]) < 1e-5
+    assert got[1].shape == want[1].shape
+    assert _err(got[3], want[3]) < 1e-4 and _err(got[0], want[0]) < LOGIT_TOL and _err(got[1], want[1]) < LOGIT_TOL
+    assert _err(got[2], want[2]) <= AB_TOL
+
+
 def test_random_hint_with_host_positions(synth_sd):
     """BASELINE config 5b: random_hint with K=16 host-provided anchor positions (random.Random(130).sample)."""
     import random as _r
@@ -193,8 +229,8 @@ def test_precision_mode_f16x1_runs(synth_sd):
 def test_error_paths(synth_sd):
     m = _model(synth_sd, 8)
     gray, ab = synth.synth_inputs(1, 64, 64)
-    with pytest.raises(NotImplementedError):
-        m(gray.cuda(), ab.cuda(), False, 0)
+    with pytest.raises(NotImplementedError):     # model.py:178 raises NameError for this combination
+        _model(synth_sd, 8, hint2regress=True)(gray.cuda(), ab.cuda(), False, 0)
     with pytest.raises(ValueError):
         m(gray[:, :, :60].cuda(), ab[:, :, :60].cuda(), True, 0)
     with pytest.raises(Exception):

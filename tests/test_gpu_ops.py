@@ -174,7 +174,7 @@ def _kmeans_gpu(H, x, sizes, init, fallback, k):
     assign = torch.empty(n, l, dtype=torch.int32, device=H.DEV); anchor = torch.empty(n, k, dtype=torch.int32, device=H.DEV)
     mask = torch.empty(n, l, device=H.DEV); info = torch.empty(n, 2, dtype=torch.int32, device=H.DEV)
     _ffi.check(_ffi.lib().disco_op_kmeans_anchors(_ffi.ptr(xd), _ffi.ptr(sd_), _ffi.ptr(idx), _ffi.ptr(fb), mf, _ffi.ptr(assign),
-                                                  _ffi.ptr(anchor), _ffi.ptr(mask), _ffi.ptr(info), n, l, k, H.stream()))
+                                                  _ffi.ptr(anchor), _ffi.ptr(mask), _ffi.ptr(info), n, l, k, 64, 0, H.stream()))
     torch.cuda.synchronize()
     return assign.cpu().long(), anchor.cpu().long(), mask.cpu(), info.cpu()
 

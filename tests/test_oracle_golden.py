@@ -107,10 +107,12 @@ def _run(golden_dir, synth_sd, q_to_ab, name):
 
     g = _load(golden_dir, name)
     n, h, w, k, T, rh, iseed, seed = (int(v) for v in g["recipe"])
+    test_mode, h2r, spos = (bool(v) for v in g["flags"]) if "flags" in g.files else (True, False, False)
     gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
-    oracle = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=k, random_hint=bool(rh))
+    sd = synth.synth_state_dict(seed, hint2regress=True) if h2r else synth_sd
+    oracle = R.DiscoOracle(sd, q_to_ab, n_clusters=k, random_hint=bool(rh), hint2regress=h2r, spix_pos=spos)
     np.random.seed(seed); torch.manual_seed(seed); random.seed(seed)
-    out, info = oracle.forward(gray, ab, sampled_T=T, return_info=True)
+    out, info = oracle.forward(gray, ab, sampled_T=T, return_info=True, test_mode=test_mode)
     return g, out, info
 
 
@@ -137,7 +139,10 @@ def _check_forward(g, out, info):
 
 
 @pytest.mark.parametrize("name", ["fwd_n2_256_k8", "fwd_diverse_256_k16", "fwd_n1_128x192_k8",
-                                  "fwd_randhint_128_k16", "fwd_gt_128_k8", "fwd_n1_512x768_k8"])
+                                  "fwd_randhint_128_k16", "fwd_gt_128_k8", "fwd_n1_512x768_k8",
+                                  # validation forward (test_mode=False), --hint2regress, --spix_pos and their mix
+                                  "fwd_val_128_k8", "fwd_h2r_128_k8", "fwd_spixpos_128x192_k8",
+                                  "fwd_spixpos_h2r_diverse_128_k16"])
 def test_forward_matches_reference(golden_dir, synth_sd, q_to_ab, name):
     g, out, info = _run(golden_dir, synth_sd, q_to_ab, name)
     _check_forward(g, out, info)
