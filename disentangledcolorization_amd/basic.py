@@ -7,6 +7,9 @@
     upfeat                  basic.py:338-376    (inference.py:115,129; spixelseg/inference.py:108)
     ColorLabel.decode_ind2ab  basic.py:196-218  (inference.py:114, integer T)
     rgb2lab / lab2rgb       basic.py:395-475
+    mark_color_hints        basic.py:95-117     (inference.py:130)
+    fetch_data_from_rgb8    main/colorizer/inference.py:23-42 after the image decode (pad-to-16 branch)
+    normLabs_to_rgb8        utils/util.py:91-106 + batch_depadding (inference.py:44-49) before the image encode
 
 No CPU fallback: CPU tensors raise DiscoError.
 """
@@ -123,3 +126,59 @@ def lab2rgb(lab_rs, l_mean=50, l_norm=50, ab_norm=110):
     if (l_mean, l_norm, ab_norm) != (50, 50, 110):
         raise NotImplementedError("only the reference's default normalisation (50, 50, 110)")
     return _color("disco_op_lab2rgb", lab_rs)
+
+
+def mark_color_hints(input_grays, target_ABs, gate_maps, kernel_size=3, base_ABs=None):
+    """models/basic.py:95-117 as one fused kernel (the reference unfolds two dilations and runs six torch.where)."""
+    _need_cuda(input_grays, target_ABs, gate_maps)
+    g, t, m = (x.contiguous().float() for x in (input_grays, target_ABs, gate_maps))
+    n, _, h, w = g.shape
+    if g.shape[1] != 1 or t.shape != (n, 2, h, w) or m.shape != (n, 1, h, w):
+        raise ValueError("expected gray (N,1,H,W), target_ABs (N,2,H,W), gate_maps (N,1,H,W)")
+    b = None
+    if base_ABs is not None:
+        _need_cuda(base_ABs)
+        b = base_ABs.contiguous().float()
+        if b.shape != (n, 2, h, w):
+            raise ValueError("base_ABs must be (N,2,H,W)")
+    with torch.cuda.device(g.device):
+        out = torch.empty(n, 3, h, w, device=g.device)
+        _ffi.check(_ffi.lib().disco_op_mark_color_hints(_ffi.ptr(g), _ffi.ptr(t), _ffi.ptr(m), _ffi.ptr(b), _ffi.ptr(out), n, h, w,
+                                                        int(kernel_size), _stream()))
+    return out
+
+
+def fetch_data_from_rgb8(rgb_img, org_size=True, device="cuda"):
+    """`fetch_data` (main/colorizer/inference.py:23-42) minus the file decode: uint8 RGB (H,W,3) array or tensor ->
+    (gray (1,1,Hp,Wp), ab (1,2,Hp,Wp), rgb (1,3,Hp,Wp), (H,W)) on the device, with the reference's pad-to-16 quirk
+    (both dims get `16 - dim % 16` when either is not a multiple of 16).  One kernel: pad + /255 + RGB->Lab + split."""
+    if not org_size:
+        raise NotImplementedError("the 256x256 cv2.resize(INTER_LINEAR) branch cannot be pinned without cv2")
+    src = torch.as_tensor(rgb_img)
+    if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
+        raise ValueError("expected a uint8 RGB image (H,W,3)")
+    src = src.to(device).contiguous()
+    _need_cuda(src)
+    H, W = int(src.shape[0]), int(src.shape[1])
+    Hp, Wp = (H + 16 - H % 16, W + 16 - W % 16) if (H % 16 or W % 16) else (H, W)
+    with torch.cuda.device(src.device):
+        gray = torch.empty(1, 1, Hp, Wp, device=src.device)
+        ab = torch.empty(1, 2, Hp, Wp, device=src.device)
+        rgb = torch.empty(1, 3, Hp, Wp, device=src.device)
+        _ffi.check(_ffi.lib().disco_op_rgb8_to_lab(_ffi.ptr(src), _ffi.ptr(gray), _ffi.ptr(ab), _ffi.ptr(rgb), 1, H, W, Hp, Wp, _stream()))
+    return gray, ab, rgb, (H, W)
+
+
+def normLabs_to_rgb8(lab_batch, H=None, W=None):
+    """`save_normLabs_from_batch` (utils/util.py:91-106) minus the file encode, with `batch_depadding` folded in:
+    normalised Lab (N,3,Hp,Wp) device tensor -> uint8 RGB (N,H,W,3) device tensor of the top-left H x W crop."""
+    _need_cuda(lab_batch)
+    lab = lab_batch.contiguous().float()
+    n, c, hp, wp = lab.shape
+    if c != 3:
+        raise ValueError("expected (N,3,H,W)")
+    H, W = (hp if H is None else int(H)), (wp if W is None else int(W))
+    with torch.cuda.device(lab.device):
+        out = torch.empty(n, H, W, 3, device=lab.device, dtype=torch.uint8)
+        _ffi.check(_ffi.lib().disco_op_lab_to_rgb8(_ffi.ptr(lab), _ffi.ptr(out), n, hp, wp, H, W, _stream()))
+    return out

@@ -1088,6 +1088,23 @@ int disco_op_lab2rgb(const float* d_lab, float* d_rgb, int n, int h, int w, void
     return launch_lab2rgb(d_lab, d_rgb, (long)n * h * w, (long)h * w, (hipStream_t)stream);
 }
 
+int disco_op_rgb8_to_lab(const uint8_t* d_rgb8, float* d_gray, float* d_ab, float* d_rgb, int n, int h, int w, int hp, int wp,
+                         void* stream) {
+    if (!d_rgb8 || !d_gray || !d_ab) { set_error("null argument"); return DISCO_EINVAL; }
+    return launch_rgb8_to_lab(d_rgb8, d_gray, d_ab, d_rgb, n, h, w, hp, wp, (hipStream_t)stream);
+}
+
+int disco_op_lab_to_rgb8(const float* d_lab, uint8_t* d_rgb8, int n, int hp, int wp, int h, int w, void* stream) {
+    if (!d_lab || !d_rgb8) { set_error("null argument"); return DISCO_EINVAL; }
+    return launch_lab_to_rgb8(d_lab, d_rgb8, n, hp, wp, h, w, (hipStream_t)stream);
+}
+
+int disco_op_mark_color_hints(const float* d_gray, const float* d_target_ab, const float* d_gate, const float* d_base_ab,
+                              float* d_out, int n, int h, int w, int kernel_size, void* stream) {
+    if (!d_gray || !d_target_ab || !d_gate || !d_out || n < 1 || h < 1 || w < 1) { set_error("bad argument"); return DISCO_EINVAL; }
+    return launch_mark_hints(d_gray, d_target_ab, d_gate, d_base_ab, d_out, n, h, w, kernel_size, (hipStream_t)stream);
+}
+
 int disco_op_position_encoding(float* d_pos, int h, int w, void* stream) {
     if (!d_pos || h < 1 || w < 1) { set_error("bad argument"); return DISCO_EINVAL; }
     std::vector<float> p((size_t)h * w * 64);

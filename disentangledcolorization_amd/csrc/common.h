@@ -154,6 +154,12 @@ int launch_select_colors(const float* logit_nchw, const float* q_to_ab, float* c
 // colour space (models/basic.py:395-475): rgb in [0,1] <-> normalised Lab ((L-50)/50, a/110, b/110), fp32 NCHW
 int launch_rgb2lab(const float* rgb, float* lab, long npix_total, long hw, hipStream_t s);
 int launch_lab2rgb(const float* lab, float* rgb, long npix_total, long hw, hipStream_t s);
+// image I/O either side of the forward (inference.py:23-42, util.py:91-106) and the anchor overlay (basic.py:95-117)
+int launch_rgb8_to_lab(const unsigned char* src, float* gray, float* ab, float* rgbn, int n, int H, int W, int Hp, int Wp,
+                       hipStream_t s);
+int launch_lab_to_rgb8(const float* lab, unsigned char* dst, int n, int Hp, int Wp, int H, int W, hipStream_t s);
+int launch_mark_hints(const float* gray, const float* target, const float* gate, const float* base, float* out, int n, int H,
+                      int W, int ks, hipStream_t s);
 int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labels, int n, int l, hipStream_t s);
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,

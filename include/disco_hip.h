@@ -219,6 +219,18 @@ int disco_op_decode_ind2ab(const float *d_logit_nchw, float *d_ab_nchw, int n, i
 /* basic.rgb2lab / basic.lab2rgb (models/basic.py:395-475): rgb in [0,1] <-> ((L-50)/50, a/110, b/110), (n,3,h,w) fp32 */
 int disco_op_rgb2lab(const float *d_rgb, float *d_lab, int n, int h, int w, void *stream);
 int disco_op_lab2rgb(const float *d_lab, float *d_rgb, int n, int h, int w, void *stream);
+/* fetch_data after the image decode (main/colorizer/inference.py:23-42): uint8 RGB (n,h,w,3) -> bottom/right edge
+ * padding to (hp,wp) -> /255 -> RGB2Lab -> gray (n,1,hp,wp) = (L-50)/50, ab (n,2,hp,wp) = ab/110 and, if d_rgb is
+ * not NULL, rgb*2-1 (n,3,hp,wp).  The colour transform is the reference's torch rgb2lab (basic.py:395-437). */
+int disco_op_rgb8_to_lab(const uint8_t *d_rgb8, float *d_gray, float *d_ab, float *d_rgb, int n, int h, int w, int hp,
+                         int wp, void *stream);
+/* save_normLabs_from_batch before the image encode (utils/util.py:91-106) with batch_depadding folded in:
+ * normalised Lab (n,3,hp,wp) -> RGB -> uint8 (n,h,w,3) of the top-left h x w crop, truncating, saturating at 255 */
+int disco_op_lab_to_rgb8(const float *d_lab, uint8_t *d_rgb8, int n, int hp, int wp, int h, int w, void *stream);
+/* basic.mark_color_hints(input_grays, target_ABs, gate_maps, kernel_size, base_ABs) (models/basic.py:95-117):
+ * gray (n,1,h,w), target/base ab (n,2,h,w), gate (n,1,h,w) -> marked Lab (n,3,h,w); d_base_ab may be NULL */
+int disco_op_mark_color_hints(const float *d_gray, const float *d_target_ab, const float *d_gate, const float *d_base_ab,
+                              float *d_out, int n, int h, int w, int kernel_size, void *stream);
 
 #ifdef __cplusplus
 }

@@ -449,6 +449,54 @@ def lab2rgb(lab_rs: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# the image I/O either side of the forward and the anchor overlay
+# --------------------------------------------------------------------------------------
+
+
+def dilate_seeds(gate: Tensor, kernel_size: int = 3) -> Tensor:
+    """basic.py:119-126: unfold(k, padding=k//2) -> max over the window -> fold(1) = k x k max filter, zero padded."""
+    pad = kernel_size // 2
+    return F.max_pool2d(F.pad(gate, (pad, pad, pad, pad), value=0.0), kernel_size, stride=1)
+
+
+def mark_color_hints(gray: Tensor, target_ab: Tensor, gate: Tensor, kernel_size: int = 3, base_ab: Tensor = None) -> Tensor:
+    """basic.py:95-117: anchors (gate > 0.7) keep target colours in a k x k centre, get a 1-px white colourless margin."""
+    binary = (gate > 0.7).float()
+    center = dilate_seeds(binary, kernel_size)
+    margin = dilate_seeds(binary, kernel_size + 2) - center
+    marked_gray = torch.where(margin > 1e-5, torch.ones_like(gate), gray)
+    if base_ab is None:
+        marked_ab = torch.where(center < 1e-5, torch.zeros_like(gate), target_ab)
+    else:
+        marked_ab = torch.where(margin > 1e-5, torch.zeros_like(gate), base_ab)
+        marked_ab = torch.where(center > 1e-5, target_ab, marked_ab)
+    return torch.cat((marked_gray, marked_ab), dim=1)
+
+
+def fetch_from_rgb8(rgb8: np.ndarray, org_size: bool = True):
+    """main/colorizer/inference.py:23-42 after cv2.imread/cvtColor, for one uint8 RGB image (H,W,3): the pad-to-16
+    quirk (BOTH dims get `16 - dim % 16` rows/columns, i.e. a full 16 when only the other one is off, :29-31),
+    /255 in float64 -> float32, RGB->Lab (the reference's torch rgb2lab stands in for cv2, see color.hip),
+    gray = (L-50)/50, ab/110, rgb*2-1.  Returns (gray (1,1,Hp,Wp), ab (1,2,Hp,Wp), rgb (1,3,Hp,Wp), (H,W))."""
+    if not org_size:
+        raise NotImplementedError("the 256x256 cv2.resize(INTER_LINEAR) branch cannot be pinned without cv2")
+    H, W = rgb8.shape[:2]
+    if H % 16 != 0 or W % 16 != 0:
+        rgb8 = np.pad(rgb8, ((0, 16 - H % 16), (0, 16 - W % 16), (0, 0)), mode="edge")
+    rgb = np.array(rgb8 / 255.0, np.float32)
+    rgb_t = torch.from_numpy(rgb.transpose((2, 0, 1)))[None]
+    lab = rgb2lab(rgb_t)
+    return lab[:, 0:1], lab[:, 1:3], rgb_t * 2.0 - 1.0, (H, W)
+
+
+def labs_to_rgb8(lab_rs: Tensor, H: int, W: int) -> np.ndarray:
+    """utils/util.py:91-106 + batch_depadding (inference.py:44-49): normalised Lab (N,3,Hp,Wp) -> RGB ->
+    (rgb*255).astype(uint8) of the top-left H x W crop, (N,H,W,3); values above 1 saturate (cv2 clips there)."""
+    rgb = lab2rgb(lab_rs)[:, :, :H, :W]
+    return (rgb * 255.0).clamp(max=255.0).permute(0, 2, 3, 1).numpy().astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
 # a14  the forward  (model.py:103-199, test_mode=True, enhanced=True, dense pos)
 # --------------------------------------------------------------------------------------
 

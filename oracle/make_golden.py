@@ -171,8 +171,33 @@ def spixelseg_case(sd):
     print("spixelseg", prob.shape, len(sub))
 
 
+def posthoc():
+    """basic.mark_color_hints (models/basic.py:95-117) of the real reference on seeded inputs: soft gate maps with
+    anchors at the borders, corners and next to each other; with and without base_ABs; kernel sizes 3 and 5."""
+    ref_harness.install()
+    import basic  # reference module
+
+    g = torch.Generator().manual_seed(77)
+    n, h, w = 2, 40, 56
+    gray = torch.rand(n, 1, h, w, generator=g) * 2 - 1
+    target = (torch.rand(n, 2, h, w, generator=g) * 2 - 1) * 0.6
+    base = (torch.rand(n, 2, h, w, generator=g) * 2 - 1) * 0.6
+    gate = torch.rand(n, 1, h, w, generator=g) * 0.69          # background below the 0.7 threshold
+    for (i, y, x, v) in [(0, 0, 0, 1.0), (0, 0, 55, 0.9), (0, 39, 0, 0.71), (0, 39, 55, 2.0), (0, 20, 20, 1.0), (0, 20, 22, 1.0),
+                         (0, 21, 25, 0.8), (1, 5, 5, 1.0), (1, 6, 6, 1.0), (1, 30, 0, 1.0), (1, 0, 30, 1.0), (1, 17, 40, 0.7)]:
+        gate[i, 0, y, x] = v
+    d = dict(gray=npy(gray), target=npy(target), base=npy(base), gate=npy(gate))
+    for ks in (3, 5):
+        d["marked_k%d" % ks] = npy(basic.mark_color_hints(gray, target, gate, kernel_size=ks, base_ABs=None))
+        d["marked_base_k%d" % ks] = npy(basic.mark_color_hints(gray, target, gate, kernel_size=ks, base_ABs=base))
+    np.savez_compressed(os.path.join(OUT, "posthoc.npz"), **d)
+    print("posthoc", {k: v.shape for k, v in d.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--posthoc-only" in sys.argv:
+        return posthoc()
     sd = synth.synth_state_dict(SEED)
     # the forward variants beyond inference.py's default flags (SURVEY §8f-3): the validation forward
     # (train_colorizer.py:206), --hint2regress, --spix_pos (inference.py:156,158)
@@ -183,6 +208,7 @@ def main():
              hint2regress=True, spix_pos=True)
     if "--variants-only" in sys.argv:
         return
+    posthoc()
     spixelseg_case(sd)
     components()
     run_case("fwd_n2_256_k8", sd, n=2, h=256, w=256, k=8)

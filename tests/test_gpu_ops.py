@@ -258,6 +258,37 @@ def test_basic_mirror_colour_space(H, comp):
     assert H.max_err(basic.lab2rgb(basic.rgb2lab(big)), big) < 2e-4
 
 
+def test_basic_mirror_hint_overlay_and_image_io(H, golden_dir):
+    """§8f rows 1-2 through the C ABI: mark_color_hints bit-exact against the reference's golden output; the fused
+    fetch (pad-to-16 quirk + /255 + RGB->Lab + split) and save (Lab->RGB->uint8, de-padded) kernels against the oracle."""
+    from disentangledcolorization_amd import basic
+
+    gd = np.load(os.path.join(golden_dir, "posthoc.npz"))
+    gray, target, base, gate = (torch.from_numpy(gd[k]).to(H.DEV) for k in ("gray", "target", "base", "gate"))
+    for ks in (3, 5):
+        assert torch.equal(basic.mark_color_hints(gray, target, gate, ks).cpu(), torch.from_numpy(gd["marked_k%d" % ks]))
+        assert torch.equal(basic.mark_color_hints(gray, target, gate, kernel_size=ks, base_ABs=base).cpu(),
+                           torch.from_numpy(gd["marked_base_k%d" % ks]))
+    with pytest.raises(_ffi.DiscoError):
+        basic.mark_color_hints(gray, target, gate, kernel_size=4)
+    rs = np.random.RandomState(3)
+    for h, w in [(37, 50), (32, 50), (37, 48), (32, 48), (250, 333)]:
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        want = R.fetch_from_rgb8(img)
+        got = basic.fetch_data_from_rgb8(img)
+        assert got[3] == want[3] == (h, w)
+        for a, b in zip(got[:3], want[:3]):
+            assert a.shape == b.shape and H.max_err(a, b) < 5e-6
+        lab = torch.cat((want[0], want[1]), 1)
+        back = basic.normLabs_to_rgb8(lab.to(H.DEV), h, w).cpu().numpy()
+        ref8 = R.labs_to_rgb8(lab, h, w)
+        # truncation to uint8: a 1-ulp difference of the float result may cross an integer boundary
+        assert back.shape == ref8.shape and np.abs(back.astype(int) - ref8.astype(int)).max() <= 1
+        assert np.abs(back[0].astype(int) - img.astype(int)).max() <= 1          # the uint8 round trip
+    with pytest.raises(NotImplementedError):
+        basic.fetch_data_from_rgb8(np.zeros((32, 32, 3), np.uint8), org_size=False)
+
+
 def test_spixelseg_dropin(H, golden_dir, synth_sd):
     from disentangledcolorization_amd import synth
     from disentangledcolorization_amd.model import SpixelSeg

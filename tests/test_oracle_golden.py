@@ -73,6 +73,26 @@ def test_colour_space_and_ranked_decode(golden_dir, q_to_ab):
         assert torch.equal(R.decode_ind2ab(torch.from_numpy(g["dec_logit"]), q, t), torch.from_numpy(g["dec_ab_T%d" % t]))
 
 
+def test_mark_color_hints_and_image_io(golden_dir):
+    """§8f rows 1-2: mark_color_hints (basic.py:95-117) bit-exact against the reference on anchors at borders,
+    corners and next to each other; fetch_data's pad-to-16 quirk (inference.py:26-31) and the uint8 round trip."""
+    g = _load(golden_dir, "posthoc")
+    gray, target, base, gate = (torch.from_numpy(g[k]) for k in ("gray", "target", "base", "gate"))
+    for ks in (3, 5):
+        assert torch.equal(R.mark_color_hints(gray, target, gate, ks), torch.from_numpy(g["marked_k%d" % ks]))
+        assert torch.equal(R.mark_color_hints(gray, target, gate, ks, base), torch.from_numpy(g["marked_base_k%d" % ks]))
+    rs = np.random.RandomState(3)
+    for (h, w), (hp, wp) in {(37, 50): (48, 64), (32, 50): (48, 64), (37, 48): (48, 64), (32, 48): (32, 48)}.items():
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        gr, ab, rgb, hw = R.fetch_from_rgb8(img)
+        assert gr.shape == (1, 1, hp, wp) and ab.shape == (1, 2, hp, wp) and rgb.shape == (1, 3, hp, wp) and hw == (h, w)
+        assert torch.equal(gr[..., h:, :], gr[..., h - 1:h, :].expand(-1, -1, hp - h, -1))      # edge replication
+        back = R.labs_to_rgb8(torch.cat((gr, ab), 1), h, w)
+        assert back.shape == (1, h, w, 3) and np.abs(back[0].astype(int) - img.astype(int)).max() <= 1
+    with pytest.raises(NotImplementedError):
+        R.fetch_from_rgb8(np.zeros((32, 32, 3), np.uint8), org_size=False)
+
+
 def test_spixelseg_standalone(golden_dir, synth_sd):
     """§8f row 4: models.model.SpixelSeg (segnet alone, `net.*` keys) == the oracle's segnet stage."""
     g = _load(golden_dir, "spixelseg")
