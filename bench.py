@@ -124,6 +124,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-launch hipEvent timings of the LAST timed step (the context keeps the events of its latest forward)
     nl, ms, fl = model.conv_profile()
+    conv_bytes = model.conv_profile_bytes() / max(nl, 1)
     conv_launches, conv_ms, conv_fl = nl * args.steps, ms * args.steps, fl * args.steps
     for name, sms, _ in model.profile():
         stage_ms[name] = sms * args.steps
@@ -163,6 +164,7 @@ def main():
                 "launches_per_step": conv_launches // max(args.steps, 1),
                 "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_fl / max(conv_launches, 1) / 1e9, 3),
+                "algorithmic_hbm_bytes_per_launch": int(conv_bytes),
                 "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK, 4),
                 "executed_mfma_tflops": round(executed, 2),
                 "sustained_mfma_tflops_same_operand_mix": round(sustained, 1),

@@ -65,6 +65,7 @@ SIGNATURES = {
     "disco_profile_count": (_I, [_P]),
     "disco_profile_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "disco_profile_conv": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "disco_profile_conv_bytes": (_I, [_P, C.POINTER(C.c_double)]),
     "disco_profile_conv_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "disco_op_nchw_to_act": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_act_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

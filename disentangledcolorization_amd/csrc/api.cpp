@@ -179,7 +179,7 @@ struct disco_ctx {
     int stg_next = 0;
     int profiling = 0;
     std::vector<ProfEntry> prof;
-    struct ConvProf { hipEvent_t e0, e1; double flops; std::string key; };
+    struct ConvProf { hipEvent_t e0, e1; double flops; std::string key; double bytes; };
     std::vector<ConvProf> conv_prof;
     std::vector<std::pair<std::string, float>> prof_ms;
     std::vector<double> prof_flops;
@@ -458,7 +458,12 @@ struct Plan {
             // algorithmic FLOPs: a ConvTranspose 4x4 s2 has 16 (not 36) taps per (ci,co) and input pixel
             // (the reference's dense count: 16 taps for the transposed conv, 9 taps on the UPSAMPLED grid for up-convs)
             const double taps = L.kind == 1 ? 16.0 * (L.c_out / 4) : (L.kind == 2 ? 9.0 * L.c_out : 9.0 * L.c_out);
-            c->conv_prof.push_back({e0, e1, 2.0 * taps * L.c_in * (double)ho * wo * in0.n, key});
+            // compulsory HBM bytes: every source read once, the output written once (hi + lo fp16 planes = 4 B per
+            // element; fp32 NCHW output 4 B), the residual read once, the packed weights once
+            double bytes = 4.0 * in0.n * ((double)in0.c * in0.h * in0.w + (in1 ? (double)in1->c * in1->h * in1->w : 0.0));
+            bytes += 4.0 * in0.n * (double)(d2s ? L.c_out / 4 * 4 : L.c_out) * ho * wo * (res ? 2.0 : 1.0);
+            bytes += (double)conv3x3_packed_bytes(L.c_out, L.c_in_pad);
+            c->conv_prof.push_back({e0, e1, 2.0 * taps * L.c_in * (double)ho * wo * in0.n, key, bytes});
         }
         return out;
     }
@@ -897,6 +902,13 @@ int disco_profile_conv(disco_ctx* c, int* launches, float* total_ms, double* tot
         if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
         *launches += 1; *total_ms += ms; *total_flops += e.flops;
     }
+    return DISCO_OK;
+}
+
+int disco_profile_conv_bytes(disco_ctx* c, double* total_bytes) {
+    if (!c || !total_bytes) { set_error("null argument"); return DISCO_EINVAL; }
+    *total_bytes = 0.0;
+    for (auto& e : c->conv_prof) *total_bytes += e.bytes;
     return DISCO_OK;
 }
 

@@ -231,6 +231,12 @@ class AnchorColorProb(nn.Module):
         _ffi.check(_ffi.lib().disco_profile_conv(self._ctx, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
 
+    def conv_profile_bytes(self):
+        """Compulsory HBM bytes of the conv3x3_mfma launches of the last forward (activations once in, once out)."""
+        b = C.c_double()
+        _ffi.check(_ffi.lib().disco_profile_conv_bytes(self._ctx, C.byref(b)))
+        return b.value
+
     def conv_profile_entries(self):
         """[(layer key, ms, algorithmic FLOPs)] per MFMA conv launch of the last forward (profiling level 2)."""
         L = _ffi.lib()

@@ -142,6 +142,9 @@ int disco_profile_entry(disco_ctx *ctx, int i, const char **name, float *ms, dou
 /* level 2: number of conv3x3_mfma launches of the last forward, their summed duration (hipEvent pairs around
  * each launch on the forward's stream) and their summed algorithmic FLOPs (2*9*Cin*Cout*Hout*Wout*N). */
 int disco_profile_conv(disco_ctx *ctx, int *launches, float *total_ms, double *total_flops);
+/* level 2: summed compulsory HBM bytes of those launches (sources and residual read once, output written once,
+ * 4 B per element = fp16 hi + lo planes, packed weights once) - the denominator for roofline.traffic */
+int disco_profile_conv_bytes(disco_ctx *ctx, double *total_bytes);
 /* level 2: the i-th MFMA conv launch of the last forward: checkpoint key of the layer, duration, algorithmic FLOPs */
 int disco_profile_conv_entry(disco_ctx *ctx, int i, const char **key, float *ms, double *flops);
 

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""HBM bytes per conv launch from two rocprofv3 PMC passes (run on the GPU box, see the recipe below) ->
+profiles/r01_pmc_traffic.json, which bench.py reports as roofline.traffic.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o fetch --output-format csv -- \
+        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o write --output-format csv -- \
+        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
+    python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/pmc_traffic.json
+
+Counters are collected in their own passes (--kernel-trace only).  Units and the gfx950 correction follow
+/opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB; FETCH_SIZE reports half of the bytes of wide
+coalesced streaming reads on gfx950, so reads are doubled; WRITE_SIZE is taken as is."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def total(dirname, counter):
+    files = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no counter_collection.csv under " + dirname)
+    s, launches = 0.0, 0
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter and "conv3x3_mfma2_kernel" in row.get("Kernel_Name", ""):
+                    s += float(row["Counter_Value"]); launches += 1
+    return s, launches
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    fetch, nf = total(fetch_dir, "FETCH_SIZE")
+    write, nw = total(write_dir, "WRITE_SIZE")
+    if not nf or nf != nw:
+        raise SystemExit("launch counts differ: %d vs %d" % (nf, nw))
+    rd = fetch * 1024 * 2 / nf
+    wr = write * 1024 / nw
+    json.dump({
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
+                  "`python bench.py --steps 1 --warmup 1` (tools/pmc_traffic.py)",
+        "unit_note": "counter unit is KiB; per MI355X_MICROARCH.md the gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of "
+                     "wide coalesced streaming reads, so reads are doubled below; WRITE_SIZE is uncalibrated and taken as is",
+        "conv3x3_mfma2_launches": nf, "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
+        "hbm_read_bytes_per_launch_corrected": int(rd), "hbm_write_bytes_per_launch": int(wr),
+        "hbm_bytes_per_launch": int(rd + wr)}, open(out, "w"), indent=1)
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()
