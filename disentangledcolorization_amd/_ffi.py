@@ -42,7 +42,8 @@ class ForwardArgs(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c_in0", C.c_int32),
                 ("c_in1", C.c_int32), ("up0", C.c_int32), ("up1", C.c_int32), ("c_out", C.c_int32),
-                ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("precision", C.c_int32)]
+                ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("precision", C.c_int32),
+                ("s2d_weights", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/disco_hip.h declares
@@ -69,6 +70,7 @@ SIGNATURES = {
     "disco_profile_conv_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "disco_op_nchw_to_act": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_act_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "disco_op_conv3x3_pack_s2": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_conv3x3_pack": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_conv3x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "disco_op_conv3x3_set_probe": (_I, [_P]),

@@ -114,6 +114,7 @@ const int GAMUT_RUNS[20][3] = {{-90, 50, 90}, {-80, 20, 90}, {-70, 0, 90}, {-60,
 struct ConvLayer {
     int c_in = 0, c_in_pad = 0, c_out = 0;
     int kind = 0;                 // 0 plain 3x3, 1 ConvTranspose 4x4 s2 as 4-phase conv, 2 upsample+3x3 as 4-phase conv
+    bool s2d = false;             // stride-2 layer: weights packed for the space-to-depth view of the input
     f16* d_w = nullptr;
     uint32_t* d_tapmask = nullptr;
     float* d_bias = nullptr;
@@ -259,7 +260,7 @@ void bn_affine(disco_ctx* c, const std::string& key, std::vector<float>& scale, 
 // Build one MFMA conv layer.  fold_bn: BN directly after the conv (SpixelNet, network.py:240-246) is folded into
 // weights+bias; post_bn: BN after the activation (ColorProbNet / HourGlass2 blocks) becomes the epilogue affine.
 int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, const std::string& post_bn,
-              const std::vector<int>* ci_map = nullptr, int c_in_pad_override = 0) {
+              const std::vector<int>* ci_map = nullptr, int c_in_pad_override = 0, bool stride2 = false) {
     std::vector<float> w = eff_weight(c, key);
     const HostTensor& ws = c->sd.count(key + ".weight") ? T(c, key + ".weight") : T(c, key + ".weight_orig");
     const int co = (int)ws.shape[0], ci = (int)ws.shape[1];
@@ -276,8 +277,23 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
     ConvLayer L;
     L.c_in = ci; L.c_out = co;
     L.c_in_pad = c_in_pad_override ? c_in_pad_override : round_up(ci, 16);
-    std::vector<char> packed(conv3x3_packed_bytes(co, L.c_in_pad));
-    conv3x3_pack_host(w.data(), co, ci, ci_map ? ci_map->data() : nullptr, L.c_in_pad, packed.data());
+    std::vector<char> packed;
+    // Measured on MI355X (profiles/r01_conv_s2d_timeline.txt): the space-to-depth path has the stride-1 LDS footprint and
+    // MFMA/LDS ratio, but each phase chunk uses half of every 128-byte line it fetches, and the stride-2 layers are bound
+    // by L2->LDS line traffic (input re-read per N tile), not by LDS reads: 0.66 vs 0.65 ms on 64->128@256^2, 0.56 vs
+    // 0.53 ms on 256->512@64^2.  The forward therefore keeps the plain stride-2 tiles; the packing stays available
+    // through disco_op_conv3x3_pack_s2.
+    static const bool kUseS2D = [] { const char* e = getenv("DISCO_S2D"); return e && atoi(e) != 0; }();
+    if (kUseS2D && stride2 && !ci_map) {     // every stride-2 layer of the path sees even input sizes (H, W multiples of 16)
+        L.s2d = true;
+        std::vector<float> w4((size_t)co * 4 * L.c_in_pad * 9);
+        conv3x3_s2d_weights_host(w.data(), co, ci, L.c_in_pad, w4.data());
+        packed.resize(conv3x3_packed_bytes(co, 4 * L.c_in_pad));
+        conv3x3_pack_host(w4.data(), co, 4 * L.c_in_pad, nullptr, 4 * L.c_in_pad, packed.data());
+    } else {
+        packed.resize(conv3x3_packed_bytes(co, L.c_in_pad));
+        conv3x3_pack_host(w.data(), co, ci, ci_map ? ci_map->data() : nullptr, L.c_in_pad, packed.data());
+    }
     int rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w);
     if (rc) return rc;
     if ((rc = upload_vec(c, bias, &L.d_bias))) return rc;
@@ -441,6 +457,10 @@ struct Plan {
         ca.nsrc = 1;
         if (in1) { ca.src[1] = {in1->p, (long)in1->plane, in1->c, in1->h, in1->w, up1}; ca.nsrc = 2; }
         ca.n = in0.n; ca.h_in = hin; ca.w_in = win; ca.c_in = L.c_in_pad;
+        if (L.s2d) {
+            if (stride != 2 || in1 || up0 || (hin & 1) || (win & 1)) { set_error("conv %s: packed for stride 2 on an even-sized plain source", key.c_str()); rc = DISCO_ESHAPE; return out; }
+            ca.s2d = 1; ca.c_in = 4 * L.c_in_pad;
+        }
         ca.h_out = ho; ca.w_out = wo; ca.stride = stride;
         ca.w = L.d_w; ca.tapmask = L.d_tapmask; ca.c_out = L.c_out; ca.c_out_pad = L.c_out;
         ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
@@ -462,7 +482,7 @@ struct Plan {
             // element; fp32 NCHW output 4 B), the residual read once, the packed weights once
             double bytes = 4.0 * in0.n * ((double)in0.c * in0.h * in0.w + (in1 ? (double)in1->c * in1->h * in1->w : 0.0));
             bytes += 4.0 * in0.n * (double)(d2s ? L.c_out / 4 * 4 : L.c_out) * ho * wo * (res ? 2.0 : 1.0);
-            bytes += (double)conv3x3_packed_bytes(L.c_out, L.c_in_pad);
+            bytes += (double)conv3x3_packed_bytes(L.c_out, L.s2d ? 4 * L.c_in_pad : L.c_in_pad);
             c->conv_prof.push_back({e0, e1, 2.0 * taps * L.c_in * (double)ho * wo * in0.n, key, bytes});
         }
         return out;
@@ -788,7 +808,7 @@ int disco_finalize(disco_ctx* c) {
     if ((rc = make_c1(c, sg + "conv0a.0", sg + "conv0a.1"))) return rc;
     for (const char* k : {"conv0b", "conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "conv3_1",
                           "conv2_1", "conv1_1", "conv0_1"})
-        if ((rc = make_conv(c, sg + k + ".0", sg + k + ".1", ""))) return rc;
+        if ((rc = make_conv(c, sg + k + ".0", sg + k + ".1", "", nullptr, 0, k[5] == 'a' && k[6] == '\0' && k[4] != '0'))) return rc;   // conv1a..conv4a: stride 2
     for (const char* k : {"deconv3", "deconv2", "deconv1", "deconv0"}) if ((rc = make_deconv(c, sg + k + ".0"))) return rc;
     if ((rc = make_small_out(c, sg + "pred_mask0"))) return rc;
     if (seg_only) { c->sd.clear(); c->finalized = true; return DISCO_OK; }
@@ -796,7 +816,7 @@ int disco_finalize(disco_ctx* c) {
     if ((rc = make_c1(c, rp + "conv1_2.0", ""))) return rc;
     if ((rc = make_conv(c, rp + "conv1_2.2", "", rp + "conv1_2.4"))) return rc;
     for (const char* b : {"conv2_3", "conv3_3", "conv4_3", "conv5_3", "conv6_3", "conv7_3"}) {
-        if ((rc = make_conv(c, rp + b + ".0", "", ""))) return rc;
+        if ((rc = make_conv(c, rp + b + ".0", "", "", nullptr, 0, b[4] >= '2' && b[4] <= '4' /* conv2_3.0, conv3_3.0, conv4_3.0: stride 2 */))) return rc;
         if ((rc = make_conv(c, rp + b + ".2", "", ""))) return rc;
         if ((rc = make_conv(c, rp + b + ".4", "", rp + b + ".6"))) return rc;
     }
@@ -817,7 +837,7 @@ int disco_finalize(disco_ctx* c) {
     }
     if ((rc = make_conv(c, en + "inConv.conv.0", "", en + "inConv.conv.2"))) return rc;
     for (const char* k : {"down1", "down2"}) {
-        if ((rc = make_conv(c, en + k + ".conv.0", "", ""))) return rc;
+        if ((rc = make_conv(c, en + k + ".conv.0", "", "", nullptr, 0, true))) return rc;       // down1 / down2: stride 2
         if ((rc = make_conv(c, en + k + ".conv.2", "", en + k + ".conv.4"))) return rc;
     }
     for (int r = 0; r < 3; ++r)
@@ -961,6 +981,20 @@ int disco_op_conv3x3_pack(const float* h_w, int c_out, int c_in, void* d_packed,
     return DISCO_OK;
 }
 
+int disco_op_conv3x3_pack_s2(const float* h_w, int c_out, int c_in, void* d_packed, size_t* bytes) {
+    if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }
+    const int cpad = round_up(c_in, 16);
+    *bytes = conv3x3_packed_bytes(c_out, 4 * cpad);
+    if (!d_packed) return DISCO_OK;
+    if (!h_w) { set_error("null weight"); return DISCO_EINVAL; }
+    std::vector<float> w4((size_t)c_out * 4 * cpad * 9);
+    conv3x3_s2d_weights_host(h_w, c_out, c_in, cpad, w4.data());
+    std::vector<char> packed(*bytes);
+    conv3x3_pack_host(w4.data(), c_out, 4 * cpad, nullptr, 4 * cpad, packed.data());
+    DISCO_HIP_CHECK(hipMemcpy(d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    return DISCO_OK;
+}
+
 int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d_src1, const void* d_packed_w,
                      const float* d_bias, const float* d_bn_scale, const float* d_bn_shift, const void* d_res, void* d_out,
                      void* stream) {
@@ -983,6 +1017,7 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
     ca.out = (f16*)d_out; ca.out_plane = (long)d->n * ca.h_out * ca.w_out * d->c_out;
     ca.res = (const f16*)d_res; ca.res_plane = ca.out_plane;
     ca.act = d->act; ca.slope = d->slope; ca.precision = d->precision;
+    if (d->s2d_weights) { ca.s2d = 1; ca.c_in = 4 * d->c_in0; }
     ca.dbg = g_conv_probe;
     return run_conv(ca, (hipStream_t)stream);
 }

@@ -78,6 +78,7 @@ struct ConvArgs {
     int precision;
     uint32_t src_bytes[2];  // filled by the launcher: bytes addressable through each source's buffer descriptor
     uint32_t w_bytes;       // ... and through the packed-weight descriptor
+    int s2d;            // stride-2 layer whose weights were packed for the space-to-depth view (conv3x3_s2d_weights_host)
     unsigned long long* dbg;  // timing probe (tools/conv_timeline.py): per-chunk s_memtime stamps of workgroup 0, or null
 };
 
@@ -92,6 +93,9 @@ void deconv_as_conv3x3_host(const float* h_w_iohw, int c_in, int c_out, float* h
 // (4*c_out, c_in, 3, 3), phase-major, taps pre-summed (sub-pixel decomposition; 4 non-zero taps per phase)
 void upconv_as_conv3x3_host(const float* h_w_oihw, int c_in, int c_out, float* h_w4_oihw);
 // bit t of mask[nb] set iff any weight of tap t is non-zero in 32-cout block nb
+// stride-2 3x3 weights (c_out,c_in,3,3) -> the equivalent stride-1 weights (c_out, 4*c_in_pad, 3, 3) over the space-to-depth
+// view of the input: channel (cb*4 + py*2+px)*16 + j = channel cb*16+j of sub-pixel phase (py,px); c_in_pad multiple of 16
+void conv3x3_s2d_weights_host(const float* h_w, int c_out, int c_in, int c_in_pad, float* out);
 void conv3x3_tapmask_host(const float* h_w, int c_out, int c_in, uint32_t* mask /* cdiv(c_out,32) */);
 
 // ---- direct (VALU) convs ------------------------------------------------------------------------

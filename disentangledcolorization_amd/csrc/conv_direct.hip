@@ -38,9 +38,10 @@ __device__ __forceinline__ void load_sum8(const f16* hi_p, long plane, float* v)
 }
 
 // ---- Cin = 1 ---------------------------------------------------------------------------------------
-// thread = (image, 16-channel block, pixel), pixel fastest: a wave writes 64 consecutive 32-byte pixels of one
-// channel block (2 KiB contiguous per plane).  blockIdx.y = (image, block): the block's 16x9 weights and its
-// bias / BN affine sit in LDS and are read as wave-uniform broadcasts.
+// thread = (image, 16-channel block, pixel, channel half), half fastest: lanes 2i and 2i+1 compute channels 0-7 and
+// 8-15 of the same pixel, so every 16-byte store instruction of a wave covers 1 KiB of contiguous memory per plane
+// (one thread per pixel issued 16-byte stores at a 32-byte lane stride: 1.8 TB/s).  blockIdx.y = (image, block):
+// the block's 16x9 weights and its bias / BN affine sit in LDS.
 __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ gray, const float* __restrict__ w,
                                                       const float* __restrict__ bias, const float* __restrict__ bsc,
                                                       const float* __restrict__ bsh, f16* out, long out_plane, int n,
@@ -57,7 +58,9 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
     __syncthreads();
     const float* gi = gray + img * hw;
     f16* ob = out + ((img * nblk + blk) * hw) * 16;
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x) {
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < 2 * hw; u += (long)gridDim.x * blockDim.x) {
+        const long p = u >> 1;
+        const int half = (int)(u & 1);
         const int x = (int)(p % wd), y = (int)(p / wd);
         float in[9];
 #pragma unroll
@@ -67,18 +70,18 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
                 const int yy = y + ky - 1, xx = x + kx - 1;
                 in[ky * 3 + kx] = (yy >= 0 && yy < h && xx >= 0 && xx < wd) ? gi[(long)yy * wd + xx] : 0.f;
             }
-        float v[16];
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 8; ++j) {
+            const int c = half * 8 + j;
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) s = fmaf(in[k], sw[j * 9 + k], s);
-            s += sw[144 + j];
+            for (int k = 0; k < 9; ++k) s = fmaf(in[k], sw[c * 9 + k], s);
+            s += sw[144 + c];
             s = apply_act(s, act, slope);
-            v[j] = s * sw[160 + j] + sw[176 + j];
+            v[j] = s * sw[160 + c] + sw[176 + c];
         }
-        store_split8(ob + p * 16, out_plane, v);
-        store_split8(ob + p * 16 + 8, out_plane, v + 8);
+        store_split8(ob + u * 8, out_plane, v);
     }
 }
 
@@ -181,7 +184,7 @@ int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, c
                    float slope, hipStream_t s) {
     if (c_out % 16) { set_error("conv_c1: c_out %d not a multiple of 16", c_out); return DISCO_ESHAPE; }
     const long hw = (long)h * w;
-    dim3 grid((unsigned)std::min<long>((hw + 255) / 256, 1024), (unsigned)(n * (c_out / 16)));
+    dim3 grid((unsigned)std::min<long>((2 * hw + 255) / 256, 1024), (unsigned)(n * (c_out / 16)));
     hipLaunchKernelGGL(conv_c1_kernel, grid, dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale, d_bn_shift, out, out_plane,
                        n, h, w, c_out, act, slope);
     DISCO_LAUNCH_CHECK("conv_c1_kernel");

@@ -78,7 +78,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
-    const int nchunks = a.c_in >> 4;
+    // a.s2d (STRIDE == 1 instantiations): a stride-2 conv run as a stride-1 conv over the space-to-depth VIEW of its
+    // input - chunk ck = 16 channels (block ck>>2) of ONE sub-pixel phase (ck&3) of the real tensor, so the LDS halo
+    // tile has the stride-1 footprint (a stride-2 tile needs 4x the LDS and ran 3 MFMAs per 4 fragment reads).
+    // Phase (py,px) meets the 3x3 window in 1/2/2/4 taps: the same 9 taps per channel block, no extra MFMAs.
+    const bool s2d = STRIDE == 1 && a.s2d;
+    const int nchunks = a.c_in >> 4;               // s2d: the launcher passes c_in = 4 x the real channel count
 
     // Persistent workgroup: blockIdx.x fixes the tile position (tx, ty) and the N tile (by); the workgroup then
     // walks over the images n = blockIdx.y, blockIdx.y + gridDim.y, ... of the batch.  Everything that depends
@@ -94,6 +99,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     if (n >= a.n) return;
 
     unsigned tmask = 0x1ffu;          // taps with non-zero weights in this workgroup's N blocks (wave-uniform)
+    // s2d: taps (row r, col c of the 3x3 window over the phase image) that exist for phase (py,px): r in {1} (py=0)
+    // or {0,1} (py=1), same for c; bit r*3+c
+    auto chunk_mask = [&](int ck) -> unsigned {
+        if (!s2d) return tmask;
+        const unsigned ph = (unsigned)ck & 3u;
+        return ph == 0 ? 0x010u : (ph == 1 ? 0x018u : (ph == 2 ? 0x012u : 0x01bu));
+    };
     if (a.tapmask) {
         tmask = 0;
 #pragma unroll
@@ -137,8 +149,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
                 bool slot_ok = u < A_UNITS;
                 if (STRIDE == 1) px = q;
                 else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok && px < G::TWI; }
-                const int gy = iy0 + py, gx = ix0 + px;
-                const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
+                int gy = iy0 + py, gx = ix0 + px;
+                bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
+                if (s2d) {      // (gy,gx) is a pixel of the phase image: real pixel (2gy+py', 2gx+px'), phase added per chunk
+                    in = slot_ok && gy >= 0 && gy < (a.h_in >> 1) && gx >= 0 && gx < (a.w_in >> 1);
+                    gy *= 2; gx *= 2;
+                }
                 voff[si][i] = in ? (unsigned)(plane * sp.plane + ((gy >> sp.up) * sp.w + (gx >> sp.up)) * 16 + kh * 8) * 2u : OOB;
             }
         }
@@ -150,10 +166,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
 
     // one ninth (part 0..8) of the DMA of chunk `ck` of image `img` into LDS buffer `buf`; part < 0: all of it
     auto issue = [&](int img, int ck, int buf, int part) {
-        const int c0 = ck << 4;
+        const int c0 = (s2d ? ck >> 2 : ck) << 4;
         const bool s1 = a.nsrc > 1 && c0 >= c_src0;
-        const unsigned soff = s1 ? (unsigned)img * img_b1 + (unsigned)((c0 - c_src0) >> 4) * blk_b1
-                                 : (unsigned)img * img_b0 + (unsigned)(c0 >> 4) * blk_b0;
+        unsigned soff = s1 ? (unsigned)img * img_b1 + (unsigned)((c0 - c_src0) >> 4) * blk_b1
+                           : (unsigned)img * img_b0 + (unsigned)(c0 >> 4) * blk_b0;
+        if (s2d) soff += (unsigned)(((ck >> 1) & 1) * a.src[0].w + (ck & 1)) * 32u;     // phase (py,px) = (ck>>1 & 1, ck & 1)
+        const unsigned wmask = chunk_mask(ck);
         char* dA = smem + buf * BUF_BYTES;
         char* dW = dA + A_BYTES;
 #pragma unroll
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
             if (part >= 0 && i / WPT != part) continue;
             const int piece = i * NWAVE + wave;
             const int nt = piece / 18, q = piece - nt * 18;
-            if (piece < W_PIECES && ((tmask >> (q >> 1)) & 1u))
+            if (piece < W_PIECES && ((wmask >> (q >> 1)) & 1u))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(dW + piece * 1024), 16, lane * 16,
                                                          w_tile_b + (unsigned)nt * w_nt_b + (unsigned)ck * W_NB + q * 1024, 0, 0);
         }
@@ -215,10 +233,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         const char* sA = smem + buf * BUF_BYTES;
         const char* sW = sA + A_BYTES;
         buf ^= 1;
+        const unsigned cmask = chunk_mask(ck);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             if (dma) issue(dma_img, dma_ck, buf, tap);   // one ninth of the next chunk's DMA per tap (buf already flipped)
-            if (!((tmask >> tap) & 1u)) continue;     // wave-uniform: all-zero tap (sub-pixel up-conv / deconv phases)
+            if (!((cmask >> tap) & 1u)) continue;     // wave-uniform: all-zero tap (sub-pixel up-conv / deconv / s2d phases)
             const int ky = tap / 3, kx = tap % 3;
             const int tapoff = ky * G::PITCH + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
             f16x8 ah[MT], al[MT], bh[NTW], bl[NTW];
@@ -472,7 +491,7 @@ template <bool X3>
 int dispatch2(const ConvArgs& a, hipStream_t s) {
     const bool wide = a.w_out > 16;
     const bool nt2 = a.c_out > 32;
-    if (a.stride == 1) {
+    if (a.stride == 1 || a.s2d) {
         if (wide) {
             if (a.h_out > 8) return nt2 ? launch_cfg2<32, 16, 2, 1, X3, 8, 1>(a, s) : launch_cfg2<32, 16, 1, 1, X3, 8, 1>(a, s);
             return nt2 ? launch_cfg2<32, 8, 2, 1, X3, 4, 2>(a, s) : launch_cfg2<32, 8, 1, 1, X3, 4, 1>(a, s);
@@ -508,6 +527,23 @@ void conv3x3_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map,
                         dst[base] = hi;
                         dst[base + 512] = lo;
                     }
+}
+
+void conv3x3_s2d_weights_host(const float* w, int c_out, int c_in, int c_in_pad, float* out) {
+    // out pixel (y,x) reads real input (2y+ky-1, 2x+kx-1) = pixel (y+dy, x+dx) of phase (py,px) with 2dy+py = ky-1:
+    //   py = 0: ky = 1 (dy = 0);   py = 1: ky = 0 (dy = -1), ky = 2 (dy = 0);   window row r = dy + 1   (same in x)
+    const int c4 = 4 * c_in_pad;
+    const size_t total = (size_t)c_out * c4 * 9;
+    for (size_t i = 0; i < total; ++i) out[i] = 0.f;
+    for (int co = 0; co < c_out; ++co)
+        for (int ci = 0; ci < c_in; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int py = (ky + 1) & 1, px = (kx + 1) & 1;
+                    const int dy = (ky - 1 - py) / 2, dx = (kx - 1 - px) / 2;     // exact: numerators even
+                    const int cc = ((ci >> 4) * 4 + py * 2 + px) * 16 + (ci & 15);
+                    out[(((size_t)co * c4 + cc) * 3 + (dy + 1)) * 3 + (dx + 1)] = w[(((size_t)co * c_in + ci) * 3 + ky) * 3 + kx];
+                }
 }
 
 void deconv_as_conv3x3_host(const float* w, int c_in, int c_out, float* out) {
@@ -579,6 +615,13 @@ int launch_conv3x3_v2(const ConvArgs& a_in, hipStream_t s) {
         a.w_bytes = (uint32_t)wb;
     }
     if (a.stride != 1 && a.stride != 2) { set_error("conv3x3: stride %d", a.stride); return DISCO_ESHAPE; }
+    if (a.s2d) {
+        // weights packed for the space-to-depth view: c_in counts the 4 phases; needs a stride-2, single-source, even-sized input
+        if (a.stride != 2 || a.nsrc != 1 || a.src[0].up || (a.h_in & 1) || (a.w_in & 1) || a.c_in != 4 * a.src[0].c || a.tapmask) {
+            set_error("conv3x3: space-to-depth weights need stride 2, one plain source and even input sizes (%dx%d)", a.h_in, a.w_in);
+            return DISCO_ESHAPE;
+        }
+    }
     if (a.c_in % 16 || a.src[0].c % 16 || (a.nsrc > 1 && a.src[1].c % 16)) {
         set_error("conv3x3: input channels must be multiples of 16 (got %d)", a.c_in);
         return DISCO_ESHAPE;

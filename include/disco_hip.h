@@ -164,11 +164,16 @@ typedef struct disco_conv_desc {
     int32_t act;               /* DISCO_ACT_* applied after bias (+residual) */
     float slope;
     int32_t precision;         /* DISCO_PREC_* */
+    int32_t s2d_weights;       /* 1: d_packed_w came from disco_op_conv3x3_pack_s2 (stride 2, one plain source, even sizes) */
 } disco_conv_desc;
 
 /* Pack an effective fp32 OIHW 3x3 weight (host) for the MFMA kernel; returns bytes needed when
  * d_packed == NULL.  c_in = c_in0 + c_in1 (each a multiple of 16, or c_in0 arbitrary when c_in1 = 0). */
 int disco_op_conv3x3_pack(const float *h_w_oihw, int c_out, int c_in, void *d_packed, size_t *bytes);
+/* The same for a STRIDE-2 layer run over the space-to-depth view of its input (the fast path for stride 2: the four
+ * sub-pixel phases of the input become 4x the channels of a stride-1 conv with 1/2/2/4 live taps, so the LDS halo
+ * tile has the stride-1 footprint); 4x the bytes of disco_op_conv3x3_pack.  Use with disco_conv_desc.s2d_weights. */
+int disco_op_conv3x3_pack_s2(const float *h_w_oihw, int c_out, int c_in, void *d_packed, size_t *bytes);
 
 /* out = bn(act(conv3x3(cat(src0,src1)) + bias [+ res]));  bias/bn_scale/bn_shift: device fp32 (c_out) or NULL */
 int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d_src1, const void *d_packed_w,

@@ -33,19 +33,20 @@ def from_act(a, c=None):
     return out
 
 
-def pack_conv(w):
-    """(Cout,Cin,3,3) fp32 cpu -> packed device buffer."""
+def pack_conv(w, s2d=False):
+    """(Cout,Cin,3,3) fp32 cpu -> packed device buffer (s2d: the space-to-depth packing of a stride-2 layer)."""
     w = w.detach().cpu().float().contiguous()
     co, ci = w.shape[:2]
     nbytes = C.c_size_t()
-    _ffi.check(_ffi.lib().disco_op_conv3x3_pack(None, co, ci, None, C.byref(nbytes)))
+    pack = _ffi.lib().disco_op_conv3x3_pack_s2 if s2d else _ffi.lib().disco_op_conv3x3_pack
+    _ffi.check(pack(None, co, ci, None, C.byref(nbytes)))
     buf = torch.empty(nbytes.value, device=DEV, dtype=torch.uint8)
-    _ffi.check(_ffi.lib().disco_op_conv3x3_pack(_ffi.ptr(w), co, ci, _ffi.ptr(buf), C.byref(nbytes)))
+    _ffi.check(pack(_ffi.ptr(w), co, ci, _ffi.ptr(buf), C.byref(nbytes)))
     return buf
 
 
 def conv3x3(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, act=_ffi.ACT_NONE, slope=0.0,
-            bn_scale=None, bn_shift=None, res=None, precision=_ffi.PREC_F16X3):
+            bn_scale=None, bn_shift=None, res=None, precision=_ffi.PREC_F16X3, s2d=False):
     """HIP conv on act tensors; returns the act output.  src*: (2,N,h,w,C) fp16."""
     n = src0.shape[1]
     h_in = src0.shape[2] * (2 if up0 else 1)
@@ -53,8 +54,8 @@ def conv3x3(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, ac
     c0 = src0.shape[4]
     c1 = src1.shape[4] if src1 is not None else 0
     co = w.shape[0]
-    packed = pack_conv(w)
-    d = _ffi.ConvDesc(n, h_in, w_in, c0, c1, int(up0), int(up1), co, stride, act, slope, precision)
+    packed = pack_conv(w, s2d)
+    d = _ffi.ConvDesc(n, h_in, w_in, c0, c1, int(up0), int(up1), co, stride, act, slope, precision, int(s2d))
     ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
     out = torch.empty(2, n, ho, wo, co, device=DEV, dtype=torch.float16)
     dv = lambda t: None if t is None else t.to(DEV).float().contiguous()

@@ -82,6 +82,39 @@ def test_conv3x3_matches_torch(H, case, prec):
     assert H.max_err(got, want) < tol * max(1.0, want.abs().max().item())
 
 
+S2D_CASES = [
+    # cin, cout, h, w, act, slope, bn   (stride 2 over the space-to-depth view; even input sizes)
+    (64, 128, 64, 96, _ffi.ACT_LRELU, 0.2, True),
+    (16, 32, 34, 50, _ffi.ACT_LRELU, 0.1, False),     # ragged output 17x25: partial tiles at both edges
+    (128, 256, 16, 16, _ffi.ACT_RELU, 0.0, False),
+    (256, 512, 32, 32, _ffi.ACT_LRELU, 0.2, True),
+    (32, 64, 2, 2, _ffi.ACT_NONE, 0.0, False),        # 1x1 output: every tap but the centre block is padding
+]
+
+
+@pytest.mark.parametrize("case", S2D_CASES)
+@pytest.mark.parametrize("prec", [_ffi.PREC_F16X3, _ffi.PREC_F16X1])
+def test_conv3x3_stride2_space_to_depth(H, case, prec):
+    """The stride-2 fast path (weights packed by disco_op_conv3x3_pack_s2) against torch and against the plain
+    stride-2 kernel on the same inputs."""
+    cin, cout, h, w, act, slope, use_bn = case
+    gen = g(cin * 77 + cout + h)
+    x = torch.randn(3, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    bn = (torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.1) if use_bn else None
+    want = _ref_conv(x, wt, b, 2, act, slope, bn, None)
+    kw = dict(stride=2, act=act, slope=slope, bn_scale=bn[0] if bn else None, bn_shift=bn[1] if bn else None, precision=prec)
+    got = H.from_act(H.conv3x3(H.to_act(x), wt, b, s2d=True, **kw))
+    plain = H.from_act(H.conv3x3(H.to_act(x), wt, b, **kw))
+    tol = 2e-5 if prec == _ffi.PREC_F16X3 else 2e-2
+    scale = max(1.0, want.abs().max().item())
+    assert got.shape == want.shape and H.max_err(got, want) < tol * scale
+    assert H.max_err(got, plain) < tol * scale
+    with pytest.raises(_ffi.DiscoError):                      # odd input size: no space-to-depth view
+        H.conv3x3(H.to_act(x[:, :, :h - 1]), wt, b, s2d=True, **kw)
+
+
 def test_conv3x3_upsample_and_concat_on_read(H):
     gen = g(5)
     a = torch.randn(2, 32, 12, 20, generator=gen)      # half-resolution source, nearest x2 on read

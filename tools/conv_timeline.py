@@ -11,16 +11,23 @@ from disentangledcolorization_amd import _ffi
 ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=512); ap.add_argument("--cout", type=int, default=512)
 ap.add_argument("--size", type=int, default=32); ap.add_argument("--n", type=int, default=64)
+ap.add_argument("--stride", type=int, default=1); ap.add_argument("--s2d", type=int, default=0)
 a = ap.parse_args()
 L = _ffi.lib()
 src = torch.randn(2, a.n, a.size, a.size, a.cin, device="cuda").half()
 w = torch.randn(a.cout, a.cin, 3, 3) * 0.05
-packed = H.pack_conv(w)
-out = torch.empty(2, a.n, a.size, a.size, a.cout, device="cuda", dtype=torch.float16)
+packed = H.pack_conv(w, bool(a.s2d))
+so = (a.size - 1) // a.stride + 1
+out = torch.empty(2, a.n, so, so, a.cout, device="cuda", dtype=torch.float16)
 bias = torch.zeros(a.cout, device="cuda")
-d = _ffi.ConvDesc(a.n, a.size, a.size, a.cin, 0, 0, 0, a.cout, 1, _ffi.ACT_RELU, 0.0, 0)
+d = _ffi.ConvDesc(a.n, a.size, a.size, a.cin, 0, 0, 0, a.cout, a.stride, _ffi.ACT_RELU, 0.0, 0, a.s2d)
 run = lambda: _ffi.check(L.disco_op_conv3x3(C.byref(d), _ffi.ptr(src), None, _ffi.ptr(packed), _ffi.ptr(bias), None, None, None, _ffi.ptr(out), H.stream()))
 for _ in range(3): run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize()
+print("avg launch %.3f ms" % (e0.elapsed_time(e1) / 10))
 buf = torch.zeros(16 * 64 * 4, dtype=torch.int64, device="cuda")
 L.disco_op_conv3x3_set_probe(_ffi.ptr(buf)); run(); torch.cuda.synchronize(); L.disco_op_conv3x3_set_probe(None)
 t = buf.cpu().view(16, 64, 4)
