@@ -325,18 +325,6 @@ int make_c1(disco_ctx* c, const std::string& key, const std::string& fold_bn) {
     return DISCO_OK;
 }
 
-int make_small_out(disco_ctx* c, const std::string& key) {
-    const HostTensor& ws = T(c, key + ".weight");
-    const int co = (int)ws.shape[0], ci = (int)ws.shape[1];
-    std::vector<float> w((size_t)9 * ci * co);
-    for (int o = 0; o < co; ++o) for (int i = 0; i < ci; ++i) for (int t = 0; t < 9; ++t)
-        w[((size_t)t * ci + i) * co + o] = ws.data[((size_t)o * ci + i) * 9 + t];
-    DirectLayer L; L.c_in = ci; L.c_out = co;
-    int rc = upload_vec(c, w, &L.d_w); if (rc) return rc;
-    if ((rc = upload_vec(c, T(c, key + ".bias").data, &L.d_bias))) return rc;
-    c->direct[key] = L;
-    return DISCO_OK;
-}
 
 // ConvTranspose2d(4,s2,p1) as a 4-phase 3x3 conv on the MFMA kernel with a depth-to-space epilogue
 int make_deconv(disco_ctx* c, const std::string& key) {
@@ -444,7 +432,7 @@ struct Plan {
 
     // MFMA conv: out = bn(act(conv(cat(in0[,in1])) + bias [+ res]))
     Act conv(const std::string& key, const Act& in0, const Act* in1, int up0, int up1, int stride, int actc, float slope,
-             const Act* res = nullptr, float* out_f32 = nullptr, bool d2s = false) {
+             const Act* res = nullptr, float* out_f32 = nullptr, bool d2s = false, bool softmax = false) {
         const ConvLayer& L = c->conv.at(key);
         const int hin = in0.h << up0, win = in0.w << up0;
         const int ho = (hin - 1) / stride + 1, wo = (win - 1) / stride + 1;
@@ -466,7 +454,7 @@ struct Plan {
         ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
         ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
         ca.out = out.p; ca.out_plane = (long)out.plane;
-        ca.out_f32 = out_f32; ca.d2s_c = d2s ? L.c_out / 4 : 0;
+        ca.out_f32 = out_f32; ca.d2s_c = d2s ? L.c_out / 4 : 0; ca.softmax = softmax ? 1 : 0;
         ca.act = actc; ca.slope = slope; ca.precision = c->opt.precision;
         if (in0.c + (in1 ? in1->c : 0) != L.c_in_pad) { set_error("conv %s: input channels %d != %d", key.c_str(), in0.c + (in1 ? in1->c : 0), L.c_in_pad); rc = DISCO_ESHAPE; return out; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -524,10 +512,8 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
     cc = P.conv(sg + "conv1_1.0", o2, &d, 0, 0, 1, LRELU, 0.1f); P.drop(d); P.drop(o2);
     d = P.deconv(sg + "deconv0.0", cc, 0.1f); P.drop(cc);
     cc = P.conv(sg + "conv0_1.0", o1, &d, 0, 0, 1, LRELU, 0.1f); P.drop(d); P.drop(o1);
-    if (!dry && P.ok()) {
-        const DirectLayer& Lp = c->direct.at(sg + "pred_mask0");
-        P.rc = launch_conv_small_out(cc.p, (long)cc.plane, 16, Lp.d_w, Lp.d_bias, d_affinity, n, H, W, 9, 0, s);
-    }
+    // pred_mask0 (16 -> 9, bias) + softmax over the 9 slots, fp32 NCHW out (network.py:311-312)
+    P.conv(sg + "pred_mask0", cc, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, dry ? (float*)16 : d_affinity, false, true);
     P.drop(cc);
 }
 
@@ -810,7 +796,7 @@ int disco_finalize(disco_ctx* c) {
                           "conv2_1", "conv1_1", "conv0_1"})
         if ((rc = make_conv(c, sg + k + ".0", sg + k + ".1", "", nullptr, 0, k[5] == 'a' && k[6] == '\0' && k[4] != '0'))) return rc;   // conv1a..conv4a: stride 2
     for (const char* k : {"deconv3", "deconv2", "deconv1", "deconv0"}) if ((rc = make_deconv(c, sg + k + ".0"))) return rc;
-    if ((rc = make_small_out(c, sg + "pred_mask0"))) return rc;
+    if ((rc = make_conv(c, sg + "pred_mask0", "", ""))) return rc;
     if (seg_only) { c->sd.clear(); c->finalized = true; return DISCO_OK; }
     const std::string rp = "repnet.";
     if ((rc = make_c1(c, rp + "conv1_2.0", ""))) return rc;

@@ -78,6 +78,7 @@ struct ConvArgs {
     int precision;
     uint32_t src_bytes[2];  // filled by the launcher: bytes addressable through each source's buffer descriptor
     uint32_t w_bytes;       // ... and through the packed-weight descriptor
+    int softmax;        // fp32 NCHW output only: softmax over the c_out (<= 32) channels after the epilogue
     int s2d;            // stride-2 layer whose weights were packed for the space-to-depth view (conv3x3_s2d_weights_host)
     unsigned long long* dbg;  // timing probe (tools/conv_timeline.py): per-chunk s_memtime stamps of workgroup 0, or null
 };
@@ -103,10 +104,6 @@ void conv3x3_tapmask_host(const float* h_w, int c_out, int c_in, uint32_t* mask 
 int launch_conv_c1(const float* d_gray, const float* d_w /*(cout,9)*/, const float* d_bias, const float* d_bn_scale,
                    const float* d_bn_shift, f16* out, long out_plane, int n, int h, int w, int c_out, int act,
                    float slope, hipStream_t s);
-// last layers: small Cout, act input -> fp32 NCHW output; mode 0 = softmax over channels, 1 = tanh, 2 = none
-int launch_conv_small_out(const f16* in, long in_plane, int c_in, const float* d_w /*(9,c_in,cout)*/,
-                          const float* d_bias, float* d_out_nchw, int n, int h, int w, int c_out, int mode,
-                          hipStream_t s);
 
 // ---- layout conversion --------------------------------------------------------------------------
 int launch_nchw_to_act(const float* src, f16* dst, long plane, int n, int c, int h, int w, int c_pad, hipStream_t s);

@@ -3,8 +3,7 @@
 // (channel-blocked [N][C/16][H][W][16] fp16, hi plane + lo plane).
 //
 //   conv_c1          Cin = 1 first layers  (segnet conv0a, network.py:263; repnet conv1_2.0, :152)
-//   conv_small_out   pred_mask0 (16 -> 9) + softmax over the 9 slots (network.py:282-283, 311-312) -> affinity NCHW fp32
-// (enhanceNet.outConv and the ConvTranspose2d layers run on the MFMA kernel: conv_mfma2.hip epilogues.)
+// (pred_mask0 + softmax9, enhanceNet.outConv and the ConvTranspose2d layers run on the MFMA kernel: conv_mfma2.hip epilogues.)
 #include <algorithm>
 #include "common.h"
 
@@ -85,60 +84,6 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
     }
 }
 
-// ---- small Cout ------------------------------------------------------------------------------------
-// thread = pixel; weights (9, c_in, COUT) fp32 in LDS (wave-uniform broadcast reads)
-template <int COUT, int MODE>
-__global__ __launch_bounds__(256) void conv_small_out_kernel(const f16* __restrict__ in, long in_plane, int c_in,
-                                                             const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* out, int n, int h,
-                                                             int wd) {
-    extern __shared__ float sw[];
-    for (int i = threadIdx.x; i < 9 * c_in * COUT; i += blockDim.x) sw[i] = w[i];
-    __syncthreads();
-    const long total = (long)n * h * wd;
-    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(pix % wd);
-        const int y = (int)((pix / wd) % h);
-        const long img = pix / ((long)wd * h);
-        float acc[COUT];
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yy = y + ky - 1;
-            if (yy < 0 || yy >= h) continue;
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xx = x + kx - 1;
-                if (xx < 0 || xx >= wd) continue;
-                const long hw = (long)h * wd;
-                const f16* p = in + img * c_in * hw + ((long)yy * wd + xx) * 16;
-                const float* wt = sw + (ky * 3 + kx) * c_in * COUT;
-                for (int c8 = 0; c8 < c_in; c8 += 8) {
-                    float v[8];
-                    load_sum8(p + (long)(c8 >> 4) * hw * 16 + (c8 & 15), in_plane, v);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-#pragma unroll
-                        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v[j], wt[(c8 + j) * COUT + c], acc[c]);
-                }
-            }
-        }
-        float* o = out + img * COUT * h * wd + (long)y * wd + x;
-        if (MODE == 0) {  // softmax over channels
-            float m = acc[0];
-#pragma unroll
-            for (int c = 1; c < COUT; ++c) m = fmaxf(m, acc[c]);
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < COUT; ++c) { acc[c] = expf(acc[c] - m); s += acc[c]; }
-#pragma unroll
-            for (int c = 0; c < COUT; ++c) o[(long)c * h * wd] = acc[c] / s;
-        } else {
-#pragma unroll
-            for (int c = 0; c < COUT; ++c) o[(long)c * h * wd] = MODE == 1 ? tanhf(acc[c]) : acc[c];
-        }
-    }
-}
-
 // ---- layout converters -----------------------------------------------------------------------------
 __global__ void nchw_to_act_kernel(const float* __restrict__ src, f16* dst, long plane, int n, int c, int h, int w,
                                    int c_pad) {
@@ -188,19 +133,6 @@ int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, c
     hipLaunchKernelGGL(conv_c1_kernel, grid, dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale, d_bn_shift, out, out_plane,
                        n, h, w, c_out, act, slope);
     DISCO_LAUNCH_CHECK("conv_c1_kernel");
-    return DISCO_OK;
-}
-
-int launch_conv_small_out(const f16* in, long in_plane, int c_in, const float* d_w, const float* d_bias,
-                          float* d_out_nchw, int n, int h, int w, int c_out, int mode, hipStream_t s) {
-    const long total = (long)n * h * w;
-    const size_t smem = (size_t)9 * c_in * c_out * sizeof(float);
-    dim3 grid(grid_for(total)), block(256);
-    if (c_out == 9 && mode == 0)
-        hipLaunchKernelGGL((conv_small_out_kernel<9, 0>), grid, block, smem, s, in, in_plane, c_in, d_w, d_bias,
-                           d_out_nchw, n, h, w);
-    else { set_error("conv_small_out: unsupported c_out=%d mode=%d", c_out, mode); return DISCO_EUNSUPPORTED; }
-    DISCO_LAUNCH_CHECK("conv_small_out_kernel");
     return DISCO_OK;
 }
 

@@ -376,6 +376,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = v[e] * bsc[e] + bsh[e];
                 }
+                if (MODE == 2 && a.softmax) {
+                    // softmax over the c_out (<= 32) channels of the pixel (pred_mask0 + F.softmax(dim=1),
+                    // network.py:311-312): the lane pair (l, l^32) holds the pixel's 32 channels
+                    const int cob = (by_e * NT + wn * NTW + nt) * 32;
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (cob + (e & 3) + 8 * (e >> 2) + 4 * kh < a.c_out) mx = fmaxf(mx, v[e]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float sm = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        v[e] = cob + (e & 3) + 8 * (e >> 2) + 4 * kh < a.c_out ? expf(v[e] - mx) : 0.f;
+                        sm += v[e];
+                    }
+                    sm += __shfl_xor(sm, 32);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = v[e] / sm;
+                }
                 if (MODE != 2) {
                     // split into fp16 hi + lo, packed in pairs (v_cvt_pk_f16_f32): dword d holds channels c(2d), c(2d+1)
                     unsigned hd[8], ld[8];
@@ -615,6 +634,7 @@ int launch_conv3x3_v2(const ConvArgs& a_in, hipStream_t s) {
         a.w_bytes = (uint32_t)wb;
     }
     if (a.stride != 1 && a.stride != 2) { set_error("conv3x3: stride %d", a.stride); return DISCO_ESHAPE; }
+    if (a.softmax && (!a.out_f32 || a.c_out > 32)) { set_error("conv3x3: the fused softmax needs the fp32 NCHW output and c_out <= 32"); return DISCO_ESHAPE; }
     if (a.s2d) {
         // weights packed for the space-to-depth view: c_in counts the 4 phases; needs a stride-2, single-source, even-sized input
         if (a.stride != 2 || a.nsrc != 1 || a.src[0].up || (a.h_in & 1) || (a.w_in & 1) || a.c_in != 4 * a.src[0].c || a.tapmask) {
