@@ -26,6 +26,9 @@ from .layout import state_dict_spec
 
 _PARAM_KINDS = {"conv_w", "sn_w", "deconv_w", "bias", "bn_w", "bn_b", "lin_w", "lin_b", "ln_w", "ln_b"}
 KMEANS_ITERS = 20  # clusterkit.py:43 iter_limit -> at most (K-1)*20 empty-cluster draws per image
+# The conv kernel addresses an activation tensor (fp16 hi + lo planes, 64 channels at full resolution) through one
+# 32-bit buffer descriptor, so a native call takes at most this many bytes per tensor; larger batches are split.
+MAX_ACT_BYTES = (1 << 32) - (1 << 20)
 
 
 class _Node(nn.Module):
@@ -306,6 +309,19 @@ class AnchorColorProb(nn.Module):
         l = h * w
         T = int(sampled_T) if test_mode else 0      # the validation forward ignores sampled_T (model.py:169-171)
         rep = 3 if T > 0 else 1
+        max_imgs = max(1, MAX_ACT_BYTES // (64 * H * W * 4 * rep))
+        if n > max_imgs:
+            # images are independent: run the batch in slices (the host draws are made once, in image order, exactly
+            # as for a single call) and concatenate
+            if self.random_hint:
+                hint_pos = self._random_hints(n, l) if hint_pos is None else np.ascontiguousarray(hint_pos, dtype=np.int32)
+            else:
+                init_idx = self._kmeans_init(n, l) if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.int32)
+            parts = [self.forward_with_draws(gray[i:i + max_imgs], ab[i:i + max_imgs], test_mode, sampled_T,
+                                             None if init_idx is None else init_idx[i:i + max_imgs],
+                                             None if hint_pos is None else hint_pos[i:i + max_imgs])
+                     for i in range(0, n, max_imgs)]
+            return tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
         n2 = n * rep
         L = _ffi.lib()
         with torch.cuda.device(dev):

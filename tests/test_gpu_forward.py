@@ -198,6 +198,54 @@ def test_forward_variants_match_oracle(synth_sd, q_to_ab, variant):
     assert _err(got[2], want[2]) <= AB_TOL
 
 
+def test_oversized_batch_is_split(synth_sd, monkeypatch):
+    """Maximum sizes: a batch whose full-resolution activations exceed the conv kernel's 32-bit buffer addressing
+    (N > 255 at 256x256, N > 63 at 512x512) is run in slices; results and the consumption of the host generators are
+    identical to one call.  (The limit is lowered here so that 5 images at 128x128 take 3 slices.)"""
+    import disentangledcolorization_amd.model as M
+    n, k = 5, 8
+    gray, ab = synth.synth_inputs(n, 128, 128, seed=77, ab_scale=0.3)
+    m = _model(synth_sd, k)
+    _seed(3)
+    want = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    state = (np.random.get_state()[1].copy(), torch.get_rng_state().clone())
+    monkeypatch.setattr(M, "MAX_ACT_BYTES", 2 * 64 * 128 * 128 * 4 + 100)
+    _seed(3)
+    got = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert np.array_equal(np.random.get_state()[1], state[0]) and torch.equal(torch.get_rng_state(), state[1])
+    md = _model(synth_sd, 16)                                   # diverse: 3 virtual images per image count against the limit
+    monkeypatch.setattr(M, "MAX_ACT_BYTES", 3 * 64 * 128 * 128 * 4 + 100)
+    _seed(4); a3 = md(gray[:2].cuda(), ab[:2].cuda(), True, 2)
+    monkeypatch.setattr(M, "MAX_ACT_BYTES", (1 << 32) - (1 << 20))
+    _seed(4); b3 = md(gray[:2].cuda(), ab[:2].cuda(), True, 2)
+    torch.cuda.synchronize()
+    for a, b in zip(a3, b3):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_batch_of_64_at_512_crosses_the_addressing_limit(synth_sd):
+    """The real thing: 64 images at 512x512 are 4.29 GB per 64-channel activation, 1 MiB over the 32-bit descriptor
+    limit, so the call runs as 63 + 1 images.  Image 63 (the second slice) and image 0 must equal the same images run
+    alone with the same k-means rows."""
+    n, k = 64, 8
+    gray, ab = synth.synth_inputs(n, 512, 512, seed=91)
+    m = _model(synth_sd, k)
+    rs = np.random.RandomState(5)
+    init = np.stack([rs.choice(1024, k, replace=False) for _ in range(n)]).astype(np.int32)
+    big = m.forward_with_draws(gray.cuda(), ab.cuda(), True, 0, init_idx=init)
+    torch.cuda.synchronize()
+    assert big[2].shape == (n, 2, 512, 512) and torch.isfinite(big[2]).all()
+    for i in (0, 63):
+        one = m.forward_with_draws(gray[i:i + 1].cuda(), ab[i:i + 1].cuda(), True, 0, init_idx=init[i:i + 1])
+        torch.cuda.synchronize()
+        for a, b in zip(one, big):
+            assert torch.equal(a[0], b[i])
+
+
 def test_random_hint_with_host_positions(synth_sd):
     """BASELINE config 5b: random_hint with K=16 host-provided anchor positions (random.Random(130).sample)."""
     import random as _r
