@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--micro", type=int, default=1, help="micro-batches per GPU, each on its own HIP stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,7 +102,7 @@ def main():
     lo, hi = shard_bounds(n_global, world, rank)
     gray_all, ab_all = synth.synth_inputs(n_global, 256, 256, seed=5)
     gray, ab = gray_all[lo:hi].cuda(), ab_all[lo:hi].cuda()    # inputs resident in HBM before timing
-    runner = ShardedColorizer.from_model(model)
+    runner = ShardedColorizer.from_model(model, micro_batches=args.micro)
 
     def step():
         np.random.seed(130)

@@ -340,16 +340,22 @@ class AnchorColorProb(nn.Module):
                 _ffi.check(L.disco_workspace_bytes(ctx, n, H, W, T, C.byref(need)))
                 self._ws_need[ws_key] = need.value
             need_bytes = self._ws_need[ws_key]
-            if self._workspace is None or self._workspace.numel() < need_bytes or self._workspace.device != dev:
-                self._workspace = None
-                self._workspace = torch.empty(need_bytes, device=dev, dtype=torch.uint8)
+            # one workspace per stream: forwards issued on different streams may overlap on the GPU (runner.py pipelines
+            # micro-batches that way), each needs its own activations
+            stream_ptr = torch.cuda.current_stream().cuda_stream
+            if not isinstance(self._workspace, dict):
+                self._workspace = {}
+            wsb = self._workspace.get(stream_ptr)
+            if wsb is None or wsb.numel() < need_bytes or wsb.device != dev:
+                self._workspace[stream_ptr] = None
+                wsb = self._workspace[stream_ptr] = torch.empty(need_bytes, device=dev, dtype=torch.uint8)
             a = _ffi.ForwardArgs()
             a.n, a.h, a.w, a.sampled_T, a.test_mode = n, H, W, T, int(test_mode)
             a.d_gray, a.d_ab = gray.data_ptr(), ab.data_ptr()
             a.d_pal_logit, a.d_ref_logit, a.d_pred_colors = pal.data_ptr(), ref.data_ptr(), pred.data_ptr()
             a.d_affinity, a.d_spix_colors, a.d_hint_mask = aff.data_ptr(), spix.data_ptr(), mask.data_ptr()
-            a.d_workspace, a.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
-            a.stream = torch.cuda.current_stream().cuda_stream
+            a.d_workspace, a.workspace_bytes = wsb.data_ptr(), wsb.numel()
+            a.stream = stream_ptr
             if self.random_hint:
                 hint_pos = self._random_hints(n, l) if hint_pos is None else np.ascontiguousarray(hint_pos, dtype=np.int32)
                 a.h_hint_pos = hint_pos.ctypes.data

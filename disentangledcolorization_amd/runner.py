@@ -37,15 +37,41 @@ class ShardedColorizer:
     For the product path forward_fn = AnchorColorProb.forward_with_draws (HIP); tests inject a CPU function.
     """
 
-    def __init__(self, forward_fn, n_clusters=8, random_hint=False, sp_size=16, group=None):
+    def __init__(self, forward_fn, n_clusters=8, random_hint=False, sp_size=16, group=None, micro_batches=1):
         self.forward_fn = forward_fn
         self.k, self.random_hint, self.sp = n_clusters, random_hint, sp_size
         self.group = group
+        # micro_batches > 1: the local shard is cut into that many slices, each issued on its own HIP stream, so the
+        # latency-bound token path / k-means of one slice (a few CUs busy) overlaps with the conv stacks of another
+        self.micro = max(1, int(micro_batches))
+        self._streams = None
 
     @classmethod
-    def from_model(cls, model, group=None):
+    def from_model(cls, model, group=None, micro_batches=1):
         fn = lambda g, a, T, idx, pos: model.forward_with_draws(g, a, True, T, init_idx=idx, hint_pos=pos)
-        return cls(fn, model.hint_num, model.random_hint, model.sp_size, group)
+        return cls(fn, model.hint_num, model.random_hint, model.sp_size, group, micro_batches)
+
+    def _forward_local(self, gray, ab, sampled_T, idx, pos):
+        n = gray.shape[0]
+        m = min(self.micro, n)
+        if m <= 1 or not gray.is_cuda:
+            return self.forward_fn(gray, ab, sampled_T, idx, pos)
+        if self._streams is None or len(self._streams) < m:
+            self._streams = [torch.cuda.Stream(device=gray.device) for _ in range(m)]
+        main = torch.cuda.current_stream(gray.device)
+        parts = []
+        for i in range(m):
+            lo, hi = shard_bounds(n, m, i)
+            st = self._streams[i]
+            st.wait_stream(main)                       # inputs were produced on the caller's stream
+            with torch.cuda.stream(st):
+                parts.append(self.forward_fn(gray[lo:hi], ab[lo:hi], sampled_T,
+                                             None if idx is None else idx[lo:hi], None if pos is None else pos[lo:hi]))
+        for i in range(m):
+            main.wait_stream(self._streams[i])
+            for t in parts[i]:
+                t.record_stream(main)                  # allocated on the side stream, consumed on the caller's
+        return tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
 
     def world(self):
         if dist.is_available() and dist.is_initialized():
@@ -61,8 +87,8 @@ class ShardedColorizer:
             raise ValueError("rank %d expects %d images, got %d" % (rank, hi - lo, gray_local.shape[0]))
         h, w = gray_local.shape[2] // self.sp, gray_local.shape[3] // self.sp
         idx, pos = global_draws(n_global, h * w, self.k, self.random_hint)
-        out = self.forward_fn(gray_local, ab_local, sampled_T,
-                              None if idx is None else idx[lo:hi], None if pos is None else pos[lo:hi])
+        out = self._forward_local(gray_local, ab_local, sampled_T,
+                                  None if idx is None else idx[lo:hi], None if pos is None else pos[lo:hi])
         pred, mask = out[2], out[5]
         if not gather or not (dist.is_available() and dist.is_initialized()):
             return pred, mask
