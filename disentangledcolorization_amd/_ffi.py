@@ -86,6 +86,7 @@ SIGNATURES = {
     "disco_op_nearest_bin": (_I, [_P, _P, _I, _I, _P]),
     "disco_op_position_encoding": (_I, [_P, _I, _I, _P]),
     "disco_op_decode_ind2ab": (_I, [_P, _P, _I, _I, _I, _P]),
+    "disco_op_decode_annealed": (_I, [_P, _P, _I, _I, C.c_float, _P]),
     "disco_op_rgb2lab": (_I, [_P, _P, _I, _I, _I, _P]),
     "disco_op_lab2rgb": (_I, [_P, _P, _I, _I, _I, _P]),
     "disco_op_rgb8_to_lab": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -85,14 +85,12 @@ def upfeat(input, prob, up_h=2, up_w=2):
 
 
 class ColorLabel:
-    """313-bin gamut labels; only what inference needs (q_to_ab, decode_ind2ab with integer T)."""
+    """313-bin gamut labels; what inference needs: q_to_ab and decode_ind2ab (integer T = ranked bin, else annealed mean)."""
 
     def __init__(self, lambda_=0.5, device="cuda"):
         self.q_to_ab = torch.from_numpy(gamut_points()).to(device)
 
     def decode_ind2ab(self, batch_q, T=0.38):
-        if T % 1 != 0:
-            raise NotImplementedError("annealed-mean decoding (non-integer T) is outside the MI355X hot path")
         _need_cuda(batch_q)
         q = batch_q.contiguous().float()
         n, c, h, w = q.shape
@@ -100,7 +98,10 @@ class ColorLabel:
             raise ValueError("expected 313 colour bins")
         with torch.cuda.device(q.device):
             ab = torch.empty(n, 2, h, w, device=q.device)
-            _ffi.check(_ffi.lib().disco_op_decode_ind2ab(_ffi.ptr(q), _ffi.ptr(ab), n, h * w, int(T), _stream()))
+            if T % 1 == 0:      # the T-th most probable bin (basic.py:199-209)
+                _ffi.check(_ffi.lib().disco_op_decode_ind2ab(_ffi.ptr(q), _ffi.ptr(ab), n, h * w, int(T), _stream()))
+            else:               # annealed mean (basic.py:210-217)
+                _ffi.check(_ffi.lib().disco_op_decode_annealed(_ffi.ptr(q), _ffi.ptr(ab), n, h * w, float(T), _stream()))
         return ab.type(batch_q.dtype)
 
 

@@ -1111,6 +1111,14 @@ int disco_op_decode_ind2ab(const float* d_logit, float* d_ab, int n, int hw, int
     return launch_select_colors(d_logit, q, d_ab, nullptr, n, hw, 0, 1, (hipStream_t)stream, T);
 }
 
+int disco_op_decode_annealed(const float* d_logit, float* d_ab, int n, int hw, float T, void* stream) {
+    if (!d_logit || !d_ab || n < 1 || hw < 1) { set_error("bad argument"); return DISCO_EINVAL; }
+    float* q = nullptr;
+    int rc = gamut_device(&q);
+    if (rc) return rc;
+    return launch_decode_annealed(d_logit, q, d_ab, n, hw, T, (hipStream_t)stream);
+}
+
 int disco_op_rgb2lab(const float* d_rgb, float* d_lab, int n, int h, int w, void* stream) {
     if (!d_rgb || !d_lab || n < 1 || h < 1 || w < 1) { set_error("bad argument"); return DISCO_EINVAL; }
     return launch_rgb2lab(d_rgb, d_lab, (long)n * h * w, (long)h * w, (hipStream_t)stream);

@@ -161,6 +161,8 @@ int launch_rgb8_to_lab(const unsigned char* src, float* gray, float* ab, float* 
 int launch_lab_to_rgb8(const float* lab, unsigned char* dst, int n, int Hp, int Wp, int H, int W, hipStream_t s);
 int launch_mark_hints(const float* gray, const float* target, const float* gate, const float* base, float* out, int n, int H,
                       int W, int ks, hipStream_t s);
+// annealed-mean decoding (ColorLabel.decode_ind2ab with non-integer T, basic.py:210-217)
+int launch_decode_annealed(const float* logit_nchw, const float* q_to_ab, float* ab, int n, int l, float T, hipStream_t s);
 int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labels, int n, int l, hipStream_t s);
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,

@@ -522,7 +522,51 @@ __global__ void nearest_bin_kernel(const float* __restrict__ ab, const float* __
     }
 }
 
+// ColorLabel.decode_ind2ab for non-integer T (basic.py:210-217): p = softmax(logit); e = exp(p / T); ab = sum_q e_q ab_q
+// / sum_q e_q / 110.  One wave per token, lanes stride over the 313 bins, fixed-order butterfly reductions.
+__global__ __launch_bounds__(256) void decode_annealed_kernel(const float* __restrict__ logit, const float* __restrict__ q_to_ab,
+                                                              float* __restrict__ ab, int n, int L, float T) {
+    const int lane = threadIdx.x & 63;
+    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= (long)n * L) return;
+    const long img = tok / L, t = tok - img * L;
+    const float* lg = logit + img * N_VOCAB * L + t;
+    float v[5];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const int q = lane + 64 * i; v[i] = q < N_VOCAB ? lg[(long)q * L] : -INFINITY; mx = fmaxf(mx, v[i]); }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { v[i] = lane + 64 * i < N_VOCAB ? expf(v[i] - mx) : 0.f; sm += v[i]; }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) sm += __shfl_xor(sm, s);
+    float se = 0.f, sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int q = lane + 64 * i;
+        if (q < N_VOCAB) {
+            const float e = expf(v[i] / sm / T);
+            se += e; sa = fmaf(e, q_to_ab[2 * q], sa); sb = fmaf(e, q_to_ab[2 * q + 1], sb);
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { se += __shfl_xor(se, s); sa += __shfl_xor(sa, s); sb += __shfl_xor(sb, s); }
+    if (lane == 0) {
+        ab[(img * 2) * L + t] = sa / se / 110.f;
+        ab[(img * 2 + 1) * L + t] = sb / se / 110.f;
+    }
+}
+
 }  // namespace
+
+int launch_decode_annealed(const float* logit_nchw, const float* q_to_ab, float* ab, int n, int l, float T, hipStream_t s) {
+    if (!(T > 0.f)) { set_error("decode_ind2ab: temperature %g", (double)T); return DISCO_EINVAL; }
+    hipLaunchKernelGGL(decode_annealed_kernel, dim3(cdiv(n * l, 4)), dim3(256), 0, s, logit_nchw, q_to_ab, ab, n, l, T);
+    DISCO_LAUNCH_CHECK("decode_annealed_kernel");
+    return DISCO_OK;
+}
 
 // workspace of one encoder stack: q,k,v (3 T 64), attn, LN1 out, two ping-pong layer outputs (4 T 64), ffn (T 256)
 size_t encoder_ws_bytes(int n, int l) { return (size_t)n * l * (3 * 64 + 4 * 64 + 256) * sizeof(float); }

@@ -224,6 +224,9 @@ int disco_op_nearest_bin(const float *d_ab_nchw, int32_t *d_labels, int n, int h
 int disco_op_position_encoding(float *d_pos, int h, int w, void *stream);
 /* ColorLabel.decode_ind2ab(logit, T) for integer T in [0,9]: ab/110 of the T-th most probable bin (basic.py:196-209) */
 int disco_op_decode_ind2ab(const float *d_logit_nchw, float *d_ab_nchw, int n, int hw, int T, void *stream);
+/* the same for non-integer T (the function's default T = 0.38): annealed mean, ab = sum_q exp(softmax(logit)_q / T) ab_q /
+ * sum_q exp(softmax(logit)_q / T) / 110 (basic.py:210-217) */
+int disco_op_decode_annealed(const float *d_logit_nchw, float *d_ab_nchw, int n, int hw, float T, void *stream);
 /* basic.rgb2lab / basic.lab2rgb (models/basic.py:395-475): rgb in [0,1] <-> ((L-50)/50, a/110, b/110), (n,3,h,w) fp32 */
 int disco_op_rgb2lab(const float *d_rgb, float *d_lab, int n, int h, int w, void *stream);
 int disco_op_lab2rgb(const float *d_lab, float *d_rgb, int n, int h, int w, void *stream);

@@ -409,9 +409,17 @@ def color_labels(ab: Tensor, q_to_ab: Tensor) -> Tensor:
     return torch.max(encode_ab2ind(ab, q_to_ab), dim=1, keepdim=True)[1]
 
 
-def decode_ind2ab(logit: Tensor, q_to_ab: Tensor, t: int = 0) -> Tensor:
-    """t-th most probable bin centre / 110 (basic.py:196-209, integer-T branch; inference.py:114)."""
-    order = torch.sort(torch.softmax(logit, dim=1), dim=1, descending=True, stable=True)[1][:, t]
+def decode_ind2ab(logit: Tensor, q_to_ab: Tensor, t=0) -> Tensor:
+    """Integer t: t-th most probable bin centre / 110 (basic.py:196-209; inference.py:114).
+    Non-integer t (the reference's default 0.38): annealed mean over exp(softmax/t) (basic.py:210-217)."""
+    prob = torch.softmax(logit, dim=1)
+    if t % 1 != 0:
+        e = torch.exp(prob / t)
+        e = e / e.sum(dim=1, keepdim=True)
+        a = torch.tensordot(e, q_to_ab[:, 0], dims=((1,), (0,))).unsqueeze(1)
+        b = torch.tensordot(e, q_to_ab[:, 1], dims=((1,), (0,))).unsqueeze(1)
+        return torch.cat((a, b), dim=1) / 110.0
+    order = torch.sort(prob, dim=1, descending=True, stable=True)[1][:, int(t)]
     return (q_to_ab[order] / 110.0).permute(0, 3, 1, 2).contiguous()
 
 

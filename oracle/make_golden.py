@@ -190,6 +190,12 @@ def posthoc():
     for ks in (3, 5):
         d["marked_k%d" % ks] = npy(basic.mark_color_hints(gray, target, gate, kernel_size=ks, base_ABs=None))
         d["marked_base_k%d" % ks] = npy(basic.mark_color_hints(gray, target, gate, kernel_size=ks, base_ABs=base))
+    # ColorLabel.decode_ind2ab with non-integer T (annealed mean, basic.py:210-217): default 0.38 and a flat 1.5
+    lg = torch.randn(2, 313, 5, 7, generator=g) * 3.0
+    cl = basic.ColorLabel(device="cpu")
+    d["ann_logit"] = npy(lg)
+    d["ann_ab_T038"] = npy(cl.decode_ind2ab(lg, T=0.38))
+    d["ann_ab_T150"] = npy(cl.decode_ind2ab(lg, T=1.5))
     np.savez_compressed(os.path.join(OUT, "posthoc.npz"), **d)
     print("posthoc", {k: v.shape for k, v in d.items()})
 

@@ -275,8 +275,6 @@ def test_basic_mirror_decode_ind2ab(H, comp, t):
     lg = torch.from_numpy(comp["dec_logit"]).to(H.DEV)
     got = basic.ColorLabel().decode_ind2ab(lg, T=t)
     assert torch.equal(got.cpu(), torch.from_numpy(comp["dec_ab_T%d" % t]))
-    with pytest.raises(NotImplementedError):
-        basic.ColorLabel().decode_ind2ab(lg, T=0.38)
 
 
 def test_basic_mirror_colour_space(H, comp):
@@ -304,6 +302,10 @@ def test_basic_mirror_hint_overlay_and_image_io(H, golden_dir):
                            torch.from_numpy(gd["marked_base_k%d" % ks]))
     with pytest.raises(_ffi.DiscoError):
         basic.mark_color_hints(gray, target, gate, kernel_size=4)
+    for key, T in (("ann_ab_T038", 0.38), ("ann_ab_T150", 1.5)):      # annealed-mean decoding, default T = 0.38
+        got = basic.ColorLabel().decode_ind2ab(torch.from_numpy(gd["ann_logit"]).to(H.DEV), T=T)
+        assert H.max_err(got, torch.from_numpy(gd[key])) < 5e-6
+    assert H.max_err(basic.ColorLabel().decode_ind2ab(torch.from_numpy(gd["ann_logit"]).to(H.DEV)), torch.from_numpy(gd["ann_ab_T038"])) < 5e-6
     rs = np.random.RandomState(3)
     for h, w in [(37, 50), (32, 50), (37, 48), (32, 48), (250, 333)]:
         img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)

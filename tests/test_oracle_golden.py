@@ -81,6 +81,9 @@ def test_mark_color_hints_and_image_io(golden_dir):
     for ks in (3, 5):
         assert torch.equal(R.mark_color_hints(gray, target, gate, ks), torch.from_numpy(g["marked_k%d" % ks]))
         assert torch.equal(R.mark_color_hints(gray, target, gate, ks, base), torch.from_numpy(g["marked_base_k%d" % ks]))
+    q = torch.from_numpy(np.asarray(__import__("disentangledcolorization_amd.gamut", fromlist=["gamut_points"]).gamut_points()))
+    for key, T in (("ann_ab_T038", 0.38), ("ann_ab_T150", 1.5)):      # annealed-mean decoding (basic.py:210-217)
+        _close(R.decode_ind2ab(torch.from_numpy(g["ann_logit"]), q, T), g[key], 2e-6)
     rs = np.random.RandomState(3)
     for (h, w), (hp, wp) in {(37, 50): (48, 64), (32, 50): (48, 64), (37, 48): (48, 64), (32, 48): (32, 48)}.items():
         img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
