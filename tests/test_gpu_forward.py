@@ -198,6 +198,35 @@ def test_forward_variants_match_oracle(synth_sd, q_to_ab, variant):
     assert _err(got[2], want[2]) <= AB_TOL
 
 
+@pytest.mark.parametrize("case", range(10))
+def test_randomised_configurations_match_oracle(synth_sd, q_to_ab, case):
+    """Seeded sweep over sizes (multiples of 16 from 64 to 320, non-square), batch, K, colour scale, diverse / GT /
+    validation modes: anchors and anchor colours bit-exact, every output within tolerance of the CPU oracle."""
+    rs = np.random.RandomState(1000 + case)
+    h, w = (int(rs.randint(4, 21)) * 16 for _ in range(2))
+    mode = ["plain", "plain", "diverse", "gt", "val"][case % 5]
+    n = 1 if mode == "diverse" else int(rs.randint(1, 4))
+    k = int(rs.randint(2, min(17, (h // 16) * (w // 16) + 1)))
+    gray, ab = synth.synth_inputs(n, h, w, seed=2000 + case, ab_scale=float(rs.uniform(0.05, 0.8)))
+    T = {"plain": 0, "diverse": 2, "gt": -1, "val": 0}[mode]
+    test_mode = mode != "val"
+    m = _model(synth_sd, k)
+    _seed(case)
+    got = m(gray.cuda(), ab.cuda(), test_mode, T)
+    torch.cuda.synchronize()
+    _seed(case)
+    want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=k).forward(gray, ab, sampled_T=T, test_mode=test_mode)
+    assert torch.equal(got[5].cpu(), want[5]), "anchors differ (%s %dx%d n=%d K=%d)" % (mode, h, w, n, k)
+    if mode in ("plain", "diverse"):
+        assert torch.equal(got[4].cpu(), want[4]), "anchor colours differ"
+    else:
+        assert _err(got[4], want[4]) < 1e-5
+    assert _err(got[3], want[3]) < 1e-4 and _err(got[0], want[0]) < LOGIT_TOL and _err(got[1], want[1]) < LOGIT_TOL
+    e = _err(got[2], want[2])
+    print(f"case {case}: {mode} {h}x{w} n={n} K={k}: max|ab - oracle| = {e:.2e}")
+    assert e <= AB_TOL
+
+
 def test_oversized_batch_is_split(synth_sd, monkeypatch):
     """Maximum sizes: a batch whose full-resolution activations exceed the conv kernel's 32-bit buffer addressing
     (N > 255 at 256x256, N > 63 at 512x512) is run in slices; results and the consumption of the host generators are
