@@ -45,33 +45,50 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
     const int g = threadIdx.x >> 6, lanech = threadIdx.x & 63;
     const float inv = 1.f / (float)npix;
     for (int ch0 = 0; ch0 <= C; ch0 += 64) {
-        const int ch = ch0 + lanech;
+        // A round with few channels left (the ab + ones tail: 3 of 64 lanes would work while the round costs as much as
+        // a full one) splits the lanes as (channel slot, pixel subgroup): nslot = 2^k >= channels left, 64/nslot pixel
+        // subgroups per wave, combined below by a fixed-order xor butterfly.
+        const int left = C + 1 - ch0;
+        int nslot = 64;
+        while (nslot > 1 && (nslot >> 1) >= left) nslot >>= 1;
+        const int nsub = 64 / nslot, chl = lanech & (nslot - 1), sub = lanech / nslot;
+        const int ch = ch0 + chl;
+        const int pstep = 4 * nsub;                       // pixels p = (g + 4 sub) + pstep * i
         float acc[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) acc[c] = 0.f;
         if (ch <= C) {
-            // 4 pixels per trip with all loads issued before their use: the pass is HBM-latency bound, this puts
-            // 4x more bytes in flight per wave
-            for (int p0 = g; p0 < npix; p0 += 16) {
+            // Per-thread source of its channel, resolved once: pointer to pixel (0,0) of the cell and the element stride
+            // between pixels.  (The pass is VALU-issue bound - PMC: 4200 VALU instructions per wave, 65% of them index
+            // arithmetic when the 64-bit offsets and the division by sp sat in the inner loop.)
+            const long cell0 = (long)(cy * a.sp) * a.W + cx * a.sp;
+            const f16* s16 = nullptr; const float* s32 = nullptr; int pstride = 0;
+            if (ch == C) {}
+            else if (ch < a.c_act) { s16 = a.feat_act + (((long)n * (a.c_act >> 4) + (ch >> 4)) * HW + cell0) * 16 + (ch & 15); pstride = 16; }
+            else if (ch < a.c_act + a.c_nchw) { s32 = a.feat_nchw + ((long)n * a.c_nchw + (ch - a.c_act)) * HW + cell0; pstride = 1; }
+            else { s32 = a.feat_bc + cell0 * a.c_bc + (ch - a.c_act - a.c_nchw); pstride = a.c_bc; }
+            const int rowstride = a.W * pstride;               // elements between cell rows
+            const long plane = a.feat_plane;
+            // 4 pixels per trip with all loads issued before their use (puts 4x more bytes in flight per wave);
+            // full round: pixel p = p0 + 4u, p0 = g, g+16, ...: for sp = 16 that is row p0>>4, columns g, g+4, g+8, g+12
+            for (int p0 = g + 4 * sub; p0 < npix; p0 += 4 * pstep) {
                 float f[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int p = p0 + 4 * u;
+                    const int p = p0 + pstep * u;
                     f[u] = 0.f;
                     if (p < npix) {
-                        const int py = p / a.sp, px = p % a.sp;
-                        const long pix = (long)(cy * a.sp + py) * a.W + cx * a.sp + px;
+                        int py, px;
+                        if (a.sp == 16) { py = p >> 4; px = p & 15; } else { py = p / a.sp; px = p - py * a.sp; }
+                        const int off = py * rowstride + px * pstride;
                         if (ch == C) f[u] = 1.f;
-                        else if (ch < a.c_act) {
-                            const long idx = (((long)n * (a.c_act >> 4) + (ch >> 4)) * HW + pix) * 16 + (ch & 15);
-                            f[u] = (float)a.feat_act[idx] + (float)a.feat_act[idx + a.feat_plane];
-                        } else if (ch < a.c_act + a.c_nchw) f[u] = a.feat_nchw[((long)n * a.c_nchw + (ch - a.c_act)) * HW + pix];
-                        else f[u] = a.feat_bc[pix * a.c_bc + (ch - a.c_act - a.c_nchw)];
+                        else if (s16) f[u] = (float)s16[off] + (float)s16[off + plane];
+                        else f[u] = s32[off];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int p = p0 + 4 * u;
+                    const int p = p0 + pstep * u;
                     if (p < npix) {
 #pragma unroll
                         for (int c = 0; c < 9; ++c) acc[c] = fmaf(f[u], sp_prob[p * 9 + c], acc[c]);
@@ -79,16 +96,23 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
                 }
             }
         }
-        // reduce the 4 pixel groups
+        if (nsub > 1) {                                   // wave-uniform: combine the pixel subgroups of each channel slot
 #pragma unroll
-        for (int c = 0; c < 9; ++c) red[(g * 9 + c) * 64 + lanech] = acc[c];
+            for (int c = 0; c < 9; ++c)
+                for (int sft = nslot; sft < 64; sft <<= 1) acc[c] += __shfl_xor(acc[c], sft);
+        }
+        // reduce the 4 pixel groups
+        if (sub == 0) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) red[(g * 9 + c) * 64 + chl] = acc[c];
+        }
         __syncthreads();
-        if (g == 0 && ch <= C) {
+        if (g == 0 && sub == 0 && ch <= C) {
             float* dst = a.partial + ((long)cell * 9) * (C + 1) + ch;
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-                const float s = (red[(0 * 9 + c) * 64 + lanech] + red[(1 * 9 + c) * 64 + lanech]) +
-                                (red[(2 * 9 + c) * 64 + lanech] + red[(3 * 9 + c) * 64 + lanech]);
+                const float s = (red[(0 * 9 + c) * 64 + chl] + red[(1 * 9 + c) * 64 + chl]) +
+                                (red[(2 * 9 + c) * 64 + chl] + red[(3 * 9 + c) * 64 + chl]);
                 dst[(long)c * (C + 1)] = s * inv;
             }
         }
