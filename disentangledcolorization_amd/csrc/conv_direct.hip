@@ -129,7 +129,8 @@ int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, c
                    float slope, hipStream_t s) {
     if (c_out % 16) { set_error("conv_c1: c_out %d not a multiple of 16", c_out); return DISCO_ESHAPE; }
     const long hw = (long)h * w;
-    dim3 grid((unsigned)std::min<long>((2 * hw + 255) / 256, 1024), (unsigned)(n * (c_out / 16)));
+    // few fat workgroups per (image, block): the 192-float parameter staging + barrier is paid once per workgroup
+    dim3 grid((unsigned)std::min<long>((2 * hw + 255) / 256, 64), (unsigned)(n * (c_out / 16)));
     hipLaunchKernelGGL(conv_c1_kernel, grid, dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale, d_bn_shift, out, out_plane,
                        n, h, w, c_out, act, slope);
     DISCO_LAUNCH_CHECK("conv_c1_kernel");

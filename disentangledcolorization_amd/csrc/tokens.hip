@@ -190,8 +190,10 @@ constexpr int KP = 16;     // key partitions (lanes) per query group
 constexpr int QPB = (256 / KP) * QT;   // 64 queries per block
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, float* out, int L) {
-    __shared__ float4 sk[KCH * 2];
-    __shared__ float4 sv[KCH * 2];
+    // halves of a key / value in separate arrays: the 16 partitions of a wave read 16 consecutive float4 (256 contiguous
+    // bytes, no bank conflict; interleaved [key][2] rows put partitions p and p+8 on the same banks)
+    __shared__ float4 sk[2][KCH];
+    __shared__ float4 sv[2][KCH];
     const int qb = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
     const int part = threadIdx.x & (KP - 1);
     const int q0i = qb * QPB + (threadIdx.x / KP) * QT;
@@ -217,8 +219,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         __syncthreads();
         for (int u = threadIdx.x; u < nk * 2; u += 256) {
             const int key = u >> 1, half = u & 1;
-            sk[u] = *reinterpret_cast<const float4*>(k + base + (size_t)(c0 + key) * 64 + half * 4);
-            sv[u] = *reinterpret_cast<const float4*>(v + base + (size_t)(c0 + key) * 64 + half * 4);
+            sk[half][key] = *reinterpret_cast<const float4*>(k + base + (size_t)(c0 + key) * 64 + half * 4);
+            sv[half][key] = *reinterpret_cast<const float4*>(v + base + (size_t)(c0 + key) * 64 + half * 4);
         }
         __syncthreads();
         float sc[KCH / KP][QT];
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int i = 0; i < KCH / KP; ++i) {
             const int j = part + KP * i;
             if (j < nk) {
-                const float4 a = sk[2 * j], b = sk[2 * j + 1];
+                const float4 a = sk[0][j], b = sk[1][j];
                 const f32x2 k0{a.x, a.y}, k1{a.z, a.w}, k2{b.x, b.y}, k3{b.z, b.w};
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int i = 0; i < KCH / KP; ++i) {
             const int j = part + KP * i;
             if (j < nk) {
-                const float4 c = sv[2 * j], d = sv[2 * j + 1];
+                const float4 c = sv[0][j], d = sv[1][j];
                 const f32x2 v0{c.x, c.y}, v1{c.z, c.w}, v2{d.x, d.y}, v3{d.z, d.w};
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
