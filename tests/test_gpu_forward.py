@@ -227,6 +227,23 @@ def test_randomised_configurations_match_oracle(synth_sd, q_to_ab, case):
     assert e <= AB_TOL
 
 
+def test_run_to_run_determinism(synth_sd):
+    """No atomics-ordered or scheduling-dependent arithmetic anywhere on the path: repeated forwards are bit-identical
+    in all six outputs (k-means / pooling reductions use fixed summation orders)."""
+    m = _model(synth_sd, 8)
+    gray, ab = synth.synth_inputs(4, 256, 256, seed=17, ab_scale=0.3)
+    g, a = gray.cuda(), ab.cuda()
+    ref = None
+    for _ in range(5):
+        _seed(1)
+        out = m(g, a, True, 0)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = [t.clone() for t in out]
+        else:
+            assert all(torch.equal(x, y) for x, y in zip(out, ref))
+
+
 def test_oversized_batch_is_split(synth_sd, monkeypatch):
     """Maximum sizes: a batch whose full-resolution activations exceed the conv kernel's 32-bit buffer addressing
     (N > 255 at 256x256, N > 63 at 512x512) is run in slices; results and the consumption of the host generators are
