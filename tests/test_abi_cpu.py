@@ -86,6 +86,23 @@ def test_dropin_state_dict_contract(synth_sd):
     assert all(torch.equal(sd_h[k], synth_sd[k]) for k in same)
 
 
+def test_checkpoint_file_roundtrip(synth_sd, tmp_path):
+    """The reference's checkpoint format (train_colorizer.py:109-113 / utils_train.py:140-151): a torch.save'd dict with
+    'state_dict' (+ ignored bookkeeping), loaded with map_location='cpu' and load_state_dict(strict)."""
+    from disentangledcolorization_amd.model import AnchorColorProb
+
+    m = AnchorColorProb(enhanced=True, init_weights=False)
+    m.load_state_dict(synth_sd)
+    path = tmp_path / "checkpoint.pth.rar"
+    torch.save({"epoch": 3, "best_loss": 0.5, "state_dict": m.state_dict(), "optimizer": {}}, path)
+    data = torch.load(path, map_location=torch.device("cpu"))
+    m2 = AnchorColorProb(enhanced=True, init_weights=False)
+    m2.load_state_dict(data["state_dict"])
+    a, b = m.state_dict(), m2.state_dict()
+    assert list(a.keys()) == list(b.keys()) and all(torch.equal(a[k], b[k]) for k in a)
+    assert a["segnet.net.conv0a.1.num_batches_tracked"].dtype == torch.int64
+
+
 def test_forward_refuses_cpu_tensors(synth_sd):
     from disentangledcolorization_amd.model import AnchorColorProb
 
