@@ -694,6 +694,7 @@ int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
     const int sp = c->opt.sp_size;
     if (a->n < 1 || a->h < sp || a->w < sp || a->h % sp || a->w % sp) { set_error("bad input size %dx%dx%d (multiples of %d)", a->n, a->h, a->w, sp); return DISCO_ESHAPE; }
     if (!c->opt.segnet_only && (a->h / sp) * (a->w / sp) < c->opt.n_clusters) { set_error("fewer tokens than clusters"); return DISCO_ESHAPE; }
+    if (a->max_fallback < 0) { set_error("max_fallback %d", a->max_fallback); return DISCO_EINVAL; }
     if (a->max_fallback > c->opt.n_clusters * 20) { set_error("max_fallback %d > K*20", a->max_fallback); return DISCO_EINVAL; }
     if (a->test_mode & ~1) { set_error("test_mode must be 0 or 1"); return DISCO_EINVAL; }
     // model.py:178 reads the undefined name `spix_color` when hint2regress meets test_mode=False: the reference raises
