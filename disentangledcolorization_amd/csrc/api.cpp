@@ -886,6 +886,17 @@ int disco_forward(disco_ctx* c, const disco_forward_args* a) {
     if (rc) return rc;
     if (!a->d_gray || !a->d_ab || !a->d_pal_logit || !a->d_ref_logit || !a->d_pred_colors || !a->d_affinity ||
         !a->d_spix_colors || !a->d_hint_mask || !a->d_workspace) { set_error("null tensor pointer"); return DISCO_EINVAL; }
+    {   // host index arrays address token rows on the device: range-check them here, a bad row would fault the GPU
+        const int L = (a->h / c->opt.sp_size) * (a->w / c->opt.sp_size), K = c->opt.n_clusters;
+        auto in_range = [&](const int32_t* p, size_t cnt, const char* what) {
+            for (size_t i = 0; p && i < cnt; ++i)
+                if (p[i] < 0 || p[i] >= L) { set_error("%s[%zu] = %d outside [0, %d)", what, i, p[i], L); return false; }
+            return true;
+        };
+        if (!in_range(c->opt.random_hint ? a->h_hint_pos : a->h_init_idx, (size_t)a->n * K, c->opt.random_hint ? "h_hint_pos" : "h_init_idx") ||
+            !in_range(c->opt.random_hint ? nullptr : a->h_fallback_rows, (size_t)a->n * (a->h_fallback_rows ? a->max_fallback : 0), "h_fallback_rows"))
+            return DISCO_EINVAL;
+    }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
     return run_plan(c, a, a->workspace_bytes, false, nullptr);
 }

@@ -329,3 +329,9 @@ def test_error_paths(synth_sd):
         m(gray[:, :, :60].cuda(), ab[:, :, :60].cuda(), True, 0)
     with pytest.raises(Exception):
         m(gray[:, :, :32, :32].cuda(), ab[:, :, :32, :32].cuda(), True, 0)   # 4 tokens < 8 clusters
+    from disentangledcolorization_amd import _ffi
+    bad = np.arange(8, dtype=np.int32)[None].copy(); bad[0, 3] = 16          # 16 tokens at 64x64: row 16 does not exist
+    with pytest.raises(_ffi.DiscoError, match="h_init_idx"):
+        m.forward_with_draws(gray.cuda(), ab.cuda(), True, 0, init_idx=bad)
+    with pytest.raises(ValueError):
+        m.forward_with_draws(gray.cuda(), ab.cuda(), True, 0, init_idx=bad[:, :5])
