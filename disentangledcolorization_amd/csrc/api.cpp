@@ -707,6 +707,14 @@ int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
 // ======================================================================================================================
 // C ABI
 // ======================================================================================================================
+// every size an op entry point takes must be positive (a zero superpixel size would divide by zero on the host, an
+// empty dimension would launch an empty grid)
+static bool positive(const char* op, std::initializer_list<long> dims) {
+    for (long d : dims)
+        if (d <= 0) { set_error("%s: non-positive size %ld", op, d); return false; }
+    return true;
+}
+
 extern "C" {
 
 int disco_expected_tensors(void) { return (int)layout().t.size(); }
@@ -959,10 +967,12 @@ int disco_profile_entry(disco_ctx* c, int i, const char** name, float* ms, doubl
 // ---- operator-level entry points ---------------------------------------------------------------------------------
 
 int disco_op_nchw_to_act(const float* d_src, void* d_dst, int n, int ch, int h, int w, int c_pad, void* stream) {
+    if (!positive("nchw_to_act", {n, ch, h, w, c_pad})) return DISCO_ESHAPE;
     if (!d_src || !d_dst || c_pad < ch || c_pad % 16) { set_error("bad argument (c_pad must be a multiple of 16 >= c)"); return DISCO_EINVAL; }
     return launch_nchw_to_act(d_src, (f16*)d_dst, (long)n * h * w * c_pad, n, ch, h, w, c_pad, (hipStream_t)stream);
 }
 int disco_op_act_to_nchw(const void* d_src, float* d_dst, int n, int ch, int h, int w, int c_pad, void* stream) {
+    if (!positive("act_to_nchw", {n, ch, h, w, c_pad})) return DISCO_ESHAPE;
     if (!d_src || !d_dst || c_pad < ch || c_pad % 16) { set_error("bad argument (c_pad must be a multiple of 16 >= c)"); return DISCO_EINVAL; }
     return launch_act_to_nchw((const f16*)d_src, (long)n * h * w * c_pad, d_dst, n, ch, h, w, c_pad, (hipStream_t)stream);
 }
@@ -997,6 +1007,7 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
                      const float* d_bias, const float* d_bn_scale, const float* d_bn_shift, const void* d_res, void* d_out,
                      void* stream) {
     if (!d || !d_src0 || !d_packed_w || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
+    if (!positive("conv3x3", {d->n, d->h_in, d->w_in, d->c_in0, d->c_out}) || d->c_in1 < 0) { if (d->c_in1 < 0) set_error("conv3x3: c_in1 %d", d->c_in1); return DISCO_ESHAPE; }
     if (d->c_in0 % 16 || d->c_in1 % 16) { set_error("conv3x3 op: source channels must be multiples of 16"); return DISCO_ESHAPE; }
     ConvArgs ca{};
     const int h0 = d->up0 ? d->h_in / 2 : d->h_in, w0 = d->up0 ? d->w_in / 2 : d->w_in;
@@ -1040,6 +1051,7 @@ int disco_op_deconv4x4_pack(const float* h_w, int c_in, int c_out, void* d_packe
 
 int disco_op_deconv4x4(const void* d_src, const void* d_packed_w, const float* d_bias, void* d_out, int n, int h_in, int w_in,
                        int c_in, int c_out, float slope, int precision, void* stream) {
+    if (!positive("deconv4x4", {n, h_in, w_in, c_in, c_out})) return DISCO_ESHAPE;
     if (!d_src || !d_packed_w || !d_bias || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
     if (c_in % 16 || (4 * c_out) % 64) { set_error("deconv4x4: c_in %% 16 and c_out %% 16 required"); return DISCO_ESHAPE; }
     ConvArgs ca{};
@@ -1053,6 +1065,7 @@ int disco_op_deconv4x4(const void* d_src, const void* d_packed_w, const float* d
 
 int disco_op_poolfeat(const float* d_feat, const float* d_prob, float* d_pooled, float* d_conf, float* d_sizes, int n, int ch,
                       int h, int w, int sp, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!positive("poolfeat", {n, ch, h, w, sp})) return DISCO_ESHAPE;
     if (!d_feat || !d_prob || !d_ws) { set_error("null argument"); return DISCO_EINVAL; }
     if (ws_bytes < poolfeat_ws_bytes(n, ch, h, w, sp)) { set_error("poolfeat workspace too small"); return DISCO_ENOMEM; }
     PoolArgs pa{};
@@ -1065,6 +1078,7 @@ int disco_op_poolfeat(const float* d_feat, const float* d_prob, float* d_pooled,
 }
 
 int disco_op_upfeat(const float* d_tok, const float* d_prob, float* d_out, int n, int ch, int h, int w, int sp, void* stream) {
+    if (!positive("upfeat", {n, ch, h, w, sp})) return DISCO_ESHAPE;
     if (!d_tok || !d_prob || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
     return launch_upfeat(d_tok, 0, d_prob, 1, nullptr, 0, d_out, n, ch, h, w, sp, (hipStream_t)stream);
 }
@@ -1073,6 +1087,7 @@ size_t disco_op_encoder_weight_floats(void) { return ENC_LAYERS * ENC_LAYER_FLOA
 
 int disco_op_encoder_stack(const float* d_x, const float* d_pos, const float* d_weights, float* d_out, int n, int l, void* d_ws,
                            size_t ws_bytes, void* stream) {
+    if (!positive("encoder_stack", {n, l})) return DISCO_ESHAPE;
     if (!d_x || !d_pos || !d_weights || !d_out || !d_ws) { set_error("null argument"); return DISCO_EINVAL; }
     if (ws_bytes < encoder_ws_bytes(n, l)) { set_error("encoder workspace too small (%zu < %zu)", ws_bytes, encoder_ws_bytes(n, l)); return DISCO_ENOMEM; }
     return launch_encoder_stack(d_x, d_pos, 0, d_weights, d_out, n, l, d_ws, (hipStream_t)stream);
@@ -1081,6 +1096,7 @@ int disco_op_encoder_stack(const float* d_x, const float* d_pos, const float* d_
 int disco_op_kmeans_anchors(const float* d_x, const float* d_sizes, const int32_t* d_init_idx, const int32_t* d_fallback_rows,
                             int max_fallback, int32_t* d_assign, int32_t* d_anchor, float* d_hint_mask, int32_t* d_info, int n,
                             int l, int k, int d, int channel_major, void* stream) {
+    if (!positive("kmeans_anchors", {n, l, k, d})) return DISCO_ESHAPE;
     if (!d_x || !d_sizes || !d_init_idx || !d_assign || !d_anchor || !d_hint_mask) { set_error("null argument"); return DISCO_EINVAL; }
     return launch_kmeans_anchors(d_x, d_sizes, d_init_idx, d_fallback_rows, max_fallback, d_assign, d_anchor, d_hint_mask, d_info,
                                  n, l, k, (hipStream_t)stream, d, channel_major);
@@ -1099,6 +1115,7 @@ static int gamut_device(float** out) {
 }
 
 int disco_op_select_colors(const float* d_logit, float* d_colors, int32_t* d_labels, int n, int hw, int t, void* stream) {
+    if (!positive("select_colors", {n, hw})) return DISCO_ESHAPE;
     if (!d_logit || !d_colors || t < 0 || t > 2) { set_error("bad argument"); return DISCO_EINVAL; }
     float* q = nullptr;
     int rc = gamut_device(&q);
@@ -1107,6 +1124,7 @@ int disco_op_select_colors(const float* d_logit, float* d_colors, int32_t* d_lab
 }
 
 int disco_op_nearest_bin(const float* d_ab, int32_t* d_labels, int n, int hw, void* stream) {
+    if (!positive("nearest_bin", {n, hw})) return DISCO_ESHAPE;
     if (!d_ab || !d_labels) { set_error("null argument"); return DISCO_EINVAL; }
     float* q = nullptr;
     int rc = gamut_device(&q);
@@ -1115,6 +1133,7 @@ int disco_op_nearest_bin(const float* d_ab, int32_t* d_labels, int n, int hw, vo
 }
 
 int disco_op_decode_ind2ab(const float* d_logit, float* d_ab, int n, int hw, int T, void* stream) {
+    if (!positive("decode_ind2ab", {n, hw})) return DISCO_ESHAPE;
     if (!d_logit || !d_ab) { set_error("null argument"); return DISCO_EINVAL; }
     if (T < 0 || T > 9) { set_error("decode_ind2ab: integer T in [0,9] supported, got %d", T); return DISCO_EUNSUPPORTED; }
     float* q = nullptr;
@@ -1159,6 +1178,7 @@ int disco_op_mark_color_hints(const float* d_gray, const float* d_target_ab, con
 }
 
 int disco_op_position_encoding(float* d_pos, int h, int w, void* stream) {
+    if (!positive("position_encoding", {h, w})) return DISCO_ESHAPE;
     if (!d_pos || h < 1 || w < 1) { set_error("bad argument"); return DISCO_EINVAL; }
     std::vector<float> p((size_t)h * w * 64);
     position_encoding_host(p.data(), h, w);

@@ -115,6 +115,25 @@ def test_conv3x3_stride2_space_to_depth(H, case, prec):
         H.conv3x3(H.to_act(x[:, :, :h - 1]), wt, b, s2d=True, **kw)
 
 
+def test_op_entry_points_reject_bad_sizes(H):
+    """Every op validates its sizes on the host (error code + message, no launch): zero / negative dimensions, a zero
+    superpixel size (would divide by zero), mismatched channel counts."""
+    L = _ffi.lib()
+    t = torch.zeros(4096, device=H.DEV)
+    for rc in (L.disco_op_poolfeat(_ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), None, None, 1, 2, 16, 16, 0, _ffi.ptr(t), 1 << 20, H.stream()),
+               L.disco_op_upfeat(_ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), 1, 2, 0, 4, 16, H.stream()),
+               L.disco_op_kmeans_anchors(_ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), None, 0, _ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), None, 1, 16, 0, 64, 0, H.stream()),
+               L.disco_op_kmeans_anchors(_ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), None, 0, _ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), None, 1, 16, 4, 65, 0, H.stream()),
+               L.disco_op_encoder_stack(_ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), 0, 16, _ffi.ptr(t), 1 << 20, H.stream()),
+               L.disco_op_rgb8_to_lab(_ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), None, 1, 8, 8, 4, 8, H.stream())):
+        assert rc < 0 and L.disco_last_error()
+    d = _ffi.ConvDesc(1, 16, 16, 24, 0, 0, 0, 16, 1, _ffi.ACT_NONE, 0.0, 0, 0)          # 24 input channels: not a multiple of 16
+    assert L.disco_op_conv3x3(C.byref(d), _ffi.ptr(t), None, _ffi.ptr(t), None, None, None, None, _ffi.ptr(t), H.stream()) < 0
+    d = _ffi.ConvDesc(0, 16, 16, 16, 0, 0, 0, 16, 1, _ffi.ACT_NONE, 0.0, 0, 0)
+    assert L.disco_op_conv3x3(C.byref(d), _ffi.ptr(t), None, _ffi.ptr(t), None, None, None, None, _ffi.ptr(t), H.stream()) < 0
+    torch.cuda.synchronize()
+
+
 def test_conv3x3_upsample_and_concat_on_read(H):
     gen = g(5)
     a = torch.randn(2, 32, 12, 20, generator=gen)      # half-resolution source, nearest x2 on read
