@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 #include <map>
 #include <string>
@@ -1103,7 +1104,10 @@ int disco_op_kmeans_anchors(const float* d_x, const float* d_sizes, const int32_
 }
 
 static int gamut_device(float** out) {
-    static float* d = nullptr;   // one table per process is enough for the op-level tests (single device)
+    static float* table[DISCO_MAX_DEVICES] = {};     // the 313-bin table of the op-level entry points, one per device
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    float*& d = table[current_device()];
     if (!d) {
         std::vector<float> q;
         for (auto& r : GAMUT_RUNS) for (int b = r[1]; b <= r[2]; b += 10) { q.push_back((float)r[0]); q.push_back((float)b); }

@@ -86,6 +86,9 @@ struct ConvArgs {
 size_t conv3x3_packed_bytes(int c_out, int c_in_pad);
 // h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map[i] = source channel index for packed channel i or -1 (zero)
 void conv3x3_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed);
+constexpr int DISCO_MAX_DEVICES = 64;
+// ordinal of the calling thread's current HIP device, clamped into [0, DISCO_MAX_DEVICES) (per-device one-time setup tables)
+inline int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0; return d % DISCO_MAX_DEVICES; }
 int diag_mfma_rate(int mode, int iters, double* tflops);   // diag.hip
 int launch_conv3x3_v2(const ConvArgs& a, hipStream_t s);   // conv_mfma2.hip: LDS-DMA double-buffered pipeline
 // ConvTranspose2d(4,s2,p1) weight (c_in,c_out,4,4) -> equivalent 3x3 conv weight (4*c_out, c_in, 3, 3), phase-major

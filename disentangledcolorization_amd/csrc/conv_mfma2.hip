@@ -499,11 +499,12 @@ int launch_cfg2(const ConvArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_mfma2_kernel<TW, TH, NT, STRIDE, X3, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[DISCO_MAX_DEVICES] = {};      // function attributes are per device (one context per device, possibly
+    const int dev = current_device();                   // several devices in one process)
+    if (!attr_set[dev]) {
         DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     // grid.x = tile positions x N tiles; grid.y = image groups: enough groups to give every CU one persistent
     // workgroup (LDS-limited residency), each walking n = g, g + groups, ... over the batch

@@ -678,11 +678,12 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
     if (l <= KM_LDS_TOKENS) {
         const size_t smem = (size_t)l * (d + 1) * sizeof(float) + (size_t)l * sizeof(int);
         auto kern = kmeans_anchor_kernel<true>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[DISCO_MAX_DEVICES] = {};      // per device
+        const int dev = current_device();
+        if (!attr_set[dev]) {
             DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)(KM_LDS_TOKENS * (KM_PITCH + 1) * sizeof(float))));
-            attr_set = true;
+            attr_set[dev] = true;
         }
         hipLaunchKernelGGL(kern, dim3(n), dim3(256), smem, s, x, d, img_stride, t_stride, c_stride, sizes, init_idx,
                            fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
