@@ -45,6 +45,7 @@ class ShardedColorizer:
         # latency-bound token path / k-means of one slice (a few CUs busy) overlaps with the conv stacks of another
         self.micro = max(1, int(micro_batches))
         self._streams = None
+        self._pending = []          # outstanding asynchronous all-gathers (async_gather=True)
 
     @classmethod
     def from_model(cls, model, group=None, micro_batches=1):
@@ -78,9 +79,12 @@ class ShardedColorizer:
             return dist.get_world_size(self.group), dist.get_rank(self.group)
         return 1, 0
 
-    def colorize(self, gray_local, ab_local, n_global, sampled_T=0, gather=True):
+    def colorize(self, gray_local, ab_local, n_global, sampled_T=0, gather=True, async_gather=False):
         """gray_local/ab_local: this rank's shard (shard_bounds order).  Returns (pred_colors, hint_mask) of the
-        GLOBAL batch on every rank when gather=True (one all-gather each), else the local shard."""
+        GLOBAL batch on every rank when gather=True (one all-gather each), else the local shard.
+        async_gather=True: the collectives are only ENQUEUED (on the communication stream, after this forward); the
+        returned tensors are complete after wait() - a pipelined caller issues the next batch's forward meanwhile, so the
+        xGMI transfer of batch k hides under the convolutions of batch k+1."""
         world, rank = self.world()
         lo, hi = shard_bounds(n_global, world, rank)
         if gray_local.shape[0] != hi - lo:
@@ -92,16 +96,24 @@ class ShardedColorizer:
         pred, mask = out[2], out[5]
         if not gather or not (dist.is_available() and dist.is_initialized()):
             return pred, mask
-        return self._all_gather(pred, n_global, world), self._all_gather(mask, n_global, world)
+        return self._all_gather(pred, n_global, world, async_gather), self._all_gather(mask, n_global, world, async_gather)
 
-    def _all_gather(self, local, n_global, world):
+    def wait(self):
+        """Complete every all-gather issued with async_gather=True (the current stream then waits for them)."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def _all_gather(self, local, n_global, world, async_op=False):
         counts = [shard_bounds(n_global, world, r)[1] - shard_bounds(n_global, world, r)[0] for r in range(world)]
         mine = counts[self.world()[1]]
         rep = local.shape[0] // mine if mine else 1          # 3 outputs per image in diverse mode
         per = [c * rep for c in counts]
         if len(set(per)) == 1:   # equal shards: one fused collective
             out = local.new_empty((per[0] * world,) + tuple(local.shape[1:]))
-            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+            work = dist.all_gather_into_tensor(out, local.contiguous(), group=self.group, async_op=async_op)
+            if async_op:
+                self._pending.append(work)
             return out
         mx = max(per)            # ragged: pad to the largest shard
         pad = local.new_zeros((mx,) + tuple(local.shape[1:]))

@@ -40,6 +40,15 @@ def _worker(rank, world, port, n_global, random_hint, q):
     lo, hi = shard_bounds(n_global, world, rank)
     sc = ShardedColorizer(_fake_forward, n_clusters=4, random_hint=random_hint)
     pred, mask = sc.colorize(gray[lo:hi], ab[lo:hi], n_global)
+    # pipelined form used by bench.py: two batches in flight, collectives only enqueued, completed by wait()
+    np.random.seed(130); random.seed(130)
+    p1, m1 = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, async_gather=True)
+    np.random.seed(130); random.seed(130)
+    p2, m2 = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, async_gather=True)
+    sc.wait()
+    assert not sc._pending
+    for a, b in ((p1, pred), (p2, pred), (m1, mask), (m2, mask)):
+        assert torch.equal(a, b)
     q.put((rank, pred.numpy(), mask.numpy()))
     dist.barrier()
     dist.destroy_process_group()
