@@ -158,6 +158,8 @@ def main():
         tf = ctypes.c_double(0.0)
         _ffi.check(_ffi.lib().disco_diag_mfma_rate(2 if args.precision == "f16x3" else 1, 8000, ctypes.byref(tf)))
         sustained = tf.value
+        _ffi.check(_ffi.lib().disco_diag_mfma_rate(3, 8000, ctypes.byref(tf)))     # pixel operands non-negative, half zeros
+        sustained_relu = tf.value
 
     if rank == 0:
         ips = n_global * args.steps / elapsed
@@ -185,6 +187,7 @@ def main():
                 "executed_mfma_tflops": round(executed, 2),
                 "sustained_mfma_tflops_same_operand_mix": round(sustained, 1),
                 "executed_frac_of_sustained": round(executed / sustained, 4) if sustained else None,
+                "sustained_mfma_tflops_relu_like_operands": round(sustained_relu, 1),
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
             },
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},

@@ -55,7 +55,7 @@ float gauss(unsigned& st) {           // sum of 12 uniforms - 6
 }  // namespace
 
 int diag_mfma_rate(int mode, int iters, double* tflops) {
-    if (mode < 0 || mode > 2 || iters <= 0 || !tflops) { set_error("diag_mfma_rate: mode %d iters %d", mode, iters); return DISCO_EINVAL; }
+    if (mode < 0 || mode > 3 || iters <= 0 || !tflops) { set_error("diag_mfma_rate: mode %d iters %d", mode, iters); return DISCO_EINVAL; }
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
         set_error("diag_mfma_rate: no HIP device"); return DISCO_EHIP;
@@ -64,8 +64,12 @@ int diag_mfma_rate(int mode, int iters, double* tflops) {
     unsigned st = 12345u;
     for (size_t i = 0; i < h.size(); ++i) {
         float v = mode == 0 ? 0.f : gauss(st);
-        if (mode == 2 && i >= (size_t)8 * 64 * 8) v *= 4.8e-4f;     // lo planes: ~2^-11 of the hi magnitude
+        if (mode >= 2 && i >= (size_t)8 * 64 * 8) v *= 4.8e-4f;     // lo planes: ~2^-11 of the hi magnitude
         h[i] = (f16)v;
+    }
+    if (mode == 3) {        // post-ReLU activations: about half of the pixel-operand elements (hi and lo alike) are exact zeros
+        for (size_t i = 0; i < (size_t)4 * 64 * 8; ++i) { st = st * 1664525u + 1013904223u; if (st & 0x10000u) h[i] = (f16)0.f; else if (h[i] < (f16)0.f) h[i] = -h[i]; }
+        for (size_t i = 0; i < (size_t)64 * 8; ++i) if (h[i] == (f16)0.f) h[(size_t)8 * 64 * 8 + i] = (f16)0.f;
     }
     f16x8* d_ops = nullptr; float* d_out = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -77,7 +81,7 @@ int diag_mfma_rate(int mode, int iters, double* tflops) {
         hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { set_error("diag_mfma_rate: HIP allocation failed"); rc = DISCO_EHIP; }
     for (int rep = 0; rep < 2 && rc == DISCO_OK; ++rep) {          // rep 0 settles clocks / power state
         hipEventRecord(e0, nullptr);
-        hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(512), 0, nullptr, d_ops, d_out, iters, mode == 2 ? 1 : 0);
+        hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(512), 0, nullptr, d_ops, d_out, iters, mode >= 2 ? 1 : 0);
         hipEventRecord(e1, nullptr);
         if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { set_error("diag_mfma_rate: kernel failed"); rc = DISCO_EHIP; }
     }

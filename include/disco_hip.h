@@ -187,7 +187,8 @@ int disco_op_conv3x3_set_probe(void *d_buf);
 
 /* Diagnostic: sustained v_mfma_f32_32x32x16_f16 rate of the current device on a registers-only loop (no LDS, no
  * memory), 2 waves per SIMD on every CU, operands: mode 0 = zeros, 1 = N(0,1) fp16, 2 = the f16x3 product mix
- * (hi*lo, lo*hi, hi*hi) the conv kernel issues.  The MI355X clock is power-managed and MFMA power depends on operand
+ * (hi*lo, lo*hi, hi*hi) the conv kernel issues, 3 = that mix with post-ReLU-like pixel operands (non-negative, half
+ * of the elements exact zeros).  The MI355X clock is power-managed and MFMA power depends on operand
  * toggling, so this - not the 2.5 PFLOP/s datasheet peak - is what a kernel with this data can reach.  Blocking;
  * *tflops = executed TFLOP/s of the second (warm) run of `iters` iterations x 12 MFMAs per wave. */
 int disco_diag_mfma_rate(int mode, int iters, double *tflops);
