@@ -52,7 +52,10 @@ struct Geo2 {
     static_assert(32 % TW == 0, "an M block covers whole tile rows");
 };
 
-template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN>
+// MASKED: the layer has all-zero taps (sub-pixel up-conv / deconv phases, space-to-depth chunks) that are skipped at run
+// time.  Plain layers (MASKED = false) get a straight-line 9-tap body - no per-tap branches - so the compiler can schedule
+// fragment reads of one tap under the MFMAs of the previous one.
+template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN, bool MASKED>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtins exist in the device pass only
     using G = Geo2<TW, TH, STRIDE>;
@@ -102,11 +105,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
     // s2d: taps (row r, col c of the 3x3 window over the phase image) that exist for phase (py,px): r in {1} (py=0)
     // or {0,1} (py=1), same for c; bit r*3+c
     auto chunk_mask = [&](int ck) -> unsigned {
+        if (!MASKED) return 0x1ffu;
         if (!s2d) return tmask;
         const unsigned ph = (unsigned)ck & 3u;
         return ph == 0 ? 0x010u : (ph == 1 ? 0x018u : (ph == 2 ? 0x012u : 0x01bu));
     };
-    if (a.tapmask) {
+    if (MASKED && a.tapmask) {
         tmask = 0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) tmask |= a.tapmask[by * NT + j];
@@ -227,9 +231,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         __builtin_amdgcn_s_barrier();                        // ... everyone's have; the previous chunk's reads are done
         if (probe) t_c = __builtin_amdgcn_s_memtime();
         // next chunk (or the first chunk of the next image: prefetch across the image boundary)
+        // next chunk, or the first chunk of the next image (prefetch across the image boundary); after the very last chunk
+        // of the workgroup the slot re-fetches chunk 0 of the current image into the idle buffer - harmless, and it keeps
+        // the tap body free of a branch
         const bool more = ck + 1 < nchunks;
-        const bool dma = more || next_n < a.n;
-        const int dma_img = more ? n : next_n, dma_ck = more ? ck + 1 : 0;
+        const int dma_img = more ? n : (next_n < a.n ? next_n : n), dma_ck = more ? ck + 1 : 0;
         const char* sA = smem + buf * BUF_BYTES;
         const char* sW = sA + A_BYTES;
         buf ^= 1;
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         for (int slot = 0; slot < 9; ++slot) {
             const int ky = ROWREUSE ? slot % 3 : slot / 3, kx = ROWREUSE ? slot / 3 : slot % 3;
             const int tap = ky * 3 + kx;
-            if (dma) issue(dma_img, dma_ck, buf, slot);  // one ninth of the next chunk's DMA per step (buf already flipped)
-            const bool live = (cmask >> tap) & 1u;       // wave-uniform: all-zero taps (sub-pixel up-conv / deconv / s2d phases) skip the MFMAs
+            issue(dma_img, dma_ck, buf, slot);           // one ninth of the next chunk's DMA per step (buf already flipped)
+            const bool live = !MASKED || ((cmask >> tap) & 1u);   // wave-uniform: all-zero taps (sub-pixel up-conv / deconv / s2d phases) skip the MFMAs
             if (!ROWREUSE && !live) continue;
             const int tapoff = ky * G::PITCH + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
 #pragma unroll
@@ -492,13 +498,13 @@ inline int num_cus() {
     return n;
 }
 
-template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN>
-int launch_cfg2(const ConvArgs& a, hipStream_t s) {
+template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN, bool MASKED>
+int launch_cfg3(const ConvArgs& a, hipStream_t s) {
     using G = Geo2<TW, TH, STRIDE>;
     constexpr int A_BYTES = (((X3 ? 2 : 1) * G::NPIX * 2 + 63) / 64) * 1024;
     constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_mfma2_kernel<TW, TH, NT, STRIDE, X3, WM, WN>;
+    auto kern = conv3x3_mfma2_kernel<TW, TH, NT, STRIDE, X3, WM, WN, MASKED>;
     static bool attr_set[DISCO_MAX_DEVICES] = {};      // function attributes are per device (one context per device, possibly
     const int dev = current_device();                   // several devices in one process)
     if (!attr_set[dev]) {
@@ -515,6 +521,12 @@ int launch_cfg2(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, a);
     DISCO_LAUNCH_CHECK("conv3x3_mfma2_kernel");
     return DISCO_OK;
+}
+
+template <int TW, int TH, int NT, int STRIDE, bool X3, int WM, int WN>
+int launch_cfg2(const ConvArgs& a, hipStream_t s) {
+    return (a.tapmask || a.s2d) ? launch_cfg3<TW, TH, NT, STRIDE, X3, WM, WN, true>(a, s)
+                                : launch_cfg3<TW, TH, NT, STRIDE, X3, WM, WN, false>(a, s);
 }
 
 template <bool X3>
