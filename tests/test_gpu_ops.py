@@ -217,8 +217,8 @@ def test_encoder_stack_matches_oracle(H, synth_sd, n, hw):
     assert H.max_err(out, want) < 2e-5
 
 
-def _kmeans_gpu(H, x, sizes, init, fallback, k):
-    n, l, _ = x.shape
+def _kmeans_gpu(H, x, sizes, init, fallback, k, d=64, channel_major=0):
+    n, l = x.shape[0], (x.shape[2] if channel_major else x.shape[1])
     xd, sd_ = x.to(H.DEV).contiguous(), sizes.to(H.DEV).contiguous()
     idx = torch.as_tensor(np.asarray(init), dtype=torch.int32).to(H.DEV)
     fb = torch.as_tensor(np.asarray(fallback), dtype=torch.int32).to(H.DEV) if fallback is not None else None
@@ -226,7 +226,7 @@ def _kmeans_gpu(H, x, sizes, init, fallback, k):
     assign = torch.empty(n, l, dtype=torch.int32, device=H.DEV); anchor = torch.empty(n, k, dtype=torch.int32, device=H.DEV)
     mask = torch.empty(n, l, device=H.DEV); info = torch.empty(n, 2, dtype=torch.int32, device=H.DEV)
     _ffi.check(_ffi.lib().disco_op_kmeans_anchors(_ffi.ptr(xd), _ffi.ptr(sd_), _ffi.ptr(idx), _ffi.ptr(fb), mf, _ffi.ptr(assign),
-                                                  _ffi.ptr(anchor), _ffi.ptr(mask), _ffi.ptr(info), n, l, k, 64, 0, H.stream()))
+                                                  _ffi.ptr(anchor), _ffi.ptr(mask), _ffi.ptr(info), n, l, k, d, channel_major, H.stream()))
     torch.cuda.synchronize()
     return assign.cpu().long(), anchor.cpu().long(), mask.cpu(), info.cpu()
 
@@ -249,6 +249,35 @@ def test_kmeans_anchors_golden_and_oracle(H, comp):
     assert info[:, 1].tolist() == events and events[3] > 0
     # first three (no fallback draws involved) are also the reference's own assignments
     assert np.array_equal(assign[:3].numpy(), comp["km_ids"][:3].astype(np.int64))
+
+
+@pytest.mark.parametrize("l,k,d", [(64, 2, 64), (256, 16, 64), (384, 8, 64), (400, 8, 64), (1000, 5, 64), (1536, 16, 64),
+                                   (4096, 32, 64), (4608, 8, 64), (96, 8, 2), (1536, 16, 2)])
+def test_kmeans_every_path_matches_oracle(H, l, k, d):
+    """All three kernel paths - points in LDS (L <= 384), tiled 1024-thread path with the member list (L <= 4096), scan
+    fallback beyond - for 64-feature token rows and for the 2-feature channel-major colours of the validation forward;
+    clustered points (so the iterations really move), duplicated points (empty clusters -> fallback rows)."""
+    n = 3
+    gen = g(l * 31 + k)
+    centres = torch.randn(n, k, d, generator=gen) * 2.0
+    which = torch.randint(0, k, (n, l), generator=gen)
+    x = torch.gather(centres, 1, which[..., None].expand(-1, -1, d)) + torch.randn(n, l, d, generator=gen) * 0.7
+    x[2, : l // 2] = x[2, 0]                                   # image 2: half of the points identical -> empty clusters
+    init = np.stack([np.random.RandomState(l + i).choice(l, k, replace=False) for i in range(n)]).astype(np.int32)
+    init[2, : max(1, k // 2)] = np.arange(max(1, k // 2))      # ... and several initial rows inside the identical half
+    sizes = torch.randint(0, 512, (n, l), generator=gen).float() / 256.0
+    fallback = torch.randint(0, l, (n, 20 * k), generator=gen)
+    want_assign, events = [], []
+    for i in range(n):
+        a, passes, ev = R.kmeans_one(x[i], init[i], k, fallback_rows=[int(v) for v in fallback[i]])
+        want_assign.append(a); events.append(ev)
+    want_assign = torch.stack(want_assign)
+    want_anchor, want_mask = R.anchors_from_clusters(want_assign, sizes, k)
+    xin = x.transpose(1, 2).contiguous() if d == 2 else x      # (n,2,l) channel-major like NCHW colours
+    assign, anchor, mask, info = _kmeans_gpu(H, xin, sizes, init, fallback.numpy(), k, d, 1 if d == 2 else 0)
+    assert torch.equal(assign, want_assign)
+    assert torch.equal(anchor, want_anchor) and torch.equal(mask, want_mask)
+    assert info[:, 1].tolist() == events and (k < 4 or events[2] > 0)
 
 
 @pytest.mark.parametrize("t", [0, 1, 2])
