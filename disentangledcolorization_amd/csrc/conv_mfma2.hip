@@ -534,11 +534,28 @@ int dispatch2(const ConvArgs& a, hipStream_t s) {
     const bool wide = a.w_out > 16;
     const bool nt2 = a.c_out > 32;
     if (a.stride == 1 || a.s2d) {
-        if (wide) {
-            if (a.h_out > 8) return nt2 ? launch_cfg2<32, 16, 2, 1, X3, 8, 1>(a, s) : launch_cfg2<32, 16, 1, 1, X3, 8, 1>(a, s);
-            return nt2 ? launch_cfg2<32, 8, 2, 1, X3, 4, 2>(a, s) : launch_cfg2<32, 8, 1, 1, X3, 4, 1>(a, s);
+        // Tile choice: the largest tile (best MFMA : LDS : DMA ratios) as long as the launch still fills the chip; small
+        // batches of small feature maps (e.g. one image, 512 channels at 32 x 32: 16 workgroups with the 16x32x64 tile)
+        // fall back to smaller tiles / one N block per workgroup, trading per-workgroup efficiency for parallelism.
+        struct Cand { int tw, th, nt; };
+        static const Cand order[6] = {{32, 16, 2}, {32, 16, 1}, {32, 8, 2}, {16, 16, 2}, {32, 8, 1}, {16, 16, 1}};
+        const long fill = (long)num_cus() * 3 / 4;
+        int pick = -1; long best = -1;
+        for (int i = 0; i < 6; ++i) {
+            const Cand& c = order[i];
+            if ((c.nt == 2 && !nt2) || (c.tw == 32 && !wide) || (c.tw == 32 && c.th == 16 && a.h_out <= 8)) continue;
+            const long w = (long)cdiv(a.w_out, c.tw) * cdiv(a.h_out, c.th) * cdiv(a.c_out, 32 * c.nt) * a.n;
+            if (w >= fill) { pick = i; break; }
+            if (w > best) { best = w; pick = i; }
         }
-        return nt2 ? launch_cfg2<16, 16, 2, 1, X3, 4, 2>(a, s) : launch_cfg2<16, 16, 1, 1, X3, 4, 1>(a, s);
+        switch (pick) {
+            case 0: return launch_cfg2<32, 16, 2, 1, X3, 8, 1>(a, s);
+            case 1: return launch_cfg2<32, 16, 1, 1, X3, 8, 1>(a, s);
+            case 2: return launch_cfg2<32, 8, 2, 1, X3, 4, 2>(a, s);
+            case 3: return launch_cfg2<16, 16, 2, 1, X3, 4, 2>(a, s);
+            case 4: return launch_cfg2<32, 8, 1, 1, X3, 4, 1>(a, s);
+            default: return launch_cfg2<16, 16, 1, 1, X3, 4, 1>(a, s);
+        }
     }
     if (wide) return nt2 ? launch_cfg2<32, 4, 2, 2, X3, 4, 2>(a, s) : launch_cfg2<32, 4, 1, 2, X3, 4, 1>(a, s);
     return nt2 ? launch_cfg2<16, 8, 2, 2, X3, 4, 2>(a, s) : launch_cfg2<16, 8, 1, 2, X3, 4, 1>(a, s);
