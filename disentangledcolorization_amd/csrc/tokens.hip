@@ -4,9 +4,9 @@
 //                     (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, exact f32) with fused epilogues:
 //                       QKV   packed in-projection of nn.MultiheadAttention, q=k=src+pos, v=src, q scaled
 //                             (transformer2d.py:52-54)
-//                       RELU  linear1 + ReLU (:56)            RES_LN  out_proj/linear2 + residual + LayerNorm (:55-59)
 //                       LOGIT mid_word_prj / trg_word_prj -> NCHW logits (model.py:134-135,187-189)
 //                       HINT  trg_word_emb on [src ; m*onehot313(label) ; m] (model.py:183-185)
+//   post_attention_kernel  out_proj + residual + LayerNorm + linear1 + ReLU + linear2 + residual + LayerNorm (:55-59), one launch
 //   attention_kernel  softmax(Q K^T) V per (image, head), d_head = 8, 4 queries x every 16th key per thread
 //   kmeans_anchor_kernel  Lloyd k-means (clusterkit.py:112-208) + per-cluster anchor argmax (anchor_gen.py:96-101)
 //   select_colors_kernel  softmax(313) -> stable top-10 -> T-th distinct colour (anchor_gen.py:54-90) + label
@@ -19,7 +19,7 @@ namespace disco {
 
 namespace {
 
-enum { EPI_QKV = 0, EPI_RELU = 1, EPI_RES_LN = 2, EPI_LOGIT = 3, EPI_HINT = 4 };
+enum { EPI_QKV = 0, EPI_LOGIT = 3, EPI_HINT = 4 };
 
 struct GemmArgs {
     const float* A;      // (rows_a, K)
@@ -30,10 +30,7 @@ struct GemmArgs {
     int ldw;
     const float* bias;   // (O) or null
     int T, L, K, O;      // T = virtual rows = n_virtual * L
-    float* out;          // QKV: q|k|v each (T,64); RELU: (T,O); RES_LN: (T,64); LOGIT: (n,O,L); HINT: (T,64)
-    const float* res;    // RES_LN residual (T,64)
-    const float* ln_w;
-    const float* ln_b;
+    float* out;          // QKV: q|k|v each (T,64); LOGIT: (n,O,L); HINT: (T,64)
     float q_scale;
     const int32_t* labels;  // HINT: (T); null = hint2regress, the anchors' ab values are embedded instead
     const float* colors;    // HINT (hint2regress): (n,2,L) NCHW ab/110 of every virtual image
@@ -112,12 +109,6 @@ __global__ __launch_bounds__(256) void token_gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) o[j] = blockIdx.y == 0 ? v[j] * g.q_scale : v[j];
         }
-    } else if (EPI == EPI_RELU) {
-        if (rok) {
-            float* o = g.out + (size_t)row * g.O + col0 + cq;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) o[j] = fmaxf(v[j], 0.f);
-        }
     } else if (EPI == EPI_LOGIT) {
         if (rok) {
 #pragma unroll
@@ -146,25 +137,6 @@ __global__ __launch_bounds__(256) void token_gemm_kernel(const GemmArgs g) {
                 }
             }
         }
-    } else {  // EPI_RES_LN: y = LayerNorm(res + v), biased variance, eps 1e-5
-        float s = 0.f;
-        if (rok) {
-            const float* rp = g.res + (size_t)row * 64 + cq;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { v[j] += rp[j]; s += v[j]; }
-        }
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-        const float mean = s * (1.f / 64.f);
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const float d = v[j] - mean; q += d * d; }
-        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
-        const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + 1e-5f);
-        if (rok) {
-            float* o = g.out + (size_t)row * 64 + cq;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) o[j] = (v[j] - mean) * rstd * g.ln_w[cq + j] + g.ln_b[cq + j];
-        }
     }
 }
 
@@ -174,6 +146,137 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL(token_gemm_kernel<EPI>, grid, dim3(256), 0, s, g);
     DISCO_LAUNCH_CHECK("token_gemm_kernel");
     return DISCO_OK;
+}
+
+// ---- fused post-attention half of an encoder layer (transformer2d.py:55-59) ---------------------------------------
+//   x1 = LN1(x + att Wo^T + bo);  out = LN2(x1 + relu(x1 W1^T + b1) W2^T + b2)
+// Every step is local to a token row, so one workgroup carries a 64-row tile through all three GEMMs with x1 and the
+// 64 x 256 hidden tile in LDS: 3 launches and 2 HBM round trips per layer become one launch.  Same MFMA order per
+// output element (k ascending, fp32 v_mfma_f32_32x32x2) and the same LayerNorm arithmetic as the separate
+// token_gemm_kernel<RELU / RES_LN> launches, so results are bit-identical to them.
+constexpr int HP = 257;   // padded row of the hidden tile
+struct PostAttnArgs {
+    const float* att;    // (T,64) attention output
+    const float* x;      // (T,64) layer input (residual)
+    const float *wo, *bo, *w1, *b1, *w2, *b2, *n1w, *n1b, *n2w, *n2b;
+    float* out;          // (T,64)
+    int T;
+};
+
+__global__ __launch_bounds__(256) void post_attention_kernel(const PostAttnArgs g) {
+    extern __shared__ float smem_pa[];
+    float* sA = smem_pa;                 // [64][GP]  A tile / C staging
+    float* sB = sA + 64 * GP;            // [64][GP]  weight tile
+    float* sX = sB + 64 * GP;            // [64][GP]  x1
+    float* sH = sX + 64 * GP;            // [64][HP]  relu(x1 W1^T + b1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0 = blockIdx.x * 64;
+    const int r = tid >> 2, cq = (tid & 3) * 16;             // epilogue mapping: thread = (row, 16 columns)
+    const int row = row0 + r;
+    const bool rok = row < g.T;
+
+    auto stage = [&](float* dst, const float* src, int ld, int rows_valid) {    // 64 x 64 tile, rows beyond rows_valid zero
+        for (int u = tid; u < 64 * 16; u += 256) {
+            const int rr = u >> 4, c4 = (u & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < rows_valid) v = *reinterpret_cast<const float4*>(src + (size_t)rr * ld + c4);
+            float* d = dst + rr * GP + c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    };
+    auto mma = [&](f32x16& acc, const float* a_tile, int lda) {    // acc += a_tile[wm rows][0..63] * sB[wn cols][0..63]^T
+        const float* pa = a_tile + (wm * 32 + (lane & 31)) * lda + (lane >> 5);
+        const float* pb = sB + (wn * 32 + (lane & 31)) * GP + (lane >> 5);
+#pragma unroll 8
+        for (int k = 0; k < 64; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+    };
+    auto to_lds = [&](const f32x16& acc, float* dst, int ld, int col_off) {   // C tile: row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            dst[rr * ld + col_off + wn * 32 + (lane & 31)] = acc[e];
+        }
+    };
+    auto layer_norm = [&](float* v, const float* w, const float* b) {      // biased variance, eps 1e-5, over the 64 columns
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += v[j];
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+        const float mean = sum * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const float d = v[j] - mean; q += d * d; }
+        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+        const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (v[j] - mean) * rstd * w[cq + j] + b[cq + j];
+    };
+    const int rows_valid = min(64, g.T - row0);
+    f32x16 acc;
+
+    // ---- x1 = LN1(x + att Wo^T + bo) ----
+    stage(sA, g.att + (size_t)row0 * 64, 64, rows_valid);
+    stage(sB, g.wo, 64, 64);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    mma(acc, sA, GP);
+    __syncthreads();
+    to_lds(acc, sA, GP, 0);
+    __syncthreads();
+    {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = sA[r * GP + cq + j] + g.bo[cq + j];
+        if (rok) {
+            const float* rp = g.x + (size_t)row * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] += rp[j];
+        }
+        layer_norm(v, g.n1w, g.n1b);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sX[r * GP + cq + j] = rok ? v[j] : 0.f;
+    }
+    // ---- h = relu(x1 W1^T + b1): four 64-column blocks ----
+    for (int cb = 0; cb < 4; ++cb) {
+        __syncthreads();                                         // sX complete / sB of the previous block consumed
+        stage(sB, g.w1 + (size_t)cb * 64 * 64, 64, 64);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mma(acc, sX, GP);
+        // + bias, relu, straight from the accumulator layout into the hidden tile
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int col = cb * 64 + wn * 32 + (lane & 31);
+            sH[rr * HP + col] = fmaxf(acc[e] + g.b1[col], 0.f);
+        }
+    }
+    // ---- out = LN2(x1 + h W2^T + b2): K = 256 in four chunks ----
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int kc = 0; kc < 4; ++kc) {
+        __syncthreads();                                         // sH complete / sB of the previous chunk consumed
+        stage(sB, g.w2 + (size_t)kc * 64, 256, 64);
+        __syncthreads();
+        mma(acc, sH + kc * 64, HP);
+    }
+    __syncthreads();
+    to_lds(acc, sA, GP, 0);
+    __syncthreads();
+    {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = sA[r * GP + cq + j] + g.b2[cq + j] + sX[r * GP + cq + j];
+        layer_norm(v, g.n2w, g.n2b);
+        if (rok) {
+            float* o = g.out + (size_t)row * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = v[j];
+        }
+    }
 }
 
 // ---- attention: softmax(Q K^T) V per (image, head), d_head = 8 --------------------------------------------------
@@ -765,17 +868,15 @@ int launch_decode_annealed(const float* logit_nchw, const float* q_to_ab, float*
     return DISCO_OK;
 }
 
-// workspace of one encoder stack: q,k,v (3 T 64), attn, LN1 out, two ping-pong layer outputs (4 T 64), ffn (T 256)
-size_t encoder_ws_bytes(int n, int l) { return (size_t)n * l * (3 * 64 + 4 * 64 + 256) * sizeof(float); }
+// workspace of one encoder stack: q,k,v (3 T 64), attention output (T 64), two ping-pong layer outputs (2 T 64)
+size_t encoder_ws_bytes(int n, int l) { return (size_t)n * l * (3 * 64 + 3 * 64) * sizeof(float); }
 
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
                          void* ws, hipStream_t s) {
     const int T = n * l;
     float* qkv = reinterpret_cast<float*>(ws);
     float* att = qkv + (size_t)3 * T * 64;
-    float* xa = att + (size_t)T * 64;
-    float* pp[2] = {xa + (size_t)T * 64, xa + (size_t)2 * T * 64};
-    float* ffn = xa + (size_t)3 * T * 64;
+    float* pp[2] = {att + (size_t)T * 64, att + (size_t)2 * T * 64};
     const float* cur = x;
     for (int layer = 0; layer < ENC_LAYERS; ++layer) {
         const float* w = weights + (size_t)layer * ENC_LAYER_FLOATS;
@@ -795,18 +896,21 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         hipLaunchKernelGGL(attention_kernel, dim3(cdiv(l, QPB), N_HEAD, n), dim3(256), 0, s, qkv, qkv + (size_t)T * 64,
                            qkv + (size_t)2 * T * 64, att, l);
         DISCO_LAUNCH_CHECK("attention_kernel");
-        // x1 = LN1(x + att Wo^T + bo)
-        g.A = att; g.pos = nullptr; g.W = out_w; g.ldw = 64; g.bias = out_b; g.K = 64; g.O = 64; g.out = xa;
-        g.res = cur; g.ln_w = n1_w; g.ln_b = n1_b;
-        if ((rc = launch_gemm<EPI_RES_LN>(g, s))) return rc;
-        // f = relu(x1 W1^T + b1)
-        g.A = xa; g.W = l1_w; g.ldw = 64; g.bias = l1_b; g.K = 64; g.O = 256; g.out = ffn; g.res = nullptr;
-        if ((rc = launch_gemm<EPI_RELU>(g, s))) return rc;
-        // x2 = LN2(x1 + f W2^T + b2)
+        // x1 = LN1(x + att Wo^T + bo); out = LN2(x1 + relu(x1 W1^T + b1) W2^T + b2): one fused launch
         float* dst = layer == ENC_LAYERS - 1 ? out : pp[layer & 1];
-        g.A = ffn; g.W = l2_w; g.ldw = 256; g.bias = l2_b; g.K = 256; g.O = 64; g.out = dst; g.res = xa;
-        g.ln_w = n2_w; g.ln_b = n2_b;
-        if ((rc = launch_gemm<EPI_RES_LN>(g, s))) return rc;
+        {
+            PostAttnArgs pa{att, cur, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, dst, T};
+            constexpr size_t smem = (size_t)(3 * 64 * GP + 64 * HP) * sizeof(float);
+            static bool attr_set[DISCO_MAX_DEVICES] = {};      // per device
+            const int dev = current_device();
+            if (!attr_set[dev]) {
+                DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(post_attention_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                attr_set[dev] = true;
+            }
+            hipLaunchKernelGGL(post_attention_kernel, dim3(cdiv(T, 64)), dim3(256), smem, s, pa);
+            DISCO_LAUNCH_CHECK("post_attention_kernel");
+        }
         cur = dst;
     }
     return DISCO_OK;
