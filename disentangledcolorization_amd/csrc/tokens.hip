@@ -419,7 +419,7 @@ constexpr int KMAX = 32;
 constexpr int KM_LDS_TOKENS = 384;       // the point set itself lives in LDS up to this many points
 constexpr int KM_PITCH = 65;
 constexpr int KM_LIST_TOKENS = 4096;     // member list + assignments in LDS up to this many points (1024 x 1024 images)
-template <bool XLDS>
+template <bool XLDS, bool GLIST>
 __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __restrict__ x, int D, long img_stride, int t_stride,
                                                              int c_stride, const float* __restrict__ sizes,
                                                              const int32_t* __restrict__ init_idx,
@@ -442,9 +442,12 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
     const int nseg = (L + 63) >> 6;
     const float* X = x + (size_t)img * img_stride;
     float* xs = dyn;
-    int* asg = reinterpret_cast<int*>(dyn + (size_t)(XLDS ? L : 256) * pitch);
-    int* list = asg + L;
-    int* seg = list + L;                    // [nseg][K]: members of cluster j in segment s -> exclusive offsets
+    // assignments and member list: LDS up to KM_LIST_TOKENS points; beyond (GLIST) they live in global memory - the
+    // assignment output itself and, until the anchors are written at the very end, the image's hint_mask row
+    int* lds_ints = reinterpret_cast<int*>(dyn + (size_t)(XLDS ? L : 256) * pitch);
+    int* asg = GLIST ? assign_out + (size_t)img * L : lds_ints;
+    int* list = GLIST ? reinterpret_cast<int*>(hint_mask + (size_t)img * L) : lds_ints + L;
+    int* seg = GLIST ? lds_ints : lds_ints + 2 * L;   // [nseg][K]: members of cluster j in segment s -> exclusive offsets
     float* best_d = reinterpret_cast<float*>(seg + nseg * K);     // [4][256] partial minima of the centre quarters
     int* best_j = reinterpret_cast<int*>(best_d + 4 * 256);
     int32_t* assign = assign_out + (size_t)img * L;
@@ -574,7 +577,8 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
         __syncthreads();
         if (s_stop) break;
     }
-    for (int t = tid; t < L; t += NTHR) assign[t] = asg[t];
+    if (!GLIST) for (int t = tid; t < L; t += NTHR) assign[t] = asg[t];
+    __syncthreads();                        // GLIST: every thread is done with the member list before hint_mask is rewritten
     // anchors: per cluster the first argmax of [assign==j] + sizes*0.01 (exact fp32 ops, no fma)
     const float* sz = sizes + (size_t)img * L;
     float* hm = hint_mask + (size_t)img * L;
@@ -976,11 +980,10 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
     const int t_stride = channel_major ? 1 : d, c_stride = channel_major ? l : 1;
     const int nseg = (l + 63) / 64;
     const size_t lists = ((size_t)2 * l + (size_t)nseg * k) * sizeof(int);
+    const size_t best = (size_t)4 * 256 * (sizeof(float) + sizeof(int));
     constexpr int MAX_SMEM = 128 * 1024;      // dynamic part; the kernels hold up to 27 KB of static LDS besides
-    if (l <= KM_LDS_TOKENS) {
-        const size_t smem = (size_t)l * (d + 1) * sizeof(float) + lists + (size_t)4 * 256 * (sizeof(float) + sizeof(int));
-        auto kern = kmeans_anchor_kernel<true>;
-        static bool attr_set[DISCO_MAX_DEVICES] = {};      // per device
+    auto launch = [&](auto kern, size_t smem) -> int {
+        static bool attr_set[DISCO_MAX_DEVICES] = {};      // per device and per instantiation (one lambda body each)
         const int dev = current_device();
         if (!attr_set[dev]) {
             DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM));
@@ -988,21 +991,18 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
         }
         hipLaunchKernelGGL(kern, dim3(n), dim3(1024), smem, s, x, d, img_stride, t_stride, c_stride, sizes, init_idx,
                            fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
-    } else if (l <= KM_LIST_TOKENS) {
-        const size_t smem = (size_t)256 * (d + 1) * sizeof(float) + lists + (size_t)4 * 256 * (sizeof(float) + sizeof(int));
-        auto kern = kmeans_anchor_kernel<false>;
-        static bool attr_set[DISCO_MAX_DEVICES] = {};
-        const int dev = current_device();
-        if (!attr_set[dev]) {
-            DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM));
-            attr_set[dev] = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(n), dim3(1024), smem, s, x, d, img_stride, t_stride, c_stride, sizes, init_idx,
-                           fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
-    } else {
+        return DISCO_OK;
+    };
+    const size_t tile = (size_t)256 * (d + 1) * sizeof(float);
+    const size_t glist_smem = tile + (size_t)nseg * k * sizeof(int) + best;
+    int rc = DISCO_OK;
+    if (l <= KM_LDS_TOKENS) rc = launch(kmeans_anchor_kernel<true, false>, (size_t)l * (d + 1) * sizeof(float) + lists + best);
+    else if (l <= KM_LIST_TOKENS) rc = launch(kmeans_anchor_kernel<false, false>, tile + lists + best);
+    else if (glist_smem <= (size_t)MAX_SMEM) rc = launch(kmeans_anchor_kernel<false, true>, glist_smem);
+    else
         hipLaunchKernelGGL(kmeans_anchor_scan_kernel<false>, dim3(n), dim3(256), (size_t)l * sizeof(int), s, x, d, img_stride,
                            t_stride, c_stride, sizes, init_idx, fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
-    }
+    if (rc) return rc;
     DISCO_LAUNCH_CHECK("kmeans_anchor_kernel");
     return DISCO_OK;
 }

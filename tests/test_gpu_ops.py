@@ -252,10 +252,10 @@ def test_kmeans_anchors_golden_and_oracle(H, comp):
 
 
 @pytest.mark.parametrize("l,k,d", [(64, 2, 64), (256, 16, 64), (384, 8, 64), (400, 8, 64), (1000, 5, 64), (1536, 16, 64),
-                                   (4096, 32, 64), (4608, 8, 64), (96, 8, 2), (1536, 16, 2)])
+                                   (4096, 32, 64), (4608, 8, 64), (8192, 16, 64), (32768, 32, 64), (96, 8, 2), (1536, 16, 2)])
 def test_kmeans_every_path_matches_oracle(H, l, k, d):
-    """All three kernel paths - points in LDS (L <= 384), tiled 1024-thread path with the member list (L <= 4096), scan
-    fallback beyond - for 64-feature token rows and for the 2-feature channel-major colours of the validation forward;
+    """All four kernel paths - points in LDS (L <= 384), tiled 1024-thread path with the member list in LDS (L <= 4096) or in
+    global memory (beyond, while the per-segment counts fit in LDS), scan fallback (32768 points, K = 32) - for 64-feature token rows and for the 2-feature channel-major colours of the validation forward;
     clustered points (so the iterations really move), duplicated points (empty clusters -> fallback rows)."""
     n = 3
     gen = g(l * 31 + k)
