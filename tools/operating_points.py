@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Forward time and stage split over batch sizes / image sizes (GPU box):  python tools/operating_points.py [--k 8]
+(asynchronous loop of 10 forwards after 3 warm-ups; stage times from the context's hipEvents of the last forward)"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from disentangledcolorization_amd import synth  # noqa: E402
+from disentangledcolorization_amd.model import AnchorColorProb  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--k", type=int, default=8)
+args = ap.parse_args()
+m = AnchorColorProb(n_clusters=args.k, enhanced=True).cuda().eval()
+m.sync_kmeans_events = False
+m.set_profiling(1)
+POINTS = [(1, 256, 256), (2, 256, 256), (4, 256, 256), (8, 256, 256), (16, 256, 256), (64, 256, 256), (128, 256, 256),
+          (256, 128, 128), (1, 512, 768), (8, 512, 768), (16, 512, 512), (1, 1024, 1024), (1, 2048, 2048)]
+for n, h, w in POINTS:
+    g, a = synth.synth_inputs(n, h, w, seed=1, ab_scale=0.3)
+    g, a = g.cuda(), a.cuda()
+    reps = 10 if n * h * w <= 64 * 256 * 256 else 3
+    for _ in range(3):
+        np.random.seed(1); m(g, a, True, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        np.random.seed(1); m(g, a, True, 0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps * 1e3
+    st = {k_: round(ms, 2) for k_, ms, _ in m.profile()}
+    print("%4d x %4dx%-4d  %8.2f ms/forward  %7.0f img/s  %5.1f ns/px  %s" % (n, h, w, dt, n / dt * 1e3, dt * 1e6 / (n * h * w), st))
