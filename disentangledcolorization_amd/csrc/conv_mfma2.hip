@@ -516,7 +516,18 @@ int launch_cfg3(const ConvArgs& a, hipStream_t s) {
     // workgroup (LDS-limited residency), each walking n = g, g + groups, ... over the batch
     const int combos = cdiv(a.w_out, TW) * cdiv(a.h_out, TH) * cdiv(a.c_out, 32 * NT);
     static const int persist = [] { const char* e = getenv("DISCO_PERSIST"); return e ? atoi(e) : 1; }();
-    int groups = persist > 0 ? std::max(1, std::min(a.n, cdiv(persist * num_cus(), combos))) : a.n;
+    // image groups g: every workgroup walks ceil(n / g) images and the launch takes ceil(combos g / CUs) rounds of
+    // workgroups, so pick the g that minimises rounds x images (ties: the smaller g, longer persistent walks).  E.g. 96
+    // combos x 8 images on 256 CUs: g = 3 would run 2 rounds of 3 images, g = 8 runs 3 rounds of 1.
+    int groups = a.n;
+    if (persist > 0) {
+        const long cus = (long)persist * num_cus();
+        long best_cost = -1;
+        for (int g = 1; g <= a.n; ++g) {
+            const long cost = (long)cdiv((long)combos * g, cus) * cdiv(a.n, g);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; groups = g; }
+        }
+    }
     dim3 grid(combos, groups);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, a);
     DISCO_LAUNCH_CHECK("conv3x3_mfma2_kernel");
