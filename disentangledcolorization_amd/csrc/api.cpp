@@ -1032,6 +1032,88 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
     return run_conv(ca, (hipStream_t)stream);
 }
 
+static Act flat_act(const void* p, int n, int c_pad, int h, int w, int planes, int sexp) {
+    Act t; t.p = (f16*)p; t.n = n; t.h = h; t.w = w; t.c = c_pad; t.sexp = sexp;
+    const size_t el = t.elems();
+    t.plane = (planes & DISCO_PLANE_LO) ? el : 0;
+    t.q_off = (planes & DISCO_PLANE_Q) ? el * 2 * ((planes & DISCO_PLANE_LO) ? 2 : 1) : 0;
+    return t;
+}
+
+int disco_op_act_bytes(int n, int c_pad, int h, int w, int planes, size_t* bytes) {
+    if (!bytes || !positive("act_bytes", {n, c_pad, h, w})) return DISCO_EINVAL;
+    *bytes = flat_act(nullptr, n, c_pad, h, w, planes, 0).bytes();
+    return DISCO_OK;
+}
+
+int disco_op_nchw_to_act_mx(const float* d_src, void* d_dst, int n, int ch, int h, int w, int c_pad, int planes, int sexp, void* stream) {
+    if (!positive("nchw_to_act_mx", {n, ch, h, w, c_pad})) return DISCO_ESHAPE;
+    if (!d_src || !d_dst || c_pad < ch || c_pad % ((planes & DISCO_PLANE_Q) ? 32 : 16)) { set_error("bad argument (c_pad must be a multiple of 16, 32 with q planes, >= c)"); return DISCO_EINVAL; }
+    return launch_nchw_to_act_mx(d_src, flat_act(d_dst, n, c_pad, h, w, planes, sexp), ch, (hipStream_t)stream);
+}
+
+int disco_op_act_mx_to_nchw(const void* d_src, float* d_dst, int n, int ch, int h, int w, int c_pad, int planes, int sexp, int which, void* stream) {
+    if (!positive("act_mx_to_nchw", {n, ch, h, w, c_pad})) return DISCO_ESHAPE;
+    if (!d_src || !d_dst || c_pad < ch) { set_error("bad argument"); return DISCO_EINVAL; }
+    const Act t = flat_act(d_src, n, c_pad, h, w, planes, sexp);
+    if (which == 0) {
+        if (!t.plane) { set_error("act_mx_to_nchw: which = 0 needs the lo plane"); return DISCO_EINVAL; }
+        return launch_act_to_nchw(t.p, (long)t.plane, d_dst, n, ch, h, w, c_pad, (hipStream_t)stream);
+    }
+    if (!t.q_off || which < 1 || which > 2) { set_error("act_mx_to_nchw: which %d / planes %d", which, planes); return DISCO_EINVAL; }
+    return launch_act_q_to_nchw(t, d_dst, ch, which - 1, (hipStream_t)stream);
+}
+
+int disco_op_conv3x3_mx_pack(const float* h_w, int c_out, int c_in, void* d_packed, int32_t* d_wexp, size_t* bytes) {
+    if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }
+    const int cpad = round_up(c_in, 32);
+    *bytes = conv_mx_packed_bytes(c_out, cpad);
+    if (!d_packed) return DISCO_OK;
+    if (!h_w || !d_wexp) { set_error("null weight"); return DISCO_EINVAL; }
+    std::vector<char> packed(*bytes);
+    std::vector<int32_t> wexp((size_t)round_up(c_out, 32));
+    conv_mx_pack_host(h_w, c_out, c_in, nullptr, cpad, packed.data(), wexp.data());
+    DISCO_HIP_CHECK(hipMemcpy(d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    DISCO_HIP_CHECK(hipMemcpy(d_wexp, wexp.data(), wexp.size() * 4, hipMemcpyHostToDevice));
+    return DISCO_OK;
+}
+
+int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const void* d_src1, const void* d_packed_w, const int32_t* d_wexp,
+                        const float* d_bias, const float* d_bn_scale, const float* d_bn_shift, const void* d_res, void* d_out,
+                        uint32_t* d_sat, void* stream) {
+    if (!d || !d_src0 || !d_packed_w || !d_wexp || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
+    if (!positive("conv3x3_mx", {d->n, d->h_in, d->w_in, d->c_in0, d->c_out}) || d->c_in1 < 0) { if (d->c_in1 < 0) set_error("conv3x3_mx: c_in1 %d", d->c_in1); return DISCO_ESHAPE; }
+    ConvMxArgs ca{};
+    const int h0 = d->up0 ? d->h_in / 2 : d->h_in, w0 = d->up0 ? d->w_in / 2 : d->w_in;
+    const Act s0 = flat_act(d_src0, d->n, d->c_in0, h0, w0, DISCO_PLANE_Q, d->sexp0);
+    if (s0.q_off >= ((size_t)1 << 32)) { set_error("conv3x3_mx: source too large"); return DISCO_ESHAPE; }
+    ca.src[0] = {s0.p, (uint32_t)s0.q_off, d->c_in0, h0, w0, d->up0, d->sexp0};
+    ca.nsrc = 1;
+    if (d->c_in1) {
+        if (!d_src1) { set_error("null second source"); return DISCO_EINVAL; }
+        const int h1 = d->up1 ? d->h_in / 2 : d->h_in, w1 = d->up1 ? d->w_in / 2 : d->w_in;
+        const Act s1 = flat_act(d_src1, d->n, d->c_in1, h1, w1, DISCO_PLANE_Q, d->sexp1);
+        if (s1.q_off >= ((size_t)1 << 32)) { set_error("conv3x3_mx: source too large"); return DISCO_ESHAPE; }
+        ca.src[1] = {s1.p, (uint32_t)s1.q_off, d->c_in1, h1, w1, d->up1, d->sexp1};
+        ca.nsrc = 2;
+    }
+    ca.n = d->n; ca.h_in = d->h_in; ca.w_in = d->w_in; ca.c_in = d->c_in0 + d->c_in1;
+    ca.stride = d->stride; ca.h_out = (d->h_in - 1) / d->stride + 1; ca.w_out = (d->w_in - 1) / d->stride + 1;
+    ca.w = d_packed_w; ca.wexp = d_wexp; ca.c_out = d->c_out; ca.c_out_pad = d->c_out;
+    ca.bias = d_bias; ca.bn_scale = d_bn_scale; ca.bn_shift = d_bn_shift;
+    if (d->out_f32) ca.out_f32 = (float*)d_out;
+    else {
+        const Act o = flat_act(d_out, d->n, d->c_out, ca.h_out, ca.w_out, d->out_planes, d->out_sexp);
+        ca.out = o.p; ca.out_plane = (long)o.plane; ca.out_q_off = o.q_off; ca.out_sexp = d->out_sexp;
+    }
+    if (d_res) {
+        const Act rr = flat_act(d_res, d->n, d->c_out, ca.h_out, ca.w_out, d->res_planes, 0);
+        ca.res = rr.p; ca.res_plane = (long)rr.plane;
+    }
+    ca.act = d->act; ca.slope = d->slope; ca.sat = d_sat;
+    return launch_conv3x3_mx(ca, (hipStream_t)stream);
+}
+
 int disco_op_conv3x3_set_probe(void* d_buf) { g_conv_probe = (unsigned long long*)d_buf; return DISCO_OK; }
 
 int disco_diag_mfma_rate(int mode, int iters, double* tflops) { return diag_mfma_rate(mode, iters, tflops); }

@@ -34,13 +34,23 @@ int hip_fail(hipError_t e, const char* what);
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
-// ---- activation tensor: channel-blocked [N][C/16][H][W][16] fp16, hi plane followed by lo plane ----
+// ---- activation tensor ----------------------------------------------------------------------------
+// hi plane: channel-blocked [N][C/16][H][W][16] fp16 = fp16(x), always present.
+// lo plane (optional, `plane` != 0): same layout, fp16(x - hi), at p + plane   (the f16x3 kernel's second operand plane,
+//   residual inputs, the pooling kernel).
+// q planes (optional, `q_off` != 0): fp8 e4m3 [N][C/32][2][H][W][32] at (char*)p + q_off: for every 32-channel block the
+//   plane a8 = fp8(x * 2^sexp) followed by the plane al8 = fp8((x - hi) * 2^(sexp + 11))   (the correction operands of
+//   conv3x3_mx_kernel).  sexp is a per-tensor power of two fixed at calibration time.
 struct Act {
     f16* p = nullptr;  // hi plane; lo plane at p + plane
     int n = 0, h = 0, w = 0, c = 0;
-    size_t plane = 0;  // elements per plane = n*h*w*c
-    size_t bytes() const { return plane * 2 * sizeof(f16); }
+    size_t plane = 0;  // elements between the hi and the lo plane (= n*h*w*c), 0: no lo plane
+    size_t q_off = 0;  // bytes between p and the q planes, 0: none
+    int sexp = 0;
+    size_t elems() const { return (size_t)n * h * w * c; }
+    size_t bytes() const { return elems() * sizeof(f16) * (1 + (plane ? 1 : 0) + (q_off ? 1 : 0)); }
 };
+constexpr int MX_LO_SHIFT = 11;     // al8 carries 2^11 more scale than a8 (|x - fp16(x)| <= 2^-11 |x|)
 
 // ---- conv3x3 (MFMA implicit GEMM) ---------------------------------------------------------------
 constexpr int CONV_CK = 16;  // input-channel chunk (one MFMA k-block)
@@ -82,6 +92,51 @@ struct ConvArgs {
     int s2d;            // stride-2 layer whose weights were packed for the space-to-depth view (conv3x3_s2d_weights_host)
     unsigned long long* dbg;  // timing probe (tools/conv_timeline.py): per-chunk s_memtime stamps of workgroup 0, or null
 };
+
+// ---- conv3x3, fp16 main product + two fp8 (e4m3, K = 64) correction products (conv_mx.hip) ----------------------------
+struct MxSrc {
+    const f16* p;        // hi plane
+    uint32_t q_off;      // bytes from p to the q planes
+    int c, h, w, up;     // channels (multiple of 32), stored size, nearest x2 upsample on read
+    int sexp;            // scale exponent of the q planes
+};
+struct ConvMxArgs {
+    MxSrc src[2];
+    int nsrc;
+    int n, h_in, w_in;
+    int c_in;                 // total input channels (multiple of 32)
+    int h_out, w_out, stride;
+    const void* w;            // packed weights (conv_mx_pack_host)
+    const int32_t* wexp;      // per output channel (padded to 32): scale exponent of its fp8 weight planes
+    const uint32_t* tapmask;
+    int c_out, c_out_pad;
+    const float* bias;
+    const float* bn_scale;
+    const float* bn_shift;
+    const f16* res;           // residual: hi plane, lo plane at res + res_plane (res_plane 0: hi only)
+    long res_plane;
+    f16* out;                 // hi plane
+    long out_plane;           // != 0: also write the lo plane at out + out_plane
+    size_t out_q_off;         // != 0: also write the q planes at (char*)out + out_q_off with scale exponent out_sexp
+    int out_sexp;
+    float* out_f32;
+    int d2s_c;
+    int act;
+    float slope;
+    int softmax;
+    unsigned int* sat;        // optional device counter: q-plane elements that had to be clamped to +-448
+    uint32_t src_bytes[2], w_bytes, out_bytes, res_bytes;   // filled by the launcher: buffer-descriptor ranges
+};
+size_t conv_mx_packed_bytes(int c_out, int c_in_pad);
+// h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map as in conv3x3_pack_host; c_in_pad multiple of 32; h_wexp: cdiv(c_out,32)*32 ints
+void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp);
+int launch_conv3x3_mx(const ConvMxArgs& a, hipStream_t s);
+unsigned char fp8_e4m3_from_float(float x);      // round to nearest even, saturating to +-448
+float fp8_e4m3_to_float(unsigned char v);
+// fp32 NCHW -> act with optional lo / q planes (q: scale exponent sexp); and amax |x| over an act's hi plane
+int launch_nchw_to_act_mx(const float* src, const Act& dst, int c, hipStream_t s);
+int launch_act_amax(const Act& a, float* d_amax, hipStream_t s);
+int launch_act_q_to_nchw(const Act& a, float* dst, int c, int which, hipStream_t s);   // tests: dequantised q planes
 
 size_t conv3x3_packed_bytes(int c_out, int c_in_pad);
 // h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map[i] = source channel index for packed channel i or -1 (zero)

@@ -180,6 +180,37 @@ int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d
                      const float *d_bias, const float *d_bn_scale, const float *d_bn_shift, const void *d_res,
                      void *d_out, void *stream);
 
+/* ---- conv3x3 with an fp16 main product and fp8 (e4m3, K = 64 MFMA) correction products (csrc/conv_mx.hip) -----------
+ * Activation buffers of this path: the fp16 hi plane [N][C/16][H][W][16], then (planes bit 0) the fp16 lo plane, then
+ * (planes bit 1) the fp8 q planes [N][C/32][2][H][W][32]: a8 = fp8(x 2^sexp) and al8 = fp8((x - hi) 2^(sexp+11)), one
+ * power-of-two scale per tensor.  C is padded to a multiple of 16 (32 with q planes). */
+#define DISCO_PLANE_LO 1
+#define DISCO_PLANE_Q 2
+int disco_op_act_bytes(int n, int c_pad, int h, int w, int planes, size_t *bytes);
+int disco_op_nchw_to_act_mx(const float *d_src, void *d_dst, int n, int c, int h, int w, int c_pad, int planes, int sexp,
+                            void *stream);
+/* which = 0: hi (+ lo when present); 1: the a8 plane dequantised; 2: hi + the al8 plane dequantised */
+int disco_op_act_mx_to_nchw(const void *d_src, float *d_dst, int n, int c, int h, int w, int c_pad, int planes, int sexp,
+                            int which, void *stream);
+typedef struct disco_conv_mx_desc {
+    int32_t n, h_in, w_in;
+    int32_t c_in0, c_in1;      /* multiples of 32; both sources carry hi + q planes (planes = DISCO_PLANE_Q) */
+    int32_t up0, up1;
+    int32_t sexp0, sexp1;      /* scale exponents of the sources' q planes */
+    int32_t c_out, stride;
+    int32_t act;
+    float slope;
+    int32_t out_planes;        /* DISCO_PLANE_* bits of the output buffer; ignored with out_f32 */
+    int32_t out_sexp;
+    int32_t out_f32;           /* 1: d_out is fp32 NCHW */
+    int32_t res_planes;        /* DISCO_PLANE_* bits of the residual buffer (its lo plane is used when present) */
+} disco_conv_mx_desc;
+/* d_packed == NULL: only *bytes.  d_wexp: device int32 [round_up(c_out, 32)], the per-output-channel weight scale exponents */
+int disco_op_conv3x3_mx_pack(const float *h_w_oihw, int c_out, int c_in, void *d_packed, int32_t *d_wexp, size_t *bytes);
+int disco_op_conv3x3_mx(const disco_conv_mx_desc *d, const void *d_src0, const void *d_src1, const void *d_packed_w,
+                        const int32_t *d_wexp, const float *d_bias, const float *d_bn_scale, const float *d_bn_shift,
+                        const void *d_res, void *d_out, uint32_t *d_sat, void *stream);
+
 /* Timing probe for disco_op_conv3x3 (tools/conv_timeline.py): d_buf = device buffer of 16*64*4 uint64 that workgroup 0
  * fills with s_memtime stamps per wave and chunk {before DMA wait, after it, after the barrier, after the last MFMA};
  * NULL switches it off. */

@@ -66,5 +66,76 @@ def conv3x3(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, ac
     return out
 
 
+# ---- the fp16 + fp8-correction conv (csrc/conv_mx.hip) ------------------------------------------------------------------
+def sexp_for(x, target_bits=5):
+    """Power-of-two scale exponent that maps max|x| into [2^(target_bits-1), 2^target_bits) (fp8 e4m3 tops out at 448)."""
+    import math
+    m = float(x.abs().max())
+    return 0 if m == 0 else target_bits - 1 - math.floor(math.log2(m))
+
+
+def act_bytes(n, c_pad, h, w, planes):
+    nb = C.c_size_t()
+    _ffi.check(_ffi.lib().disco_op_act_bytes(n, c_pad, h, w, planes, C.byref(nb)))
+    return nb.value
+
+
+class MxAct:
+    """A flat activation buffer of the mx path: hi plane [+ lo plane] [+ fp8 q planes] (include/disco_hip.h)."""
+
+    def __init__(self, n, c, h, w, planes, sexp=0, c_pad=None):
+        self.n, self.c, self.h, self.w, self.planes, self.sexp = n, c, h, w, planes, sexp
+        self.c_pad = c_pad or c
+        self.buf = torch.zeros(act_bytes(n, self.c_pad, h, w, planes), device=DEV, dtype=torch.uint8)
+
+    def read(self, which=0):
+        out = torch.empty(self.n, self.c, self.h, self.w, device=DEV, dtype=torch.float32)
+        _ffi.check(_ffi.lib().disco_op_act_mx_to_nchw(_ffi.ptr(self.buf), _ffi.ptr(out), self.n, self.c, self.h, self.w, self.c_pad,
+                                                     self.planes, self.sexp, which, stream()))
+        torch.cuda.synchronize()
+        return out
+
+
+def to_act_mx(x, planes=_ffi.PLANE_Q, sexp=None, c_pad=None):
+    x = x.to(DEV).float().contiguous()
+    n, c, h, w = x.shape
+    a = MxAct(n, c, h, w, planes, sexp_for(x) if sexp is None else sexp, c_pad)
+    _ffi.check(_ffi.lib().disco_op_nchw_to_act_mx(_ffi.ptr(x), _ffi.ptr(a.buf), n, c, h, w, a.c_pad, planes, a.sexp, stream()))
+    return a
+
+
+def pack_conv_mx(w):
+    w = w.detach().cpu().float().contiguous()
+    co, ci = w.shape[:2]
+    nbytes = C.c_size_t()
+    _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(None, co, ci, None, None, C.byref(nbytes)))
+    buf = torch.empty(nbytes.value, device=DEV, dtype=torch.uint8)
+    wexp = torch.empty((co + 31) // 32 * 32, device=DEV, dtype=torch.int32)
+    _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(_ffi.ptr(w), co, ci, _ffi.ptr(buf), _ffi.ptr(wexp), C.byref(nbytes)))
+    return buf, wexp
+
+
+def conv3x3_mx(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, act=_ffi.ACT_NONE, slope=0.0, bn_scale=None,
+               bn_shift=None, res=None, out_planes=_ffi.PLANE_LO, out_sexp=0, out_f32=False, packed=None):
+    """src*: MxAct with q planes; res: MxAct (hi [+ lo]).  Returns (MxAct | fp32 NCHW tensor, saturation count)."""
+    h_in, w_in = src0.h * (2 if up0 else 1), src0.w * (2 if up0 else 1)
+    co = w.shape[0]
+    buf, wexp = packed or pack_conv_mx(w)
+    ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
+    d = _ffi.ConvMxDesc(src0.n, h_in, w_in, src0.c_pad, src1.c_pad if src1 is not None else 0, int(up0), int(up1), src0.sexp,
+                        src1.sexp if src1 is not None else 0, co, stride, act, slope, out_planes, out_sexp, int(out_f32),
+                        res.planes if res is not None else 0)
+    out = torch.empty(src0.n, co, ho, wo, device=DEV, dtype=torch.float32) if out_f32 else MxAct(src0.n, co, ho, wo, out_planes, out_sexp)
+    sat = torch.zeros(1, device=DEV, dtype=torch.int32)
+    dv = lambda t: None if t is None else t.to(DEV).float().contiguous()
+    bias, bn_scale, bn_shift = dv(bias), dv(bn_scale), dv(bn_shift)
+    _ffi.check(_ffi.lib().disco_op_conv3x3_mx(C.byref(d), _ffi.ptr(src0.buf), _ffi.ptr(src1.buf) if src1 is not None else None,
+                                             _ffi.ptr(buf), _ffi.ptr(wexp), _ffi.ptr(bias), _ffi.ptr(bn_scale), _ffi.ptr(bn_shift),
+                                             _ffi.ptr(res.buf) if res is not None else None,
+                                             _ffi.ptr(out) if out_f32 else _ffi.ptr(out.buf), _ffi.ptr(sat), stream()))
+    torch.cuda.synchronize()
+    return out, int(sat.item())
+
+
 def max_err(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()

@@ -1,0 +1,126 @@
+"""-m gpu: the fp16 + fp8-correction conv kernel (csrc/conv_mx.hip) against torch (float64 reference of the same op).
+
+Tolerance: the two fp8 correction products leave a relative error of ~2^-16 of the accumulated |w||a| mass per output
+(tools/precision_sim.py); the checks below allow 1.5e-4 of the output range - two orders of magnitude tighter than plain
+fp16 operands (2e-2 in test_gpu_ops.py) and what the end-to-end 1e-3 bar on ab needs with margin."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from disentangledcolorization_amd import _ffi  # noqa: E402
+
+LO, Q = _ffi.PLANE_LO, _ffi.PLANE_Q
+TOL = 1.5e-4
+
+
+@pytest.fixture(scope="module")
+def H():
+    import gpu_helpers
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _ffi.lib()
+    return gpu_helpers
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _ref(x, w, b, stride, act, slope, bn, res):
+    y = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1)
+    if res is not None: y = y + res.double()
+    if act == _ffi.ACT_RELU: y = F.relu(y)
+    elif act == _ffi.ACT_LRELU: y = F.leaky_relu(y, slope)
+    elif act == _ffi.ACT_TANH: y = torch.tanh(y)
+    if bn is not None: y = y * bn[0].double()[None, :, None, None] + bn[1].double()[None, :, None, None]
+    return y
+
+
+def test_mx_layout_roundtrip(H):
+    """hi+lo carries ~22 bits; the a8 plane is x to 4 significant bits; hi + al8 is x to ~2^-15 relative."""
+    x = torch.randn(2, 64, 9, 11, generator=g(0)) * 3
+    a = H.to_act_mx(x, LO | Q)
+    assert H.max_err(a.read(0).cpu(), x) < 2e-7 * 16
+    a8 = a.read(1).cpu()
+    big = x.abs() > x.abs().max() * 2 ** -9                        # scaled values in the NORMAL fp8 range (>= 2^-6)
+    assert ((a8 - x).abs()[big] <= x.abs()[big] * 2 ** -4 + 1e-30).all()
+    assert H.max_err(a.read(2).cpu(), x) < x.abs().max().item() * 2 ** -15
+
+
+MX_CASES = [
+    # cin, cout, h, w, stride, act, slope, bn, res, out_planes
+    (64, 64, 32, 32, 1, _ffi.ACT_LRELU, 0.2, True, False, Q),
+    (32, 64, 24, 40, 1, _ffi.ACT_RELU, 0.0, True, False, LO | Q),
+    (64, 64, 16, 16, 1, _ffi.ACT_NONE, 0.0, False, True, LO),
+    (64, 128, 32, 64, 2, _ffi.ACT_LRELU, 0.2, True, False, Q),
+    (128, 256, 16, 16, 2, _ffi.ACT_RELU, 0.0, False, False, Q),
+    (256, 32, 8, 8, 1, _ffi.ACT_RELU, 0.0, False, True, LO | Q),
+    (96, 64, 17, 33, 1, _ffi.ACT_TANH, 0.0, False, False, LO),     # ragged: partial tiles, odd sizes
+    (512, 512, 8, 8, 1, _ffi.ACT_LRELU, 0.2, True, False, Q),
+    (64, 64, 64, 64, 1, _ffi.ACT_RELU, 0.0, False, False, Q),      # the 16x32-pixel tile with row reuse
+    (256, 256, 32, 32, 1, _ffi.ACT_RELU, 0.0, False, False, Q),
+]
+
+
+@pytest.mark.parametrize("case", MX_CASES)
+def test_conv3x3_mx_matches_torch(H, case):
+    cin, cout, h, w, stride, act, slope, use_bn, use_res, planes = case
+    gen = g(cin * 1000 + cout + h)
+    n = 3
+    x = torch.randn(n, cin, h, w, generator=gen)
+    if cin >= 128: x = F.relu(x)                                   # post-ReLU-like inputs for the deep layers
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    bn = (torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.1) if use_bn else None
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = torch.randn(n, cout, ho, wo, generator=gen) if use_res else None
+    want = _ref(x, wt, b, stride, act, slope, bn, res)
+    scale = max(1.0, want.abs().max().item())
+    osexp = H.sexp_for(want)
+    out, sat = H.conv3x3_mx(H.to_act_mx(x), wt, b, stride=stride, act=act, slope=slope, bn_scale=bn[0] if bn else None,
+                            bn_shift=bn[1] if bn else None, res=H.to_act_mx(res, LO) if use_res else None, out_planes=planes,
+                            out_sexp=osexp)
+    assert sat == 0
+    if planes & LO:
+        assert H.max_err(out.read(0), want) < TOL * scale
+    if planes & Q:
+        # hi + dequantised al8 reproduces the result to ~2^-15; a8 is the result to 4 significant bits
+        assert H.max_err(out.read(2), want) < (TOL + 2 ** -14) * scale
+        a8 = out.read(1).cpu().double()
+        big = want.abs() > scale * 2 ** -9
+        assert ((a8 - want).abs()[big] <= want.abs()[big] * 2 ** -3.9 + TOL * scale).all()
+    # fp32 NCHW output of the same layer
+    out32, _ = H.conv3x3_mx(H.to_act_mx(x), wt, b, stride=stride, act=act, slope=slope, bn_scale=bn[0] if bn else None,
+                            bn_shift=bn[1] if bn else None, out_f32=True) if not use_res else (None, 0)
+    if out32 is not None:
+        assert H.max_err(out32, want) < TOL * scale
+
+
+def test_conv3x3_mx_upsample_and_concat_on_read(H):
+    gen = g(5)
+    a = torch.randn(2, 64, 12, 20, generator=gen)      # half-resolution source, nearest x2 on read
+    s = torch.randn(2, 32, 24, 40, generator=gen) * 4  # full-resolution skip with its own scale
+    wt = torch.randn(64, 96, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * 96))
+    b = torch.randn(64, generator=gen) * 0.1
+    up = a.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    want = _ref(torch.cat((up, s), 1), wt, b, 1, _ffi.ACT_RELU, 0.0, None, None)
+    out, sat = H.conv3x3_mx(H.to_act_mx(a), wt, b, src1=H.to_act_mx(s), up0=True, act=_ffi.ACT_RELU, out_planes=LO)
+    assert sat == 0 and H.max_err(out.read(0), want) < TOL * max(1.0, want.abs().max().item())
+
+
+def test_conv3x3_mx_saturation_counter(H):
+    """An output scale that is far too large must be reported, not silently clamped."""
+    gen = g(9)
+    x = torch.randn(1, 32, 16, 16, generator=gen)
+    wt = torch.randn(32, 32, 3, 3, generator=gen) * 0.1
+    out, sat = H.conv3x3_mx(H.to_act_mx(x), wt, torch.zeros(32), out_planes=Q, out_sexp=12)
+    assert sat > 0
+
+
+def test_conv3x3_mx_rejects_bad_shapes(H):
+    x = torch.randn(1, 48, 8, 8)
+    with pytest.raises(_ffi.DiscoError):
+        H.conv3x3_mx(H.to_act_mx(x, c_pad=64), torch.randn(16, 48, 3, 3), torch.zeros(16), out_planes=Q)   # 16 output channels cannot carry q planes
