@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DISCO_HIP_LIB") or os.path.join(_HERE, "libdisco_hip.
 
 OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
-PREC_F16X3, PREC_F16X1 = 0, 1
+PREC_F16X3, PREC_F16X1, PREC_MX8 = 0, 1, 2
 PLANE_LO, PLANE_Q = 1, 2
 
 
@@ -68,6 +68,9 @@ SIGNATURES = {
     "disco_expected_tensor": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(_I)]),
     "disco_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "disco_forward": (_I, [_P, C.POINTER(ForwardArgs)]),
+    "disco_saturation_count": (_I, [_P, _P, C.POINTER(C.c_uint64)]),
+    "disco_calibration_count": (_I, [_P]),
+    "disco_calibration_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
     "disco_forward_segnet": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "disco_sync": (_I, [_P]),
     "disco_set_profiling": (_I, [_P, _I]),

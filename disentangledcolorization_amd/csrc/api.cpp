@@ -116,6 +116,11 @@ struct ConvLayer {
     int c_in = 0, c_in_pad = 0, c_out = 0;
     int kind = 0;                 // 0 plain 3x3, 1 ConvTranspose 4x4 s2 as 4-phase conv, 2 upsample+3x3 as 4-phase conv
     bool s2d = false;             // stride-2 layer: weights packed for the space-to-depth view of the input
+    bool mx = false;              // packed for conv3x3_mx_kernel (fp16 main product + fp8 corrections)
+    int c_out_k = 0;              // mx: output channels the kernel computes (c_out padded with zero weights so that act
+                                  // outputs carry whole 32-channel blocks; per phase for the depth-to-space kinds)
+    int c_real = 0;               // real (reference) output channels, per phase for kinds 1 and 2: FLOP accounting
+    int32_t* d_wexp = nullptr;    // mx: per-output-channel scale exponents of the fp8 weight planes
     f16* d_w = nullptr;
     uint32_t* d_tapmask = nullptr;
     float* d_bias = nullptr;
@@ -171,6 +176,10 @@ struct disco_ctx {
     std::vector<void*> allocs;
     std::map<std::string, ConvLayer> conv;
     std::map<std::string, DirectLayer> direct;
+    std::map<std::string, int> sexp;     // mx: scale exponent of the q planes of every tensor, by producer (set by calibration)
+    std::map<std::string, float> amax;   // calibration: max |x| of every conv output (fp16 range guard, diagnostics)
+    unsigned int* d_sat = nullptr;       // mx: q-plane elements that had to be clamped since the last read
+    bool calibrated = false;
     float* d_enc[2] = {nullptr, nullptr};
     float* d_mid_w = nullptr; float* d_emb_w = nullptr; float* d_trg_w = nullptr; float* d_q_to_ab = nullptr;
     std::map<std::pair<int, int>, float*> pos_cache;
@@ -258,10 +267,35 @@ void bn_affine(disco_ctx* c, const std::string& key, std::vector<float>& scale, 
     }
 }
 
+bool use_mx(const disco_ctx* c) { return c->opt.precision == DISCO_PREC_MX8; }
+int pad_cout_mx(int co) { return co <= 32 ? 32 : round_up(co, 64); }
+
+// upload bias / BN affine padded to `n` channels (bias 0, scale 1, shift 0 beyond the real ones)
+int upload_padded(disco_ctx* c, std::vector<float> v, size_t n, float fill, float** out) {
+    v.resize(std::max(v.size(), n), fill);
+    return upload_vec(c, v, out);
+}
+
+// Pack and upload the weights of an mx layer.  w: (co, ci, 3, 3) effective weights; ci_map / c_in_pad describe the packed
+// input channels (multiples of 32 per source); act_out: the layer writes an activation tensor, so its output channels are
+// padded to whole blocks with zero weights (fp32 NCHW outputs keep their real channel count).
+int finish_mx(disco_ctx* c, ConvLayer& L, const std::vector<float>& w, int co, int ci, const int* ci_map, int c_in_pad, bool act_out) {
+    L.mx = true; L.c_in = ci; L.c_in_pad = c_in_pad;
+    L.c_out_k = act_out ? pad_cout_mx(co) : co;
+    std::vector<char> packed(conv_mx_packed_bytes(L.c_out_k, c_in_pad));
+    std::vector<int32_t> wexp((size_t)round_up(L.c_out_k, 32));
+    conv_mx_pack_host(w.data(), co, ci, ci_map, c_in_pad, packed.data(), wexp.data());     // rows >= co pack as zeros
+    int rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w);
+    if (rc) return rc;
+    return upload_vec(c, wexp, &L.d_wexp);
+}
+
 // Build one MFMA conv layer.  fold_bn: BN directly after the conv (SpixelNet, network.py:240-246) is folded into
 // weights+bias; post_bn: BN after the activation (ColorProbNet / HourGlass2 blocks) becomes the epilogue affine.
+// ci_map / c_in_pad_override describe the packed input channels when they are not simply the reference's (concat of padded
+// sources, permuted inputs); act_out = false for layers whose only output is fp32 NCHW (pred_mask0, outConv).
 int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, const std::string& post_bn,
-              const std::vector<int>* ci_map = nullptr, int c_in_pad_override = 0, bool stride2 = false) {
+              const std::vector<int>* ci_map = nullptr, int c_in_pad_override = 0, bool stride2 = false, bool act_out = true) {
     std::vector<float> w = eff_weight(c, key);
     const HostTensor& ws = c->sd.count(key + ".weight") ? T(c, key + ".weight") : T(c, key + ".weight_orig");
     const int co = (int)ws.shape[0], ci = (int)ws.shape[1];
@@ -276,7 +310,21 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
         }
     }
     ConvLayer L;
-    L.c_in = ci; L.c_out = co;
+    L.c_in = ci; L.c_out = co; L.c_real = co;
+    int rc;
+    if (use_mx(c)) {
+        const int cpad = c_in_pad_override ? c_in_pad_override : round_up(ci, 32);
+        if ((rc = finish_mx(c, L, w, co, ci, ci_map ? ci_map->data() : nullptr, cpad, act_out))) return rc;
+        if ((rc = upload_padded(c, bias, (size_t)L.c_out_k, 0.f, &L.d_bias))) return rc;
+        if (!post_bn.empty()) {
+            std::vector<float> sc, sh;
+            bn_affine(c, post_bn, sc, sh);
+            if ((rc = upload_padded(c, sc, (size_t)L.c_out_k, 1.f, &L.d_bn_scale))) return rc;
+            if ((rc = upload_padded(c, sh, (size_t)L.c_out_k, 0.f, &L.d_bn_shift))) return rc;
+        }
+        c->conv[key] = L;
+        return DISCO_OK;
+    }
     L.c_in_pad = c_in_pad_override ? c_in_pad_override : round_up(ci, 16);
     std::vector<char> packed;
     // Measured on MI355X (profiles/r01_conv_s2d_timeline.txt): the space-to-depth path has the stride-1 LDS footprint and
@@ -295,7 +343,7 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
         packed.resize(conv3x3_packed_bytes(co, L.c_in_pad));
         conv3x3_pack_host(w.data(), co, ci, ci_map ? ci_map->data() : nullptr, L.c_in_pad, packed.data());
     }
-    int rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w);
+    rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w);
     if (rc) return rc;
     if ((rc = upload_vec(c, bias, &L.d_bias))) return rc;
     if (!post_bn.empty()) {
@@ -327,6 +375,25 @@ int make_c1(disco_ctx* c, const std::string& key, const std::string& fold_bn) {
 }
 
 
+// 4-phase weights (4*co, ci, 3, 3), phase-major, of a depth-to-space layer -> the mx layer: every phase padded to whole
+// 32-channel blocks (zero weights), bias repeated per phase by the kernel (parameters are indexed modulo the phase size)
+int finish_phase_mx(disco_ctx* c, ConvLayer& L, const std::vector<float>& w4, int co, int ci, const std::vector<float>& bias) {
+    const int cop = round_up(co, 32);
+    std::vector<float> wp((size_t)4 * cop * ci * 9, 0.f);
+    for (int ph = 0; ph < 4; ++ph)
+        for (int o = 0; o < co; ++o)
+            std::copy(w4.begin() + ((size_t)(ph * co + o)) * ci * 9, w4.begin() + ((size_t)(ph * co + o) + 1) * ci * 9,
+                      wp.begin() + ((size_t)(ph * cop + o)) * ci * 9);
+    int rc = finish_mx(c, L, wp, 4 * cop, ci, nullptr, round_up(ci, 32), true);
+    if (rc) return rc;
+    L.c_out = 4 * cop; L.c_real = co;
+    std::vector<uint32_t> mask(cdiv(L.c_out_k, 32));
+    conv3x3_tapmask_host(wp.data(), 4 * cop, ci, mask.data());
+    mask.resize(cdiv(L.c_out_k, 32), 0u);
+    if ((rc = upload_vec(c, mask, &L.d_tapmask))) return rc;
+    return upload_padded(c, bias, (size_t)cop, 0.f, &L.d_bias);
+}
+
 // ConvTranspose2d(4,s2,p1) as a 4-phase 3x3 conv on the MFMA kernel with a depth-to-space epilogue
 int make_deconv(disco_ctx* c, const std::string& key) {
     const HostTensor& ws = T(c, key + ".weight");
@@ -334,10 +401,16 @@ int make_deconv(disco_ctx* c, const std::string& key) {
     std::vector<float> w3((size_t)4 * co * ci * 9);
     deconv_as_conv3x3_host(ws.data.data(), ci, co, w3.data());
     ConvLayer L;
-    L.c_in = ci; L.c_out = 4 * co; L.c_in_pad = round_up(ci, 16); L.kind = 1;
+    L.c_in = ci; L.c_out = 4 * co; L.c_real = co; L.c_in_pad = round_up(ci, 16); L.kind = 1;
+    int rc;
+    if (use_mx(c)) {
+        if ((rc = finish_phase_mx(c, L, w3, co, ci, T(c, key + ".bias").data))) return rc;
+        c->conv[key] = L;
+        return DISCO_OK;
+    }
     std::vector<char> packed(conv3x3_packed_bytes(L.c_out, L.c_in_pad));
     conv3x3_pack_host(w3.data(), L.c_out, ci, nullptr, L.c_in_pad, packed.data());
-    int rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w); if (rc) return rc;
+    rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w); if (rc) return rc;
     std::vector<uint32_t> mask(cdiv(L.c_out, 32));
     conv3x3_tapmask_host(w3.data(), L.c_out, ci, mask.data());
     if ((rc = upload_vec(c, mask, &L.d_tapmask))) return rc;
@@ -354,10 +427,16 @@ int make_upconv(disco_ctx* c, const std::string& key) {
     std::vector<float> w4((size_t)4 * co * ci * 9);
     upconv_as_conv3x3_host(ws.data.data(), ci, co, w4.data());
     ConvLayer L;
-    L.c_in = ci; L.c_out = 4 * co; L.c_in_pad = round_up(ci, 16); L.kind = 2;
+    L.c_in = ci; L.c_out = 4 * co; L.c_real = co; L.c_in_pad = round_up(ci, 16); L.kind = 2;
+    int rc;
+    if (use_mx(c)) {
+        if ((rc = finish_phase_mx(c, L, w4, co, ci, T(c, key + ".bias").data))) return rc;
+        c->conv[key] = L;
+        return DISCO_OK;
+    }
     std::vector<char> packed(conv3x3_packed_bytes(L.c_out, L.c_in_pad));
     conv3x3_pack_host(w4.data(), L.c_out, ci, nullptr, L.c_in_pad, packed.data());
-    int rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w); if (rc) return rc;
+    rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w); if (rc) return rc;
     std::vector<uint32_t> mask(cdiv(L.c_out, 32));
     conv3x3_tapmask_host(w4.data(), L.c_out, ci, mask.data());
     if ((rc = upload_vec(c, mask, &L.d_tapmask))) return rc;
@@ -402,6 +481,7 @@ struct Plan {
     const disco_forward_args* a;
     Arena arena;
     bool dry;            // size pass: no launches
+    bool calib = false;  // calibration pass of disco_finalize: measures activation ranges, fixes the q-plane scales
     hipStream_t s;
     char* base;
     int rc = DISCO_OK;
@@ -417,8 +497,16 @@ struct Plan {
         return dry ? (void*)(uintptr_t)(off + 256) : (void*)(base + off);   // dry: fake non-null token
     }
     void drop(void* p) { if (p) arena.release(dry ? (size_t)(uintptr_t)p - 256 : (size_t)((char*)p - base)); }
-    Act act(int n, int h, int w, int ch) {
-        Act t; t.n = n; t.h = h; t.w = w; t.c = ch; t.plane = (size_t)n * h * w * ch;
+    // planes of an activation tensor: F_LO = fp16 lo plane, F_Q = fp8 q planes (scale exponent of producer `key`)
+    enum { F_LO = 1, F_Q = 2 };
+    bool mx() const { return use_mx(c); }
+    int cpad(int ch) const { return round_up(ch, mx() ? 32 : 16); }
+    int dfmt() const { return mx() ? (int)F_Q : (int)F_LO; }          // what a conv -> conv tensor carries
+    Act act(int n, int h, int w, int ch, int fmt) {
+        Act t; t.n = n; t.h = h; t.w = w; t.c = ch;
+        const size_t el = t.elems();
+        t.plane = (fmt & F_LO) ? el : 0;
+        t.q_off = (fmt & F_Q) ? el * 2 * ((fmt & F_LO) ? 2 : 1) : 0;
         t.p = (f16*)raw(t.bytes());
         return t;
     }
@@ -430,60 +518,127 @@ struct Plan {
         hipEventRecord(ev, s);
         c->prof.push_back({name, ev, flops});
     }
+    // scale exponent of the q planes of the tensor produced by `key` (fixed by the calibration pass of disco_finalize)
+    bool scale_of(const std::string& key, int* sexp) {
+        auto it = c->sexp.find(key);
+        if (it == c->sexp.end()) {
+            if (calib) { *sexp = 0; return true; }
+            set_error("no calibrated scale for the output of %s", key.c_str()); rc = DISCO_ESTATE; return false;
+        }
+        *sexp = it->second;
+        return true;
+    }
+    // Calibration (disco_finalize): `produce` has just written tensor `t` with a provisional q scale; measure max |x| of its
+    // hi plane, fix the scale so that the maximum lands in [16, 32) of fp8's +-448 range (2^4 of headroom for other inputs,
+    // 2^-13 of the maximum still representable), and run the producer again with the final scale.
+    template <class F>
+    void calibrate(const std::string& key, Act& t, F&& produce) {
+        if (!calib || dry || !ok()) return;
+        float* d_amax = (float*)raw(256);
+        float amax = 0.f;
+        if (!ok()) return;
+        if (hipMemsetAsync(d_amax, 0, 4, s) != hipSuccess) { rc = DISCO_EHIP; return; }
+        rc = launch_act_amax(t, d_amax, s);
+        if (ok() && (hipMemcpyAsync(&amax, d_amax, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = hip_fail(hipGetLastError(), "calibration amax");
+        drop(d_amax);
+        if (!ok()) return;
+        c->amax[key] = amax;
+        if (!(amax <= 16384.f)) {     // also catches NaN
+            set_error("activation range of %s (max |x| = %g) leaves no fp16 headroom: this checkpoint cannot run in fp16 hi/lo arithmetic", key.c_str(), (double)amax);
+            rc = DISCO_EUNSUPPORTED; return;
+        }
+        int e = 0;
+        if (amax > 0.f) { std::frexp(amax, &e); e = 5 - e; }        // amax 2^e in [16, 32)
+        c->sexp[key] = e;
+        if (t.q_off) { t.sexp = e; produce(); }
+    }
 
-    // MFMA conv: out = bn(act(conv(cat(in0[,in1])) + bias [+ res]))
+    // MFMA conv: out = bn(act(conv(cat(in0[,in1])) + bias [+ res]));  ofmt: planes of the output tensor (-1: the default)
     Act conv(const std::string& key, const Act& in0, const Act* in1, int up0, int up1, int stride, int actc, float slope,
-             const Act* res = nullptr, float* out_f32 = nullptr, bool d2s = false, bool softmax = false) {
+             const Act* res = nullptr, float* out_f32 = nullptr, bool d2s = false, bool softmax = false, int ofmt = -1) {
         const ConvLayer& L = c->conv.at(key);
         const int hin = in0.h << up0, win = in0.w << up0;
         const int ho = (hin - 1) / stride + 1, wo = (win - 1) / stride + 1;
+        if (ofmt < 0) ofmt = dfmt();
+        const int co_t = L.mx ? L.c_out_k : L.c_out;                 // channels the kernel computes
         Act out{};
-        if (d2s) out = act(in0.n, 2 * ho, 2 * wo, L.c_out / 4);
-        else if (!out_f32) out = act(in0.n, ho, wo, L.c_out);
+        if (d2s) out = act(in0.n, 2 * ho, 2 * wo, co_t / 4, ofmt);
+        else if (!out_f32) out = act(in0.n, ho, wo, co_t, ofmt);
         if (dry || !ok()) return out;
-        ConvArgs ca{};
-        ca.src[0] = {in0.p, (long)in0.plane, in0.c, in0.h, in0.w, up0};
-        ca.nsrc = 1;
-        if (in1) { ca.src[1] = {in1->p, (long)in1->plane, in1->c, in1->h, in1->w, up1}; ca.nsrc = 2; }
-        ca.n = in0.n; ca.h_in = hin; ca.w_in = win; ca.c_in = L.c_in_pad;
-        if (L.s2d) {
-            if (stride != 2 || in1 || up0 || (hin & 1) || (win & 1)) { set_error("conv %s: packed for stride 2 on an even-sized plain source", key.c_str()); rc = DISCO_ESHAPE; return out; }
-            ca.s2d = 1; ca.c_in = 4 * L.c_in_pad;
-        }
-        ca.h_out = ho; ca.w_out = wo; ca.stride = stride;
-        ca.w = L.d_w; ca.tapmask = L.d_tapmask; ca.c_out = L.c_out; ca.c_out_pad = L.c_out;
-        ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
-        ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
-        ca.out = out.p; ca.out_plane = (long)out.plane;
-        ca.out_f32 = out_f32; ca.d2s_c = d2s ? L.c_out / 4 : 0; ca.softmax = softmax ? 1 : 0;
-        ca.act = actc; ca.slope = slope; ca.precision = c->opt.precision;
         if (in0.c + (in1 ? in1->c : 0) != L.c_in_pad) { set_error("conv %s: input channels %d != %d", key.c_str(), in0.c + (in1 ? in1->c : 0), L.c_in_pad); rc = DISCO_ESHAPE; return out; }
+        if (!out_f32 && (ofmt & F_Q) && !scale_of(key, &out.sexp)) return out;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = c->profiling >= 2 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        const bool timed = c->profiling >= 2 && !calib && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
         if (timed) hipEventRecord(e0, s);
-        rc = run_conv(ca, s);
+        if (L.mx) {
+            auto launch = [&]() {
+                ConvMxArgs ca{};
+                const Act* src[2] = {&in0, in1};
+                const int ups[2] = {up0, up1};
+                ca.nsrc = in1 ? 2 : 1;
+                for (int i = 0; i < ca.nsrc; ++i) {
+                    if (!src[i]->q_off || src[i]->q_off >= ((size_t)1 << 32)) { set_error("conv %s: source %d has no (addressable) q planes", key.c_str(), i); rc = DISCO_ESHAPE; return; }
+                    ca.src[i] = {src[i]->p, (uint32_t)src[i]->q_off, src[i]->c, src[i]->h, src[i]->w, ups[i], src[i]->sexp};
+                }
+                ca.n = in0.n; ca.h_in = hin; ca.w_in = win; ca.c_in = L.c_in_pad;
+                ca.h_out = ho; ca.w_out = wo; ca.stride = stride;
+                ca.w = L.d_w; ca.wexp = L.d_wexp; ca.tapmask = L.d_tapmask; ca.c_out = co_t; ca.c_out_pad = co_t;
+                ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
+                ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
+                ca.out = out.p; ca.out_plane = (long)out.plane; ca.out_q_off = out.q_off; ca.out_sexp = out.sexp;
+                ca.out_f32 = out_f32; ca.d2s_c = d2s ? co_t / 4 : 0; ca.softmax = softmax ? 1 : 0;
+                ca.act = actc; ca.slope = slope; ca.sat = calib ? nullptr : c->d_sat;
+                rc = launch_conv3x3_mx(ca, s);
+            };
+            launch();
+            if (!out_f32) calibrate(key, out, launch);
+        } else {
+            ConvArgs ca{};
+            if (!in0.plane || (in1 && !in1->plane) || (res && !res->plane) || (!out_f32 && !out.plane)) { set_error("conv %s: the f16x3 kernel needs lo planes", key.c_str()); rc = DISCO_ESHAPE; return out; }
+            ca.src[0] = {in0.p, (long)in0.plane, in0.c, in0.h, in0.w, up0};
+            ca.nsrc = 1;
+            if (in1) { ca.src[1] = {in1->p, (long)in1->plane, in1->c, in1->h, in1->w, up1}; ca.nsrc = 2; }
+            ca.n = in0.n; ca.h_in = hin; ca.w_in = win; ca.c_in = L.c_in_pad;
+            if (L.s2d) {
+                if (stride != 2 || in1 || up0 || (hin & 1) || (win & 1)) { set_error("conv %s: packed for stride 2 on an even-sized plain source", key.c_str()); rc = DISCO_ESHAPE; return out; }
+                ca.s2d = 1; ca.c_in = 4 * L.c_in_pad;
+            }
+            ca.h_out = ho; ca.w_out = wo; ca.stride = stride;
+            ca.w = L.d_w; ca.tapmask = L.d_tapmask; ca.c_out = L.c_out; ca.c_out_pad = L.c_out;
+            ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
+            ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
+            ca.out = out.p; ca.out_plane = (long)out.plane;
+            ca.out_f32 = out_f32; ca.d2s_c = d2s ? L.c_out / 4 : 0; ca.softmax = softmax ? 1 : 0;
+            ca.act = actc; ca.slope = slope; ca.precision = c->opt.precision;
+            rc = run_conv(ca, s);
+        }
         if (timed) {
             hipEventRecord(e1, s);
-            // algorithmic FLOPs: a ConvTranspose 4x4 s2 has 16 (not 36) taps per (ci,co) and input pixel
-            // (the reference's dense count: 16 taps for the transposed conv, 9 taps on the UPSAMPLED grid for up-convs)
-            const double taps = L.kind == 1 ? 16.0 * (L.c_out / 4) : (L.kind == 2 ? 9.0 * L.c_out : 9.0 * L.c_out);
-            // compulsory HBM bytes: every source read once, the output written once (hi + lo fp16 planes = 4 B per
-            // element; fp32 NCHW output 4 B), the residual read once, the packed weights once
+            // algorithmic FLOPs (the reference's dense count on its real channels): 16 taps for a ConvTranspose 4x4 s2 and 9 taps
+            // on the UPSAMPLED grid for up-convs, per input pixel of this launch; 9 taps per output pixel otherwise
+            const double taps = L.kind == 1 ? 16.0 * L.c_real : (L.kind == 2 ? 36.0 * L.c_real : 9.0 * L.c_real);
+            // compulsory HBM bytes: every source plane the kernel reads once (4 B per element: hi + lo, or hi + two fp8 planes), every
+            // output plane written once, the residual read once, the packed weights once
+            const double bpe_out = out_f32 ? 4.0 : 2.0 * (1 + ((ofmt & F_LO) ? 1 : 0) + ((ofmt & F_Q) ? 1 : 0));
             double bytes = 4.0 * in0.n * ((double)in0.c * in0.h * in0.w + (in1 ? (double)in1->c * in1->h * in1->w : 0.0));
-            bytes += 4.0 * in0.n * (double)(d2s ? L.c_out / 4 * 4 : L.c_out) * ho * wo * (res ? 2.0 : 1.0);
-            bytes += (double)conv3x3_packed_bytes(L.c_out, L.s2d ? 4 * L.c_in_pad : L.c_in_pad);
+            bytes += bpe_out * in0.n * (double)(out_f32 ? L.c_real : co_t) * ho * wo;
+            if (res) bytes += 4.0 * in0.n * (double)co_t * ho * wo;
+            bytes += L.mx ? (double)conv_mx_packed_bytes(co_t, L.c_in_pad) : (double)conv3x3_packed_bytes(L.c_out, L.s2d ? 4 * L.c_in_pad : L.c_in_pad);
             c->conv_prof.push_back({e0, e1, 2.0 * taps * L.c_in * (double)ho * wo * in0.n, key, bytes});
         }
         return out;
     }
-    Act deconv(const std::string& key, const Act& in, float slope) {
-        return conv(key, in, nullptr, 0, 0, 1, DISCO_ACT_LRELU, slope, nullptr, nullptr, true);
+    Act deconv(const std::string& key, const Act& in, float slope, int ofmt = -1) {
+        return conv(key, in, nullptr, 0, 0, 1, DISCO_ACT_LRELU, slope, nullptr, nullptr, true, false, ofmt);
     }
     Act c1(const std::string& key, const float* gray, int n, int h, int w, int actc, float slope) {
         const DirectLayer& L = c->direct.at(key);
-        Act out = act(n, h, w, L.c_out);
+        Act out = act(n, h, w, cpad(L.c_out), dfmt());
         if (dry || !ok()) return out;
-        rc = launch_conv_c1(gray, L.d_w, L.d_bias, nullptr, nullptr, out.p, (long)out.plane, n, h, w, L.c_out, actc, slope, s);
+        if (out.q_off && !scale_of(key, &out.sexp)) return out;
+        auto launch = [&]() { rc = launch_conv_c1(gray, L.d_w, L.d_bias, nullptr, nullptr, out, L.c_out, actc, slope, calib ? nullptr : c->d_sat, s); };
+        launch();
+        calibrate(key, out, launch);
         return out;
     }
 };
@@ -518,8 +673,10 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
     P.drop(cc);
 }
 
-int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, size_t* peak) {
+int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, size_t* peak, bool calib = false) {
     Plan P(c, a, cap, dry);
+    P.calib = calib;
+    if (!dry && !calib && use_mx(c) && !c->calibrated) { set_error("mx context used before its calibration pass"); return DISCO_ESTATE; }
     const int n = a->n, H = a->h, W = a->w, sp = c->opt.sp_size, K = c->opt.n_clusters;
     const int hs = H / sp, ws = W / sp, L = hs * ws;
     const bool test = a->test_mode != 0, h2r = c->opt.hint2regress != 0, spos = c->opt.spix_pos != 0;
@@ -551,7 +708,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
         f = P.conv(k + ".4", x2, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(x2);
         if (b == 1) f3 = f;
     }
-    Act sh = P.conv(rp + "conv3short8.0", f3, nullptr, 0, 0, 1, NOACT, 0.f);
+    Act sh = P.conv(rp + "conv3short8.0", f3, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, Plan::F_LO);   // residual only
     P.drop(f3);
     Act f8 = P.conv(rp + "conv8up.1", f, nullptr, 0, 0, 1, RELU, 0.f, &sh, nullptr, true); P.drop(sh); P.drop(f);
     t = P.conv(rp + "conv8_3.1", f8, nullptr, 0, 0, 1, RELU, 0.f); P.drop(f8);
@@ -559,7 +716,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     t = P.conv(rp + "conv9up.1", f8, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, true); P.drop(f8);
     Act f9 = P.conv(rp + "conv9_2.0", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
     t = P.conv(rp + "conv10up.1", f9, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, true); P.drop(f9);
-    Act feats = P.conv(rp + "conv10_2.1", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
+    Act feats = P.conv(rp + "conv10_2.1", t, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, false, false, Plan::F_LO); P.drop(t);   // pooled, not convolved
     P.mark("repnet", 2.0 * 68.8914e9 * px / 65536.0);
 
     // ---- a3-a5 tokens, colours, sizes (model.py:114-121) ------------------------------------------------------
@@ -645,10 +802,16 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     P.mark("hintpath", 2.0 * 0.134e9 * n2);
 
     // ---- a12 upfeat + a13 HourGlass2 + tanh (model.py:194-197) --------------------------------------------------
-    Act full = P.act(n2, H, W, 64);
-    Act g16 = P.act(n2, H, W, 16);
-    if (!dry && P.ok()) P.rc = launch_upfeat(dec, 1, a->d_affinity, rep, full.p, (long)full.plane, nullptr, n2, 64, hs, ws, sp, s);
-    if (!dry && P.ok()) P.rc = launch_gray16(a->d_gray, rep, g16.p, (long)g16.plane, n2, H, W, s);
+    Act full = P.act(n2, H, W, 64, P.dfmt());
+    Act g16 = P.act(n2, H, W, P.cpad(16), P.dfmt());
+    if (!dry && P.ok() && full.q_off && P.scale_of("upfeat", &full.sexp) && P.scale_of("gray16", &g16.sexp)) {}
+    {
+        unsigned int* sat = calib ? nullptr : c->d_sat;
+        auto up = [&]() { P.rc = launch_upfeat(dec, 1, a->d_affinity, rep, &full, nullptr, n2, 64, hs, ws, sp, sat, s); };
+        auto gr = [&]() { P.rc = launch_gray16(a->d_gray, rep, g16, sat, s); };
+        if (!dry && P.ok()) { up(); P.calibrate("upfeat", full, up); }
+        if (!dry && P.ok()) { gr(); P.calibrate("gray16", g16, gr); }
+    }
     P.drop(dec);
     P.mark("upfeat");
     const std::string en = "enhanceNet.";
@@ -657,12 +820,13 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     t = P.conv(en + "down1.conv.0", e1, nullptr, 0, 0, 2, RELU, 0.f);
     Act e2 = P.conv(en + "down1.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
     t = P.conv(en + "down2.conv.0", e2, nullptr, 0, 0, 2, RELU, 0.f);
-    Act x = P.conv(en + "down2.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
+    const int rfmt = P.mx() ? (Plan::F_LO | Plan::F_Q) : Plan::F_LO;      // residual-chain tensors: convolved AND added back
+    Act x = P.conv(en + "down2.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, false, false, rfmt); P.drop(t);
     for (int r = 0; r < 3; ++r) {
         const std::string k = en + "residual." + std::to_string(r) + ".conv.";
         Act t1 = P.conv(k + "0", x, nullptr, 0, 0, 1, NOACT, 0.f);
         Act t2 = P.conv(k + "1", t1, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t1);
-        Act y = P.conv(k + "3", t2, nullptr, 0, 0, 1, RELU, 0.f, &x); P.drop(t2); P.drop(x);
+        Act y = P.conv(k + "3", t2, nullptr, 0, 0, 1, RELU, 0.f, &x, nullptr, false, false, rfmt); P.drop(t2); P.drop(x);
         x = y;
     }
     t = P.conv(en + "up2.conv1", x, nullptr, 0, 0, 1, NOACT, 0.f); P.drop(x);
@@ -687,6 +851,60 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     P.drop(d_info);
     if (peak) *peak = P.arena.peak;
     return P.rc;
+}
+
+void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int W, float* d_affinity);
+
+// The calibration pass of an mx context (end of disco_finalize): one forward over two synthetic 256x256 images - uniform noise
+// and a smooth low-frequency pattern - in which every producer of an fp8-carrying tensor runs twice: once to measure the
+// tensor's max |x|, once more with the power-of-two scale that measurement fixes (Plan::calibrate).  The scales are
+// properties of the checkpoint from then on (deterministic: the inputs are generated here); q-plane clamping at run time is
+// counted (disco_saturation_count) so that inputs far outside the calibrated range are noticed.
+int calibrate_ctx(disco_ctx* c) {
+    if (!use_mx(c)) { c->calibrated = true; return DISCO_OK; }
+    const int n = 2, H = 256, W = 256, K = c->opt.n_clusters, L = (H / 16) * (W / 16);
+    std::vector<float> g((size_t)n * H * W);
+    unsigned st = 20240607u;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            st = st * 1664525u + 1013904223u;
+            const float u = (st >> 8) * (1.f / 16777216.f);
+            g[(size_t)y * W + x] = 2.f * u - 1.f;
+            g[(size_t)H * W + (size_t)y * W + x] = 0.8f * std::sin(x * (1.f / 9.f)) * std::cos(y * (1.f / 13.f)) + 0.1f * (2.f * u - 1.f);
+        }
+    std::vector<int32_t> idx((size_t)n * K);
+    for (int i = 0; i < n; ++i) for (int k = 0; k < K; ++k) idx[(size_t)i * K + k] = (k * 7 + i) % L;
+    disco_forward_args a{};
+    a.n = n; a.h = H; a.w = W; a.sampled_T = 0; a.test_mode = 1;
+    a.h_init_idx = idx.data(); a.h_hint_pos = idx.data();
+    const bool seg = c->opt.segnet_only != 0;
+    size_t peak = 0;
+    int rc;
+    if (seg) { Plan P(c, &a, (size_t)1 << 46, true); segnet_stage(P, c, nullptr, n, H, W, nullptr); peak = P.arena.peak; rc = P.rc; }
+    else rc = run_plan(c, &a, (size_t)1 << 46, true, &peak);
+    if (rc) return rc;
+    peak += (size_t)1 << 20;
+    const size_t px = (size_t)n * H * W, lt = (size_t)n * L;
+    const size_t outs[7] = {px * 4, px * 2 * 4, lt * 313 * 4, lt * 313 * 4, px * 2 * 4, px * 9 * 4, lt * 2 * 4 + lt * 4};
+    void* bufs[8] = {};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 7 && e == hipSuccess; ++i) e = hipMalloc(&bufs[i], outs[i]);
+    if (e == hipSuccess) e = hipMalloc(&bufs[7], peak);
+    if (e == hipSuccess) e = hipMemcpy(bufs[0], g.data(), px * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(bufs[1], 0, px * 2 * 4);
+    if (e != hipSuccess) rc = hip_fail(e, "calibration buffers");
+    if (!rc) {
+        a.d_gray = (const float*)bufs[0]; a.d_ab = (const float*)bufs[1];
+        a.d_pal_logit = (float*)bufs[2]; a.d_ref_logit = (float*)bufs[3]; a.d_pred_colors = (float*)bufs[4];
+        a.d_affinity = (float*)bufs[5]; a.d_spix_colors = (float*)bufs[6]; a.d_hint_mask = (float*)bufs[6] + lt * 2;
+        a.d_workspace = bufs[7]; a.workspace_bytes = peak; a.stream = nullptr;
+        if (seg) { Plan P(c, &a, peak, false); P.calib = true; segnet_stage(P, c, a.d_gray, n, H, W, a.d_affinity); rc = P.rc; }
+        else rc = run_plan(c, &a, peak, false, nullptr, true);
+        if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) rc = hip_fail(hipGetLastError(), "calibration forward");
+    }
+    for (void* b : bufs) if (b) hipFree(b);
+    if (!rc) c->calibrated = true;
+    return rc;
 }
 
 int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
@@ -740,7 +958,7 @@ int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (!opt || !out) { set_error("null argument"); return DISCO_EINVAL; }
     if (opt->sp_size != 16) { set_error("sp_size %d unsupported (16 only, inference.py:146)", opt->sp_size); return DISCO_EUNSUPPORTED; }
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
-    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_F16X1) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
+    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_F16X1 && opt->precision != DISCO_PREC_MX8) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
     if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }
     if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("segnet_only context takes no colorizer flags"); return DISCO_EINVAL; }
     int ndev = 0;
@@ -803,11 +1021,18 @@ int disco_finalize(disco_ctx* c) {
     const std::string sg = "segnet.net.";
     if ((rc = make_c1(c, sg + "conv0a.0", sg + "conv0a.1"))) return rc;
     for (const char* k : {"conv0b", "conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "conv3_1",
-                          "conv2_1", "conv1_1", "conv0_1"})
+                          "conv2_1", "conv1_1"})
         if ((rc = make_conv(c, sg + k + ".0", sg + k + ".1", "", nullptr, 0, k[5] == 'a' && k[6] == '\0' && k[4] != '0'))) return rc;   // conv1a..conv4a: stride 2
+    if (use_mx(c)) {     // cat(o1, deconv0): both sources carry 16 real channels in a 32-channel block
+        std::vector<int> map(64, -1);
+        for (int i = 0; i < 16; ++i) { map[i] = i; map[32 + i] = 16 + i; }
+        if ((rc = make_conv(c, sg + "conv0_1.0", sg + "conv0_1.1", "", &map, 64))) return rc;
+    } else if ((rc = make_conv(c, sg + "conv0_1.0", sg + "conv0_1.1", "", nullptr, 0, false))) return rc;
     for (const char* k : {"deconv3", "deconv2", "deconv1", "deconv0"}) if ((rc = make_deconv(c, sg + k + ".0"))) return rc;
-    if ((rc = make_conv(c, sg + "pred_mask0", "", ""))) return rc;
-    if (seg_only) { c->sd.clear(); c->finalized = true; return DISCO_OK; }
+    if ((rc = make_conv(c, sg + "pred_mask0", "", "", nullptr, 0, false, false))) return rc;
+    if ((rc = dev_alloc(c, 256, (void**)&c->d_sat))) return rc;
+    DISCO_HIP_CHECK(hipMemset(c->d_sat, 0, 256));
+    if (seg_only) { c->sd.clear(); c->finalized = true; return calibrate_ctx(c); }
     const std::string rp = "repnet.";
     if ((rc = make_c1(c, rp + "conv1_2.0", ""))) return rc;
     if ((rc = make_conv(c, rp + "conv1_2.2", "", rp + "conv1_2.4"))) return rc;
@@ -826,10 +1051,11 @@ int disco_finalize(disco_ctx* c) {
     if ((rc = make_conv(c, rp + "conv10_2.1", "", ""))) return rc;
     const std::string en = "enhanceNet.";
     {   // input = cat(gray, 64 token features) in the reference; here source 0 = features, source 1 = 16-ch gray plane
-        std::vector<int> map(80, -1);
+        const int cp = use_mx(c) ? 96 : 80;          // the gray plane is one 32- (16-) channel block
+        std::vector<int> map(cp, -1);
         for (int i = 0; i < 64; ++i) map[i] = i + 1;
         map[64] = 0;
-        if ((rc = make_conv(c, en + "inConv.inConv.0", "", "", &map, 80))) return rc;
+        if ((rc = make_conv(c, en + "inConv.inConv.0", "", "", &map, cp))) return rc;
     }
     if ((rc = make_conv(c, en + "inConv.conv.0", "", en + "inConv.conv.2"))) return rc;
     for (const char* k : {"down1", "down2"}) {
@@ -845,7 +1071,7 @@ int disco_finalize(disco_ctx* c) {
         if ((rc = make_conv(c, en + k + ".conv2.0", "", ""))) return rc;
         if ((rc = make_conv(c, en + k + ".conv2.2", "", en + k + ".conv2.4"))) return rc;
     }
-    if ((rc = make_conv(c, en + "outConv", "", ""))) return rc;
+    if ((rc = make_conv(c, en + "outConv", "", "", nullptr, 0, false, false))) return rc;
     if ((rc = make_encoder(c, "wildpath", &c->d_enc[0]))) return rc;
     if ((rc = make_encoder(c, "hintpath", &c->d_enc[1]))) return rc;
     if ((rc = upload_vec(c, T(c, "mid_word_prj.weight").data, &c->d_mid_w))) return rc;
@@ -857,6 +1083,29 @@ int disco_finalize(disco_ctx* c) {
     if ((rc = upload_vec(c, q, &c->d_q_to_ab))) return rc;
     c->sd.clear();   // host copies are no longer needed
     c->finalized = true;
+    return calibrate_ctx(c);
+}
+
+int disco_saturation_count(disco_ctx* c, void* stream, uint64_t* count) {
+    if (!c || !count || !c->finalized) { set_error("disco_saturation_count: bad argument"); return DISCO_EINVAL; }
+    unsigned int v = 0;
+    DISCO_HIP_CHECK(hipSetDevice(c->device));
+    DISCO_HIP_CHECK(hipMemcpyAsync(&v, c->d_sat, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DISCO_HIP_CHECK(hipMemsetAsync(c->d_sat, 0, 4, (hipStream_t)stream));
+    DISCO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *count = v;
+    return DISCO_OK;
+}
+
+int disco_calibration_count(disco_ctx* c) { return c ? (int)c->amax.size() : 0; }
+
+int disco_calibration_entry(disco_ctx* c, int i, const char** key, float* amax, int* sexp) {
+    if (!c || i < 0 || i >= (int)c->amax.size() || !key || !amax || !sexp) { set_error("bad calibration index"); return DISCO_EINVAL; }
+    auto it = c->amax.begin();
+    std::advance(it, i);
+    *key = it->first.c_str(); *amax = it->second;
+    auto sx = c->sexp.find(it->first);
+    *sexp = sx == c->sexp.end() ? 0 : sx->second;
     return DISCO_OK;
 }
 
@@ -884,6 +1133,7 @@ int disco_forward_segnet(disco_ctx* c, int n, int h, int w, const float* d_gray,
     if (n < 1 || h < 16 || w < 16 || h % 16 || w % 16) { set_error("bad input size %dx%dx%d (multiples of 16)", n, h, w); return DISCO_ESHAPE; }
     if (!d_gray || !d_affinity || !d_ws) { set_error("null tensor pointer"); return DISCO_EINVAL; }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
+    if (!c->calibrated) { set_error("context used before its calibration pass"); return DISCO_ESTATE; }
     Plan P(c, &a, ws_bytes, false);
     segnet_stage(P, c, d_gray, n, h, w, d_affinity);
     return P.rc;
@@ -1163,7 +1413,7 @@ int disco_op_poolfeat(const float* d_feat, const float* d_prob, float* d_pooled,
 int disco_op_upfeat(const float* d_tok, const float* d_prob, float* d_out, int n, int ch, int h, int w, int sp, void* stream) {
     if (!positive("upfeat", {n, ch, h, w, sp})) return DISCO_ESHAPE;
     if (!d_tok || !d_prob || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
-    return launch_upfeat(d_tok, 0, d_prob, 1, nullptr, 0, d_out, n, ch, h, w, sp, (hipStream_t)stream);
+    return launch_upfeat(d_tok, 0, d_prob, 1, nullptr, d_out, n, ch, h, w, sp, nullptr, (hipStream_t)stream);
 }
 
 size_t disco_op_encoder_weight_floats(void) { return ENC_LAYERS * ENC_LAYER_FLOATS; }

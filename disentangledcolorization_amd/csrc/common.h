@@ -52,6 +52,40 @@ struct Act {
 };
 constexpr int MX_LO_SHIFT = 11;     // al8 carries 2^11 more scale than a8 (|x - fp16(x)| <= 2^-11 |x|)
 
+// four floats -> four fp8 e4m3 bytes (round to nearest even), clamped to the finite range; *sat counts clamped values
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d, unsigned* sat = nullptr) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the conversion builtins exist in the device pass only
+    const float x0 = __builtin_amdgcn_fmed3f(a, -448.f, 448.f), x1 = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    const float x2 = __builtin_amdgcn_fmed3f(c, -448.f, 448.f), x3 = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    if (sat) *sat += (x0 != a) + (x1 != b) + (x2 != c) + (x3 != d);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, w, true);
+    return (unsigned)w;
+#else
+    return 0u;
+#endif
+}
+// 8 consecutive channels (the half `half` of a 16-channel block `blk`) of pixel `pix` of image `img` -> the planes of an act
+__device__ __forceinline__ void store_act8(f16* hi_p, long plane, long q_off, int sexp, long img, int blk, int half, long pix, long hw,
+                                            int nblk, const float* v, unsigned* sat = nullptr) {
+    f16x8 h, l;
+    float lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = (f16)v[j]; lo[j] = v[j] - (float)h[j]; l[j] = (f16)lo[j]; }
+    f16* o = hi_p + (((long)img * nblk + blk) * hw + pix) * 16 + half * 8;
+    *reinterpret_cast<f16x8*>(o) = h;
+    if (plane) *reinterpret_cast<f16x8*>(o + plane) = l;
+    if (q_off) {
+        const float qs = ldexpf(1.f, sexp), qls = ldexpf(1.f, sexp + MX_LO_SHIFT);
+        unsigned char* q = reinterpret_cast<unsigned char*>(hi_p) + q_off + (((long)img * (nblk >> 1) + (blk >> 1)) * 2) * hw * 32 + pix * 32 + (blk & 1) * 16 + half * 8;
+        uint2 a, b;
+        a.x = pack_fp8x4(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, sat); a.y = pack_fp8x4(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs, sat);
+        b.x = pack_fp8x4(lo[0] * qls, lo[1] * qls, lo[2] * qls, lo[3] * qls, sat); b.y = pack_fp8x4(lo[4] * qls, lo[5] * qls, lo[6] * qls, lo[7] * qls, sat);
+        *reinterpret_cast<uint2*>(q) = a;
+        *reinterpret_cast<uint2*>(q + hw * 32) = b;
+    }
+}
+
 // ---- conv3x3 (MFMA implicit GEMM) ---------------------------------------------------------------
 constexpr int CONV_CK = 16;  // input-channel chunk (one MFMA k-block)
 
@@ -159,9 +193,9 @@ void conv3x3_tapmask_host(const float* h_w, int c_out, int c_in, uint32_t* mask 
 
 // ---- direct (VALU) convs ------------------------------------------------------------------------
 // first layers: Cin = 1, fp32 NCHW gray input -> act output
+// `out` may carry lo and/or q planes and more (zero) channels than c_out; sat: optional clamp counter of the q planes
 int launch_conv_c1(const float* d_gray, const float* d_w /*(cout,9)*/, const float* d_bias, const float* d_bn_scale,
-                   const float* d_bn_shift, f16* out, long out_plane, int n, int h, int w, int c_out, int act,
-                   float slope, hipStream_t s);
+                   const float* d_bn_shift, const Act& out, int c_out, int act, float slope, unsigned int* sat, hipStream_t s);
 
 // ---- layout conversion --------------------------------------------------------------------------
 int launch_nchw_to_act(const float* src, f16* dst, long plane, int n, int c, int h, int w, int c_pad, hipStream_t s);
@@ -187,10 +221,10 @@ struct PoolArgs {
 size_t poolfeat_ws_bytes(int n, int c, int H, int W, int sp);
 int launch_poolfeat(const PoolArgs& a, hipStream_t s);
 // upfeat: tokens (n,L,C) [tok_layout] or NCHW -> act planes (c_pad) and/or fp32 NCHW
-int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_rep, f16* out_act, long out_plane,
-                  float* out_nchw, int n, int c, int h, int w, int sp, hipStream_t s);
-// gray (n,1,H,W) -> 16-channel act with gray in channel 0 (rep: output image i reads gray image i/rep)
-int launch_gray16(const float* gray, int rep, f16* out, long out_plane, int n, int H, int W, hipStream_t s);
+int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_rep, const Act* out_act,
+                  float* out_nchw, int n, int c, int h, int w, int sp, unsigned int* sat, hipStream_t s);
+// gray (n,1,H,W) -> act of out.c (16 or 32) channels with gray in channel 0, zeros elsewhere (rep: output image i reads gray image i/rep)
+int launch_gray16(const float* gray, int rep, const Act& out, unsigned int* sat, hipStream_t s);
 
 // ---- token path ---------------------------------------------------------------------------------
 constexpr int D_MODEL = 64;

@@ -43,20 +43,22 @@ __device__ __forceinline__ void load_sum8(const f16* hi_p, long plane, float* v)
 // the block's 16x9 weights and its bias / BN affine sit in LDS.
 __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ gray, const float* __restrict__ w,
                                                       const float* __restrict__ bias, const float* __restrict__ bsc,
-                                                      const float* __restrict__ bsh, f16* out, long out_plane, int n,
-                                                      int h, int wd, int c_out, int act, float slope) {
+                                                      const float* __restrict__ bsh, f16* out, long out_plane, long q_off, int sexp,
+                                                      unsigned int* sat_out, int n, int h, int wd, int c_out, int c_pad, int act,
+                                                      float slope) {
     __shared__ float sw[16 * 9 + 48];
-    const int nblk = c_out >> 4;
+    const int nblk = c_pad >> 4;
     const int blk = blockIdx.y % nblk;
     const long img = blockIdx.y / nblk;
     const long hw = (long)h * wd;
-    if (threadIdx.x < 144) sw[threadIdx.x] = w[blk * 144 + threadIdx.x];
-    else if (threadIdx.x < 160) sw[threadIdx.x] = bias ? bias[blk * 16 + threadIdx.x - 144] : 0.f;
-    else if (threadIdx.x < 176) sw[threadIdx.x] = bsc ? bsc[blk * 16 + threadIdx.x - 160] : 1.f;
-    else if (threadIdx.x < 192) sw[threadIdx.x] = bsh ? bsh[blk * 16 + threadIdx.x - 176] : 0.f;
+    const bool real = blk * 16 < c_out;                 // channel blocks beyond c_out are zero padding
+    if (threadIdx.x < 144) sw[threadIdx.x] = real ? w[blk * 144 + threadIdx.x] : 0.f;
+    else if (threadIdx.x < 160) sw[threadIdx.x] = real && bias ? bias[blk * 16 + threadIdx.x - 144] : 0.f;
+    else if (threadIdx.x < 176) sw[threadIdx.x] = real && bsc ? bsc[blk * 16 + threadIdx.x - 160] : 1.f;
+    else if (threadIdx.x < 192) sw[threadIdx.x] = real && bsh ? bsh[blk * 16 + threadIdx.x - 176] : 0.f;
     __syncthreads();
     const float* gi = gray + img * hw;
-    f16* ob = out + ((img * nblk + blk) * hw) * 16;
+    unsigned sat = 0;
     for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < 2 * hw; u += (long)gridDim.x * blockDim.x) {
         const long p = u >> 1;
         const int half = (int)(u & 1);
@@ -78,10 +80,11 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
             for (int k = 0; k < 9; ++k) s = fmaf(in[k], sw[c * 9 + k], s);
             s += sw[144 + c];
             s = apply_act(s, act, slope);
-            v[j] = s * sw[160 + c] + sw[176 + c];
+            v[j] = real ? s * sw[160 + c] + sw[176 + c] : 0.f;
         }
-        store_split8(ob + u * 8, out_plane, v);
+        store_act8(out, out_plane, q_off, sexp, img, blk, half, p, hw, nblk, v, &sat);
     }
+    if (sat_out && sat) atomicAdd(sat_out, sat);
 }
 
 // ---- layout converters -----------------------------------------------------------------------------
@@ -125,14 +128,13 @@ inline int grid_for(long total, int block = 256) {
 }  // namespace
 
 int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, const float* d_bn_scale,
-                   const float* d_bn_shift, f16* out, long out_plane, int n, int h, int w, int c_out, int act,
-                   float slope, hipStream_t s) {
-    if (c_out % 16) { set_error("conv_c1: c_out %d not a multiple of 16", c_out); return DISCO_ESHAPE; }
-    const long hw = (long)h * w;
+                   const float* d_bn_shift, const Act& out, int c_out, int act, float slope, unsigned int* sat, hipStream_t s) {
+    if (c_out % 16 || out.c % (out.q_off ? 32 : 16) || out.c < c_out) { set_error("conv_c1: c_out %d into a %d-channel act", c_out, out.c); return DISCO_ESHAPE; }
+    const long hw = (long)out.h * out.w;
     // few fat workgroups per (image, block): the 192-float parameter staging + barrier is paid once per workgroup
-    dim3 grid((unsigned)std::min<long>((2 * hw + 255) / 256, 64), (unsigned)(n * (c_out / 16)));
-    hipLaunchKernelGGL(conv_c1_kernel, grid, dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale, d_bn_shift, out, out_plane,
-                       n, h, w, c_out, act, slope);
+    dim3 grid((unsigned)std::min<long>((2 * hw + 255) / 256, 64), (unsigned)(out.n * (out.c / 16)));
+    hipLaunchKernelGGL(conv_c1_kernel, grid, dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale, d_bn_shift, out.p, (long)out.plane,
+                       (long)out.q_off, out.sexp, sat, out.n, out.h, out.w, c_out, out.c, act, slope);
     DISCO_LAUNCH_CHECK("conv_c1_kernel");
     return DISCO_OK;
 }

@@ -30,6 +30,10 @@
 #include <vector>
 #include "common.h"
 
+#ifndef MX_ABL
+#define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk
+#endif
+
 namespace disco {
 
 namespace {
@@ -223,17 +227,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         int pl = p_lane, wo = w_off;
         asm volatile("" : "+v"(pl), "+v"(wo));
         i32x4 ra[MT][2];
+        i32x4 rb[NTW][2];
 #pragma unroll
         for (int slot = 0; slot < 9; ++slot) {
             const int ky = ROWREUSE ? slot % 3 : slot / 3, kx = ROWREUSE ? slot / 3 : slot % 3;
             const int tap = ky * 3 + kx;
+#if !(MX_ABL & 1)
             issue(dma_img, dma_ck, buf, slot);
+#endif
             const bool live = !MASKED || ((tmask >> tap) & 1u);
             if (!ROWREUSE && !live) continue;
             const int tapoff = ky * G::PITCH + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (ROWREUSE && ky > 0 && mt == 0) { ra[0][0] = ra[1][0]; ra[0][1] = ra[1][1]; continue; }
+#if MX_ABL & 2
+                if (slot > 0) continue;
+#endif
                 const int p = pl + mt * G::ROWS_PER_MB * STRIDE * G::PITCH + tapoff;
                 const int sw = (p >> 3) & 1;
                 if (ISQ) {
@@ -247,9 +257,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 }
             }
             if (ROWREUSE && !live) continue;
-            i32x4 rb[NTW][2];
+#if MX_ABL & 2
+            static_assert(true, "");
+#endif
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
+#if MX_ABL & 2
+                if (slot > 0) continue;
+#endif
                 const int off = wo + nt * W_NB + tap * 2 * WBLK;
                 rb[nt][0] = *reinterpret_cast<const i32x4*>(sW + off);
                 rb[nt][1] = *reinterpret_cast<const i32x4*>(sW + off + WBLK);

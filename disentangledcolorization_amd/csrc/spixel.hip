@@ -160,12 +160,13 @@ __global__ void pool_gather_kernel(PoolArgs a) {
 // shares them), and a wave writes 64 consecutive 32-byte pixels per block and plane.
 __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ tok, int tok_layout,
                                                      const float* __restrict__ prob, int prob_rep, f16* out_act,
-                                                     long out_plane, float* out_nchw, int n, int c, int hs, int ws,
-                                                     int sp) {
+                                                     long out_plane, long q_off, int sexp, unsigned int* sat_out, float* out_nchw,
+                                                     int n, int c, int hs, int ws, int sp) {
     const int H = hs * sp, W = ws * sp, L = hs * ws;
     const long HW = (long)H * W;
     const int nblk = c >> 4;
     const long total = (long)n * HW;
+    unsigned sat = 0;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const long p = t % HW;
         const int img = (int)(t / HW);
@@ -201,15 +202,8 @@ __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ t
                 for (int j = 0; j < 16; ++j) acc[j] = s == 0 ? __fmul_rn(tv[j], pw[0]) : __fadd_rn(acc[j], __fmul_rn(tv[j], pw[s]));
             }
             if (out_act) {
-                f16x8 hv, lv;
-                f16* o = out_act + (((long)img * nblk + blk) * HW + p) * 16;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { hv[j] = (f16)acc[half * 8 + j]; lv[j] = (f16)(acc[half * 8 + j] - (float)hv[j]); }
-                    *reinterpret_cast<f16x8*>(o + half * 8) = hv;
-                    *reinterpret_cast<f16x8*>(o + half * 8 + out_plane) = lv;
-                }
+                store_act8(out_act, out_plane, q_off, sexp, img, blk, 0, p, HW, nblk, acc, &sat);
+                store_act8(out_act, out_plane, q_off, sexp, img, blk, 1, p, HW, nblk, acc + 8, &sat);
             }
             if (out_nchw) {
 #pragma unroll
@@ -217,6 +211,7 @@ __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ t
             }
         }
     }
+    if (sat_out && sat) atomicAdd(sat_out, sat);
 }
 
 // generic (c not a multiple of 8) NCHW-only variant: thread = (pixel, channel)
@@ -243,23 +238,21 @@ __global__ void upfeat_scalar_kernel(const float* __restrict__ tok, const float*
     }
 }
 
-__global__ void gray16_kernel(const float* __restrict__ gray, int rep, f16* out, long out_plane, long npix_total,
-                              long HW) {
+__global__ void gray16_kernel(const float* __restrict__ gray, int rep, f16* out, long out_plane, long q_off, int sexp, int nblk,
+                              unsigned int* sat_out, long npix_total, long HW) {
+    unsigned sat = 0;
     for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix_total; pix += (long)gridDim.x * blockDim.x) {
         const long img = pix / HW, p = pix % HW;
-        const float v = gray[(img / rep) * HW + p];
-        f16x8 z;
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = (f16)0.f;
-        f16x8 h = z, l = z;
-        h[0] = (f16)v;
-        l[0] = (f16)(v - (float)h[0]);
-        f16* o = out + pix * 16;
-        *reinterpret_cast<f16x8*>(o) = h;
-        *reinterpret_cast<f16x8*>(o + 8) = z;
-        *reinterpret_cast<f16x8*>(o + out_plane) = l;
-        *reinterpret_cast<f16x8*>(o + out_plane + 8) = z;
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        for (int blk = 0; blk < nblk; ++blk)
+            for (int half = 0; half < 2; ++half) {
+                v[0] = (blk == 0 && half == 0) ? gray[(img / rep) * HW + p] : 0.f;
+                store_act8(out, out_plane, q_off, sexp, img, blk, half, p, HW, nblk, v, &sat);
+            }
     }
+    if (sat_out && sat) atomicAdd(sat_out, sat);
 }
 
 inline int grid_for(long total, int block = 256) {
@@ -287,12 +280,14 @@ int launch_poolfeat(const PoolArgs& a, hipStream_t s) {
     return DISCO_OK;
 }
 
-int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_rep, f16* out_act, long out_plane,
-                  float* out_nchw, int n, int c, int h, int w, int sp, hipStream_t s) {
+int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_rep, const Act* out_act, float* out_nchw, int n,
+                  int c, int h, int w, int sp, unsigned int* sat, hipStream_t s) {
     if (c % 16 == 0) {
+        if (out_act && (out_act->c != c || (out_act->q_off && c % 32))) { set_error("upfeat: act of %d channels for c=%d", out_act->c, c); return DISCO_ESHAPE; }
         const long total = (long)n * h * sp * w * sp;
         hipLaunchKernelGGL(upfeat_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, tok_layout, prob, prob_rep,
-                           out_act, out_plane, out_nchw, n, c, h, w, sp);
+                           out_act ? out_act->p : nullptr, out_act ? (long)out_act->plane : 0L, out_act ? (long)out_act->q_off : 0L,
+                           out_act ? out_act->sexp : 0, sat, out_nchw, n, c, h, w, sp);
         DISCO_LAUNCH_CHECK("upfeat_kernel");
         return DISCO_OK;
     }
@@ -303,9 +298,11 @@ int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_
     return DISCO_OK;
 }
 
-int launch_gray16(const float* gray, int rep, f16* out, long out_plane, int n, int H, int W, hipStream_t s) {
-    const long HW = (long)H * W, total = (long)n * HW;
-    hipLaunchKernelGGL(gray16_kernel, dim3(grid_for(total)), dim3(256), 0, s, gray, rep, out, out_plane, total, HW);
+int launch_gray16(const float* gray, int rep, const Act& out, unsigned int* sat, hipStream_t s) {
+    if (out.c % (out.q_off ? 32 : 16)) { set_error("gray16: %d channels", out.c); return DISCO_ESHAPE; }
+    const long HW = (long)out.h * out.w, total = (long)out.n * HW;
+    hipLaunchKernelGGL(gray16_kernel, dim3(grid_for(total)), dim3(256), 0, s, gray, rep, out.p, (long)out.plane, (long)out.q_off, out.sexp,
+                       out.c / 16, sat, total, HW);
     DISCO_LAUNCH_CHECK("gray16_kernel");
     return DISCO_OK;
 }

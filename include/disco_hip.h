@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 3
+#define DISCO_ABI_VERSION 4
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -60,6 +60,11 @@ typedef struct disco_ctx disco_ctx;
 /* conv precision modes */
 #define DISCO_PREC_F16X3 0 /* fp16 hi/lo split operands, 3 MFMA products, fp32 accumulate */
 #define DISCO_PREC_F16X1 1 /* fp16 hi operands only */
+#define DISCO_PREC_MX8 2   /* fp16 main product + two fp8 (e4m3) correction products in one K=64 MFMA (csrc/conv_mx.hip):
+                              w a ~= w_h a_h + fp8(w - w_h) fp8(a) + fp8(w) fp8(a - a_h).  Activations carry an fp16 plane and
+                              two fp8 planes with one power-of-two scale per tensor, fixed by a calibration forward at the
+                              end of disco_finalize; clamping against that scale at run time is counted
+                              (disco_saturation_count).  Measured end to end: max |ab - reference| ~1e-4. */
 
 int disco_abi_version(void);
 const char *disco_last_error(void);
@@ -127,6 +132,14 @@ typedef struct disco_forward_args {
 } disco_forward_args;
 
 int disco_workspace_bytes(disco_ctx *ctx, int n, int h, int w, int sampled_T, size_t *bytes);
+/* DISCO_PREC_MX8: number of fp8 activation elements that had to be clamped (|x 2^scale| > 448) since the previous call; the
+ * counter is read on `stream` (one synchronisation) and reset.  Non-zero means some activation exceeded ~14x the range the
+ * calibration pass saw: the affected correction products lose accuracy (results degrade towards plain-fp16 operands). */
+int disco_saturation_count(disco_ctx *ctx, void *stream, uint64_t *count);
+/* The calibration pass's per-tensor record (diagnostics; the fp16 range guard: disco_finalize fails with
+ * DISCO_EUNSUPPORTED when any tensor's max |x| exceeds 16384): producer key, max |x|, chosen scale exponent. */
+int disco_calibration_count(disco_ctx *ctx);
+int disco_calibration_entry(disco_ctx *ctx, int i, const char **key, float *amax, int *sexp);
 /* SpixelSeg.forward(gray) -> affinity (n,9,h,w), softmax over the 9 neighbour slots (models/network.py:293-313).
  * Works on full and segnet_only contexts; workspace as reported by disco_workspace_bytes. */
 int disco_forward_segnet(disco_ctx *ctx, int n, int h, int w, const float *d_gray, float *d_affinity, void *d_workspace,

@@ -32,18 +32,54 @@ SHAPES = [  # name, cin0, cin1, cout, h_in (logical), stride, up0
 ]
 
 
+def bench_mx(L, args, name, c0, c1, co, hin, stride, up0):
+    n = args.n
+    hs = hin // 2 if up0 else hin
+    x0 = H.to_act_mx(torch.relu(torch.randn(n, c0, hs, hs, device="cuda")), sexp=2)
+    x1 = H.to_act_mx(torch.relu(torch.randn(n, c1, hin, hin, device="cuda")), sexp=2) if c1 else None
+    w = torch.randn(co, c0 + c1, 3, 3) * 0.05
+    packed, wexp = H.pack_conv_mx(w)
+    ho = (hin - 1) // stride + 1
+    out = H.MxAct(n, co, ho, ho, _ffi.PLANE_Q, 0)
+    bias = torch.zeros(co, device="cuda")
+    d = _ffi.ConvMxDesc(n, hin, hin, c0, c1, up0, 0, x0.sexp, x1.sexp if x1 else 0, co, stride, _ffi.ACT_RELU, 0.0, _ffi.PLANE_Q, 0, 0, 0)
+
+    def run():
+        _ffi.check(L.disco_op_conv3x3_mx(C.byref(d), _ffi.ptr(x0.buf), _ffi.ptr(x1.buf) if x1 else None, _ffi.ptr(packed), _ffi.ptr(wexp),
+                                        _ffi.ptr(bias), None, None, None, _ffi.ptr(out.buf), None, H.stream()))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    fl = 2.0 * 9 * (c0 + c1) * co * ho * ho * n
+    print(f"{name:22s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF alg  {2 * fl / ms / 1e9:8.1f} TF-equivalent pipe units   [mx]", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--prec", type=int, default=0)
     ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--mx", type=int, default=0, help="1: the fp16 + fp8-correction kernel (conv_mx.hip); 2: both, side by side")
     args = ap.parse_args()
     L = _ffi.lib()
     for name, c0, c1, co, hin, stride, up0 in SHAPES:
         if args.only and args.only not in name:
             continue
         n = args.n
+        if args.mx and (c0 % 32 or c1 % 32 or co < 32):
+            continue
+        if args.mx:
+            bench_mx(L, args, name, c0, c1, co, hin, stride, up0)
+            if args.mx == 1:
+                continue
         hs = hin // 2 if up0 else hin
         src0 = torch.randn(2, n, hs, hs, c0, device="cuda").half()
         src1 = torch.randn(2, n, hin, hin, c1, device="cuda").half() if c1 else None
