@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
-    ap.add_argument("--precision", default="f16x3", choices=["mx8", "f16x3", "f16x1"])
+    ap.add_argument("--precision", default="mx8", choices=["mx8", "mx8all", "f16x3", "f16x1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--micro", type=int, default=1, help="micro-batches per GPU, each on its own HIP stream")
     args = ap.parse_args()

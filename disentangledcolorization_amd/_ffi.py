@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DISCO_HIP_LIB") or os.path.join(_HERE, "libdisco_hip.
 
 OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
-PREC_F16X3, PREC_F16X1, PREC_MX8 = 0, 1, 2
+PREC_F16X3, PREC_F16X1, PREC_MX8, PREC_MX8_ALL = 0, 1, 2, 3
 PLANE_LO, PLANE_Q = 1, 2
 
 

@@ -267,7 +267,16 @@ void bn_affine(disco_ctx* c, const std::string& key, std::vector<float>& scale, 
     }
 }
 
-bool use_mx(const disco_ctx* c) { return c->opt.precision == DISCO_PREC_MX8; }
+// Which layers run on conv3x3_mx_kernel.  DISCO_PREC_MX8: the enhanceNet only - everything downstream of the anchors.  The
+// stacks that feed k-means (segnet -> affinity -> pooling / sizes, repnet -> tokens) keep the f16x3 kernel: anchors are a
+// discrete decision, and the ~3e-5 perturbation of the fp8-corrected arithmetic at the encoder output flipped them in 1 of
+// 108 images against the fp32 oracle (tools/anchor_stability.py, profiles/r02_anchor_stability.txt), f16x3 in none.
+// DISCO_PREC_MX8_ALL runs every layer on the mx kernel (measurements only: not anchor-safe).
+bool any_mx(const disco_ctx* c) { return c->opt.precision == DISCO_PREC_MX8 || c->opt.precision == DISCO_PREC_MX8_ALL; }
+bool use_mx(const disco_ctx* c, const std::string& key) {
+    if (c->opt.precision == DISCO_PREC_MX8_ALL) return true;
+    return c->opt.precision == DISCO_PREC_MX8 && key.compare(0, 11, "enhanceNet.") == 0;
+}
 int pad_cout_mx(int co) { return co <= 32 ? 32 : round_up(co, 64); }
 
 // upload bias / BN affine padded to `n` channels (bias 0, scale 1, shift 0 beyond the real ones)
@@ -312,7 +321,7 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
     ConvLayer L;
     L.c_in = ci; L.c_out = co; L.c_real = co;
     int rc;
-    if (use_mx(c)) {
+    if (use_mx(c, key)) {
         const int cpad = c_in_pad_override ? c_in_pad_override : round_up(ci, 32);
         if ((rc = finish_mx(c, L, w, co, ci, ci_map ? ci_map->data() : nullptr, cpad, act_out))) return rc;
         if ((rc = upload_padded(c, bias, (size_t)L.c_out_k, 0.f, &L.d_bias))) return rc;
@@ -403,7 +412,7 @@ int make_deconv(disco_ctx* c, const std::string& key) {
     ConvLayer L;
     L.c_in = ci; L.c_out = 4 * co; L.c_real = co; L.c_in_pad = round_up(ci, 16); L.kind = 1;
     int rc;
-    if (use_mx(c)) {
+    if (use_mx(c, key)) {
         if ((rc = finish_phase_mx(c, L, w3, co, ci, T(c, key + ".bias").data))) return rc;
         c->conv[key] = L;
         return DISCO_OK;
@@ -429,7 +438,7 @@ int make_upconv(disco_ctx* c, const std::string& key) {
     ConvLayer L;
     L.c_in = ci; L.c_out = 4 * co; L.c_real = co; L.c_in_pad = round_up(ci, 16); L.kind = 2;
     int rc;
-    if (use_mx(c)) {
+    if (use_mx(c, key)) {
         if ((rc = finish_phase_mx(c, L, w4, co, ci, T(c, key + ".bias").data))) return rc;
         c->conv[key] = L;
         return DISCO_OK;
@@ -499,7 +508,8 @@ struct Plan {
     void drop(void* p) { if (p) arena.release(dry ? (size_t)(uintptr_t)p - 256 : (size_t)((char*)p - base)); }
     // planes of an activation tensor: F_LO = fp16 lo plane, F_Q = fp8 q planes (scale exponent of producer `key`)
     enum { F_LO = 1, F_Q = 2 };
-    bool mx() const { return use_mx(c); }
+    bool mx_stage = false;        // the stack being planned runs on the mx kernel (set per network by the plan)
+    bool mx() const { return mx_stage; }
     int cpad(int ch) const { return round_up(ch, mx() ? 32 : 16); }
     int dfmt() const { return mx() ? (int)F_Q : (int)F_LO; }          // what a conv -> conv tensor carries
     Act act(int n, int h, int w, int ch, int fmt) {
@@ -609,8 +619,9 @@ struct Plan {
             ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
             ca.out = out.p; ca.out_plane = (long)out.plane;
             ca.out_f32 = out_f32; ca.d2s_c = d2s ? L.c_out / 4 : 0; ca.softmax = softmax ? 1 : 0;
-            ca.act = actc; ca.slope = slope; ca.precision = c->opt.precision;
+            ca.act = actc; ca.slope = slope; ca.precision = c->opt.precision == DISCO_PREC_F16X1 ? DISCO_PREC_F16X1 : DISCO_PREC_F16X3;
             rc = run_conv(ca, s);
+            if (!out_f32) calibrate(key, out, [] {});     // calibration pass: records max |x| (fp16 range guard) for f16x3 layers too
         }
         if (timed) {
             hipEventRecord(e1, s);
@@ -648,6 +659,7 @@ constexpr int RELU = DISCO_ACT_RELU, LRELU = DISCO_ACT_LRELU, NOACT = DISCO_ACT_
 // ---- a1 SpixelNet (network.py:293-313): gray -> affinity (n,9,H,W), softmax over the 9 neighbour slots -------------
 void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int W, float* d_affinity) {
     const bool dry = P.dry;
+    P.mx_stage = use_mx(c, "segnet.");
     hipStream_t s = P.s;
     const std::string sg = "segnet.net.";
     Act s0a = P.c1(sg + "conv0a.0", d_gray, n, H, W, LRELU, 0.1f);
@@ -676,7 +688,7 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
 int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, size_t* peak, bool calib = false) {
     Plan P(c, a, cap, dry);
     P.calib = calib;
-    if (!dry && !calib && use_mx(c) && !c->calibrated) { set_error("mx context used before its calibration pass"); return DISCO_ESTATE; }
+    if (!dry && !calib && any_mx(c) && !c->calibrated) { set_error("mx context used before its calibration pass"); return DISCO_ESTATE; }
     const int n = a->n, H = a->h, W = a->w, sp = c->opt.sp_size, K = c->opt.n_clusters;
     const int hs = H / sp, ws = W / sp, L = hs * ws;
     const bool test = a->test_mode != 0, h2r = c->opt.hint2regress != 0, spos = c->opt.spix_pos != 0;
@@ -696,6 +708,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
 
     // ---- a2 ColorProbNet (network.py:220-236) ----------------------------------------------------------------
     const std::string rp = "repnet.";
+    P.mx_stage = use_mx(c, rp);
     Act t = P.c1(rp + "conv1_2.0", a->d_gray, n, H, W, LRELU, 0.2f);
     Act f = P.conv(rp + "conv1_2.2", t, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(t);
     Act f3{};
@@ -802,6 +815,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     P.mark("hintpath", 2.0 * 0.134e9 * n2);
 
     // ---- a12 upfeat + a13 HourGlass2 + tanh (model.py:194-197) --------------------------------------------------
+    P.mx_stage = use_mx(c, "enhanceNet.");
     Act full = P.act(n2, H, W, 64, P.dfmt());
     Act g16 = P.act(n2, H, W, P.cpad(16), P.dfmt());
     if (!dry && P.ok() && full.q_off && P.scale_of("upfeat", &full.sexp) && P.scale_of("gray16", &g16.sexp)) {}
@@ -861,7 +875,7 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
 // properties of the checkpoint from then on (deterministic: the inputs are generated here); q-plane clamping at run time is
 // counted (disco_saturation_count) so that inputs far outside the calibrated range are noticed.
 int calibrate_ctx(disco_ctx* c) {
-    if (!use_mx(c)) { c->calibrated = true; return DISCO_OK; }
+    if (!any_mx(c) || (c->opt.segnet_only && c->opt.precision != DISCO_PREC_MX8_ALL)) { c->calibrated = true; return DISCO_OK; }
     const int n = 2, H = 256, W = 256, K = c->opt.n_clusters, L = (H / 16) * (W / 16);
     std::vector<float> g((size_t)n * H * W);
     unsigned st = 20240607u;
@@ -958,7 +972,7 @@ int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (!opt || !out) { set_error("null argument"); return DISCO_EINVAL; }
     if (opt->sp_size != 16) { set_error("sp_size %d unsupported (16 only, inference.py:146)", opt->sp_size); return DISCO_EUNSUPPORTED; }
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
-    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_F16X1 && opt->precision != DISCO_PREC_MX8) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
+    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_F16X1 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
     if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }
     if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("segnet_only context takes no colorizer flags"); return DISCO_EINVAL; }
     int ndev = 0;
@@ -1023,7 +1037,7 @@ int disco_finalize(disco_ctx* c) {
     for (const char* k : {"conv0b", "conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "conv3_1",
                           "conv2_1", "conv1_1"})
         if ((rc = make_conv(c, sg + k + ".0", sg + k + ".1", "", nullptr, 0, k[5] == 'a' && k[6] == '\0' && k[4] != '0'))) return rc;   // conv1a..conv4a: stride 2
-    if (use_mx(c)) {     // cat(o1, deconv0): both sources carry 16 real channels in a 32-channel block
+    if (use_mx(c, sg)) {     // cat(o1, deconv0): both sources carry 16 real channels in a 32-channel block
         std::vector<int> map(64, -1);
         for (int i = 0; i < 16; ++i) { map[i] = i; map[32 + i] = 16 + i; }
         if ((rc = make_conv(c, sg + "conv0_1.0", sg + "conv0_1.1", "", &map, 64))) return rc;
@@ -1051,7 +1065,7 @@ int disco_finalize(disco_ctx* c) {
     if ((rc = make_conv(c, rp + "conv10_2.1", "", ""))) return rc;
     const std::string en = "enhanceNet.";
     {   // input = cat(gray, 64 token features) in the reference; here source 0 = features, source 1 = 16-ch gray plane
-        const int cp = use_mx(c) ? 96 : 80;          // the gray plane is one 32- (16-) channel block
+        const int cp = use_mx(c, en) ? 96 : 80;          // the gray plane is one 32- (16-) channel block
         std::vector<int> map(cp, -1);
         for (int i = 0; i < 64; ++i) map[i] = i + 1;
         map[64] = 0;

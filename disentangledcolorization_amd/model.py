@@ -39,11 +39,11 @@ class SpixelSeg(nn.Module):
     """Drop-in for `models/model.py::SpixelSeg` (model.py:12-29): the superpixel network alone, as used by
     main/spixelseg/inference.py:45-89.  state_dict keys `net.*` (94 tensors); forward(gray) -> (N,9,H,W) affinity."""
 
-    def __init__(self, inChannel=1, outChannel=9, batchNorm=True, precision="f16x3"):
+    def __init__(self, inChannel=1, outChannel=9, batchNorm=True, precision="mx8"):
         super().__init__()
         if inChannel != 1 or outChannel != 9 or not batchNorm:
             raise NotImplementedError("SpixelSeg(inChannel=1, outChannel=9, batchNorm=True) only")
-        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8}[precision]
+        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL}[precision]
         for key, shape, dt, kind in state_dict_spec():
             if not key.startswith("segnet."):
                 continue
@@ -128,7 +128,7 @@ class SpixelSeg(nn.Module):
 class AnchorColorProb(nn.Module):
     def __init__(self, inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=False,
                  learning_pos=False, n_clusters=8, random_hint=False, hint2regress=False, enhanced=False,
-                 use_mask=False, rank=0, precision="f16x3", init_weights=True):
+                 use_mask=False, rank=0, precision="mx8", init_weights=True):
         super().__init__()
         unsupported = []
         if inChannel != 1: unsupported.append("inChannel=%r" % inChannel)
@@ -145,7 +145,7 @@ class AnchorColorProb(nn.Module):
         self.enhanced, self.hint2regress, self.spix_pos, self.use_token_mask = True, bool(hint2regress), bool(spix_pos), False
         self.n_vocab = 313
         self.rank = rank
-        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8}[precision]
+        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL}[precision]
         self.sync_kmeans_events = True   # emulate the reference's torch.randint fallback draws (one sync per forward)
         self._build_tree()
         self._ctx = None

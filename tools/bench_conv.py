@@ -35,9 +35,10 @@ SHAPES = [  # name, cin0, cin1, cout, h_in (logical), stride, up0
 def bench_mx(L, args, name, c0, c1, co, hin, stride, up0):
     n = args.n
     hs = hin // 2 if up0 else hin
-    x0 = H.to_act_mx(torch.relu(torch.randn(n, c0, hs, hs, device="cuda")), sexp=2)
-    x1 = H.to_act_mx(torch.relu(torch.randn(n, c1, hin, hin, device="cuda")), sexp=2) if c1 else None
-    w = torch.randn(co, c0 + c1, 3, 3) * 0.05
+    z = 0.0 if args.zeros else 1.0
+    x0 = H.to_act_mx(z * torch.relu(torch.randn(n, c0, hs, hs, device="cuda")), sexp=2)
+    x1 = H.to_act_mx(z * torch.relu(torch.randn(n, c1, hin, hin, device="cuda")), sexp=2) if c1 else None
+    w = torch.randn(co, c0 + c1, 3, 3) * 0.05 * z
     packed, wexp = H.pack_conv_mx(w)
     ho = (hin - 1) // stride + 1
     out = H.MxAct(n, co, ho, ho, _ffi.PLANE_Q, 0)
@@ -67,6 +68,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--prec", type=int, default=0)
     ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--zeros", type=int, default=0, help="1: all-zero activations and weights (how much of the time is the power-managed clock?)")
     ap.add_argument("--mx", type=int, default=0, help="1: the fp16 + fp8-correction kernel (conv_mx.hip); 2: both, side by side")
     args = ap.parse_args()
     L = _ffi.lib()
