@@ -7,15 +7,24 @@
 
 One step = one forward of AnchorColorProb (test mode, K=8 clustering anchors, all six outputs produced) over a
 batch of 64 synthetic 256x256 L-channel images per GPU (BASELINE config 2), inputs resident in HBM, followed —
-for N>1 — by the RCCL all-gather of pred_colors and hint_mask.  Weak scaling: 64 images per GPU.
+for N>1 — by the ONE packed RCCL all-gather of pred_colors + hint_mask.  Weak scaling: 64 images per GPU.
 Weights: the deterministic synthetic checkpoint of the real layout (disentangledcolorization_amd/synth.py).
 Prints ONE JSON line on rank 0.
+
+The timed loop runs without host synchronisation (k-means empty-cluster bookkeeping off); afterwards the same batch is
+run once more with the bookkeeping on and the line reports `kmeans_events` - the run FAILS unless it is 0 and the two
+results are identical, i.e. unless the timed forwards were the reference-exact ones.
+
+DISCO_BENCH_FAKE=1 (tests/test_dist_gloo.py): the same distributed scaffolding on the gloo backend with a cheap CPU
+stand-in for the forward, so that the N>1 code path is exercised without GPUs.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 import torch
@@ -27,41 +36,66 @@ sys.path.insert(0, REPO)
 GFLOP_PER_IMAGE = 255.470          # algorithmic work of one 256x256 image
 FP16_MFMA_PEAK = 2.5e15            # dense, MI355X_MICROARCH.md
 FP32_MFMA_PEAK = 157.3e12
+CONV_SOURCES = ["conv_mfma2.hip", "conv_mx.hip", "common.h", "api.cpp"]
 
 
-def cpu_baseline(sd, seconds_budget=25.0):
-    """The CPU oracle (port of the reference arithmetic) timed on this box's host cores, bounded sample."""
+def cpu_baseline(sd, seconds_budget=30.0):
+    """The CPU oracle (port of the reference arithmetic) timed on this box's host cores: N in {1, 8}, every core, best of
+    up to 3 repeats each within a bounded time budget."""
     from disentangledcolorization_amd import synth
     from disentangledcolorization_amd.gamut import gamut_points
     from oracle.disco_ref import DiscoOracle
 
-    cores = min(os.cpu_count() or 1, 32)      # oneDNN convs of this size stop scaling (and thrash) beyond ~32 threads
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     oracle = DiscoOracle(sd, gamut_points(), n_clusters=8)
-    n = 1
-    gray, ab = synth.synth_inputs(n, 256, 256, seed=5)
-    np.random.seed(130)
-    t0 = time.time(); oracle.forward(gray, ab); warm = time.time() - t0
-    best, reps = float("inf"), 0
     t_start = time.time()
-    while reps < 5 and (time.time() - t_start) + warm < seconds_budget:
+    res = {}
+    for n in (1, 8):
+        gray, ab = synth.synth_inputs(n, 256, 256, seed=5)
         np.random.seed(130)
-        t0 = time.time(); oracle.forward(gray, ab); best = min(best, time.time() - t0); reps += 1
-    if reps == 0:
-        best = warm
-    return {"value": round(n / best, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle/disco_ref.py forward, N=%d 256x256, best of %d after 1 warm-up, torch %d threads"
-                      % (n, max(reps, 1), cores)}
+        t0 = time.time(); oracle.forward(gray, ab); first = time.time() - t0      # warm-up (thread pool, allocator)
+        best, reps = float("inf"), 0
+        while reps < 3 and (time.time() - t_start) + min(best, first) < seconds_budget * (0.45 if n == 1 else 1.0):
+            np.random.seed(130)
+            t0 = time.time(); oracle.forward(gray, ab); best = min(best, time.time() - t0); reps += 1
+        res[n] = (n / min(best, first), max(reps, 1))
+    n_best = max(res, key=lambda k: res[k][0])
+    return {"value": round(res[n_best][0], 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "by_batch": {str(k): round(v[0], 3) for k, v in res.items()},
+            "sample": "oracle/disco_ref.py forward (torch CPU, %d threads), 256x256, N=1 and N=8, best of <=3 after a warm-up; value = the better of the two (N=%d)"
+                      % (cores, n_best)}
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in CONV_SOURCES:
+        with open(os.path.join(REPO, "disentangledcolorization_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic():
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE; profiles/r01_pmc_traffic.json).  PMC counters cannot be read from inside a timed run."""
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE x2 gfx950 correction
+    + WRITE_SIZE).  PMC counters cannot be read from inside a timed run, so the file carries the hash of the kernel sources it
+    was measured on; a stale file is reported as null rather than as a number."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+        with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
+            d = json.load(f)
+        return d["hbm_bytes_per_launch"] if d.get("source_hash") == source_hash() else None
     except Exception:
         return None
+
+
+def fake_forward(gray, ab, T, idx, pos, fstream, fbases, want):
+    """DISCO_BENCH_FAKE: CPU stand-in with the model's output contract (depends on the per-image k-means rows)."""
+    n, _, H, W = gray.shape
+    h, w = H // 16, W // 16
+    d = torch.as_tensor(idx if idx is not None else pos, dtype=torch.float32)
+    pred = torch.tanh(gray.repeat(1, 2, 1, 1) * 0.5 + d.sum(1).reshape(n, 1, 1, 1) * 1e-3)
+    mask = torch.zeros(n, h * w)
+    mask.scatter_add_(1, torch.as_tensor(idx if idx is not None else pos, dtype=torch.long), torch.ones(n, d.shape[1]))
+    return (None, None, pred, None, None, mask.reshape(n, 1, h, w)), (np.zeros(n, np.int32) if want else None)
 
 
 def main():
@@ -69,11 +103,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0, help="fix the TOTAL batch instead (tests; ragged shards allowed)")
+    ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="mx8", choices=["mx8", "mx8all", "f16x3", "f16x1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--micro", type=int, default=1, help="micro-batches per GPU, each on its own HIP stream")
     args = ap.parse_args()
+    fake = os.environ.get("DISCO_BENCH_FAKE") == "1"
 
     # stdout carries exactly one JSON line: native libraries (RCCL's version banner, HIP runtime notices) write to fd 1
     # directly, so fd 1 points at stderr until the result is printed
@@ -86,97 +123,126 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if fake else torch.device("cuda", local_rank)
+    if not fake:
+        torch.cuda.set_device(local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if fake:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    sync = (lambda: None) if fake else torch.cuda.synchronize
 
     from disentangledcolorization_amd import synth
-    from disentangledcolorization_amd.model import AnchorColorProb
     from disentangledcolorization_amd.runner import ShardedColorizer, shard_bounds
 
-    sd = synth.synth_state_dict(130)
-    model = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, n_clusters=8,
-                            enhanced=True, precision=args.precision, init_weights=False)
-    model.load_state_dict(sd)
-    model = model.cuda().eval()
-    model.sync_kmeans_events = False          # no host sync inside the timed region
-    model.set_profiling(2)                    # hipEvent pairs around every conv3x3_mfma launch (and stage marks)
-    n_global = args.batch * world
+    n_global = args.global_batch if args.global_batch > 0 else args.batch * world
     lo, hi = shard_bounds(n_global, world, rank)
-    gray_all, ab_all = synth.synth_inputs(n_global, 256, 256, seed=5)
-    gray, ab = gray_all[lo:hi].cuda(), ab_all[lo:hi].cuda()    # inputs resident in HBM before timing
-    runner = ShardedColorizer.from_model(model, micro_batches=args.micro)
+    gray_all, ab_all = synth.synth_inputs(n_global, args.size, args.size, seed=5)
+    gray, ab = gray_all[lo:hi].to(dev), ab_all[lo:hi].to(dev)    # inputs resident in HBM before timing
+    model = sd = None
+    if fake:
+        runner = ShardedColorizer(fake_forward, n_clusters=8, micro_batches=args.micro, exact_fallback=False)
+    else:
+        from disentangledcolorization_amd.model import AnchorColorProb
+        sd = synth.synth_state_dict(130)
+        model = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, n_clusters=8,
+                                enhanced=True, precision=args.precision, init_weights=False)
+        model.load_state_dict(sd)
+        model = model.cuda().eval()
+        model.set_profiling(2)                    # hipEvent pairs around every MFMA conv launch (and stage marks)
+        runner = ShardedColorizer.from_model(model, micro_batches=args.micro, exact_fallback=False)   # no host sync while timing
+
+    def seed():
+        np.random.seed(130); torch.manual_seed(130)
 
     def step():
-        # batch k's all-gather is enqueued behind its forward on the communication stream and overlaps with batch k+1's
-        # convolutions; everything is complete at the synchronize() that closes the timed region
-        np.random.seed(130)
+        # batch k's all-gather is enqueued behind its forward and overlaps with batch k+1's convolutions; everything is
+        # complete at the synchronize() that closes the timed region
+        seed()
         return runner.colorize(gray, ab, n_global, 0, gather=True, async_gather=True)
 
     # initialisation (untimed, not counted as warm-up): the first forward creates the native context (weight fold / pack /
-    # upload) and sizes the workspace; a second one lets clocks and the caching allocator settle on a fresh box
+    # upload / calibration) and sizes the workspace; a second one lets clocks and the caching allocator settle
     for _ in range(2):
         step()
     runner.wait()
-    torch.cuda.synchronize()
+    sync()
     for _ in range(args.warmup):
         step()
     runner.wait()
-    conv_ms = conv_fl = 0.0
-    conv_launches = 0
-    stage_ms = {}
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step()          # asynchronous: no host sync inside the timed region; every conv launch is event-bracketed
+        last = step()   # asynchronous: no host sync inside the timed region; every conv launch is event-bracketed
     runner.wait()       # the outstanding all-gathers (N > 1)
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    # per-launch hipEvent timings of the LAST timed step (the context keeps the events of its latest forward)
-    nl, ms, fl = model.conv_profile()
-    conv_bytes = model.conv_profile_bytes() / max(nl, 1)
-    conv_launches, conv_ms, conv_fl = nl * args.steps, ms * args.steps, fl * args.steps
-    for name, sms, _ in model.profile():
-        stage_ms[name] = sms * args.steps
+    checksum = zlib.crc32(last[1].cpu().numpy().tobytes(), zlib.crc32(last[0].cpu().numpy().tobytes()))
+    conv_ms = conv_fl = conv_bytes = 0.0
+    conv_launches = 0
+    stage_ms = {}
+    if model is not None:
+        # per-launch hipEvent timings of the LAST timed step (the context keeps the events of its latest forward)
+        nl, ms, fl = model.conv_profile()
+        conv_bytes = model.conv_profile_bytes() / max(nl, 1)
+        conv_launches, conv_ms, conv_fl = nl * args.steps, ms * args.steps, fl * args.steps
+        for name, sms, _ in model.profile():
+            stage_ms[name] = sms * args.steps
     if use_dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # registers-only MFMA loop on the same operand mix (after the timed region): the rate the power-managed clock
-    # sustains for this data, i.e. the practical ceiling under the 2.5 PFLOP/s datasheet peak
-    sustained = None
-    if rank == 0:
-        import ctypes
+    # ---- after the timed region: was the timed path the reference-exact one?  One synchronised forward of the same batch:
+    # the empty-cluster event counts must all be zero (then reading every image's fallback rows from the start of the draw
+    # stream, as the timed loop does, changes nothing) and no fp8 activation may have been clamped.
+    events = sat = 0
+    if model is not None:
+        exact = ShardedColorizer.from_model(model, exact_fallback=True)
+        seed()
+        p_exact, m_exact = exact.colorize(gray, ab, n_global, 0, gather=True)
+        sync()
+        events = int(exact.last_events.sum())
+        same = bool(torch.equal(p_exact, last[0]) and torch.equal(m_exact, last[1]))
         from disentangledcolorization_amd import _ffi
-        tf = ctypes.c_double(0.0)
-        _ffi.check(_ffi.lib().disco_diag_mfma_rate(2 if args.precision == "f16x3" else 1, 8000, ctypes.byref(tf)))
-        sustained = tf.value
-        _ffi.check(_ffi.lib().disco_diag_mfma_rate(3, 8000, ctypes.byref(tf)))     # pixel operands non-negative, half zeros
-        sustained_relu = tf.value
+        import ctypes
+        c64 = ctypes.c_uint64(0)
+        _ffi.check(_ffi.lib().disco_saturation_count(model._ctx, _ffi.current_stream(), ctypes.byref(c64)))
+        sat = int(c64.value)
+        if events != 0 or not same:
+            raise SystemExit("bench: the timed (unsynchronised) forward is not the reference-exact one: kmeans_events=%d, "
+                             "identical to the synchronised forward: %s" % (events, same))
 
     if rank == 0:
         ips = n_global * args.steps / elapsed
-        achieved = conv_fl / (conv_ms * 1e-3) if conv_ms > 0 else 0.0
-        executed = (3 if args.precision == "f16x3" else 1) * achieved / 1e12
         out = {
             "metric": "colorized 256x256 images/sec", "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16x3 (fp16 hi/lo split operands, fp32 accumulate)" if args.precision == "f16x3" else "f16",
+            "dtype": {"mx8": "f16x3 (fp16 hi/lo split, 3 MFMA products) for SpixelNet+ColorProbNet; f16+fp8x2 (fp16 main product + two fp8 e4m3 "
+                             "correction products in one K=64 MFMA) for HourGlass2; fp32 accumulate",
+                      "mx8all": "f16+fp8x2 (fp16 main product + two fp8 e4m3 correction products), fp32 accumulate - not anchor-safe",
+                      "f16x3": "f16x3 (fp16 hi/lo split operands, fp32 accumulate)", "f16x1": "f16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE config 2: batch=64/GPU synthetic 256x256 L-channel, K=8 clustering anchors, "
                                    "forward only, synthetic checkpoint of the DISCO layout", "images_per_gpu": args.batch,
-                       "global_batch": n_global, "parallelism": "batch-sharded x%d, all-gather of pred_colors+hint_mask" % world},
-            "roofline": {
-                "bound": "mfma", "kernel": "conv3x3_mfma_kernel (all instantiations)",
+                       "global_batch": n_global, "image_size": args.size,
+                       "parallelism": "batch-sharded x%d, one packed all-gather of pred_colors+hint_mask" % world},
+            "kmeans_events": events, "fp8_saturated_elements": sat, "result_checksum": "%08x" % checksum,
+        }
+        if model is not None:
+            achieved = conv_fl / (conv_ms * 1e-3) if conv_ms > 0 else 0.0
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv3x3_mfma2_kernel + conv3x3_mx_kernel (all instantiations)",
                 "achieved": round(achieved / 1e12, 2), "peak": FP16_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic(),
                 "launches_per_step": conv_launches // max(args.steps, 1),
@@ -184,16 +250,13 @@ def main():
                 "algorithmic_gflop_per_launch": round(conv_fl / max(conv_launches, 1) / 1e9, 3),
                 "algorithmic_hbm_bytes_per_launch": int(conv_bytes),
                 "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK, 4),
-                "executed_mfma_tflops": round(executed, 2),
-                "sustained_mfma_tflops_same_operand_mix": round(sustained, 1),
-                "executed_frac_of_sustained": round(executed / sustained, 4) if sustained else None,
-                "sustained_mfma_tflops_relu_like_operands": round(sustained_relu, 1),
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
-            },
-            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd)
+                "power_limited_mfma_ceilings_tflops_algorithmic": {"f16x3": 439, "f16+fp8x2": 891,
+                                                                   "source": "profiles/r02_mfma_mix.txt (registers-only loops, random operands)"},
+            }
+            out["stage_ms_per_step"] = {k: round(v / args.steps, 3) for k, v in stage_ms.items()}
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(sd)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

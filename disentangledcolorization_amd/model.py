@@ -286,11 +286,19 @@ class AnchorColorProb(nn.Module):
     def forward(self, input_grays, input_colors, test_mode=False, sampled_T=0):
         return self.forward_with_draws(input_grays, input_colors, test_mode, sampled_T)
 
-    @torch.no_grad()
-    def forward_with_draws(self, input_grays, input_colors, test_mode=True, sampled_T=0, init_idx=None, hint_pos=None):
-        """forward() with the host-side draws supplied by the caller (runner.py draws them once for the
-        global batch so that results do not depend on the number of GPUs): init_idx (n,K) k-means rows,
-        hint_pos (n,K) random-hint tokens.  None = draw from the global generators like the reference."""
+    def train(self, mode=True):
+        """eval() is a no-op like on any frozen module; training is outside the hot path."""
+        if mode:
+            raise NotImplementedError("the MI355X hot path is inference only: AnchorColorProb.train() is not available")
+        return super().train(False)
+
+    def _replicate_for_data_parallel(self):
+        raise NotImplementedError(
+            "nn.DataParallel cannot replicate the native context of AnchorColorProb (its replicas carry no parameters). "
+            "Run one process per GPU and shard the batch with disentangledcolorization_amd.runner.ShardedColorizer, or pin "
+            "the process to one GPU (HIP_VISIBLE_DEVICES); see INTEGRATION.md.")
+
+    def _check_inputs(self, input_grays, input_colors, test_mode):
         test_mode = bool(test_mode)
         if not test_mode and self.hint2regress:
             raise NotImplementedError("hint2regress has no test_mode=False forward: models/model.py:178 raises NameError")
@@ -302,28 +310,54 @@ class AnchorColorProb(nn.Module):
         n, _, H, W = gray.shape
         if gray.shape[1] != 1 or ab.shape != (n, 2, H, W):
             raise ValueError("expected gray (N,1,H,W) and ab (N,2,H,W)")
+        if H % self.sp_size or W % self.sp_size:
+            raise ValueError("H and W must be multiples of %d" % self.sp_size)
+        return test_mode, gray, ab
+
+    def max_fallback(self):
+        """Upper bound of empty-cluster draws one image can consume (clusterkit.py:176-182: K-1 per pass, 20 passes)."""
+        return KMEANS_ITERS * self.hint_num
+
+    @torch.no_grad()
+    def forward_once(self, input_grays, input_colors, test_mode=True, sampled_T=0, init_idx=None, hint_pos=None,
+                     fallback_stream=None, fallback_bases=None, want_events=True):
+        """ONE native forward with every host-side draw supplied by the caller; consumes no generator state.
+        init_idx (n,K) k-means rows / hint_pos (n,K) random-hint tokens; fallback_stream: the values successive
+        torch.randint(L,(1,)) calls would return (a prefix of the reference's global draw stream), fallback_bases (n,):
+        where in that stream image i's empty-cluster draws start.  Returns (6-tuple, events) with events (n,) int32 =
+        draws each image consumed (None when want_events is False: no host synchronisation then)."""
+        test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
+        dev = gray.device
+        n, _, H, W = gray.shape
         sp = self.sp_size
-        if H % sp or W % sp:
-            raise ValueError("H and W must be multiples of %d" % sp)
         h, w = H // sp, W // sp
         l = h * w
         T = int(sampled_T) if test_mode else 0      # the validation forward ignores sampled_T (model.py:169-171)
         rep = 3 if T > 0 else 1
+        K = self.hint_num
+        if self.random_hint:
+            if hint_pos is None or np.shape(hint_pos) != (n, K):
+                raise ValueError("hint_pos must be (n, n_clusters) = (%d, %d), got %s" % (n, K, np.shape(hint_pos)))
+            hint_pos = np.ascontiguousarray(hint_pos, dtype=np.int32)
+        else:
+            if init_idx is None or np.shape(init_idx) != (n, K):
+                raise ValueError("init_idx must be (n, n_clusters) = (%d, %d), got %s" % (n, K, np.shape(init_idx)))
+            init_idx = np.ascontiguousarray(init_idx, dtype=np.int32)
         max_imgs = max(1, MAX_ACT_BYTES // (64 * H * W * 4 * rep))
         if n > max_imgs:
-            # images are independent: run the batch in slices (the host draws are made once, in image order, exactly
-            # as for a single call) and concatenate
-            if self.random_hint:
-                hint_pos = self._random_hints(n, l) if hint_pos is None else np.ascontiguousarray(hint_pos, dtype=np.int32)
-            else:
-                init_idx = self._kmeans_init(n, l) if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.int32)
-            parts = [self.forward_with_draws(gray[i:i + max_imgs], ab[i:i + max_imgs], test_mode, sampled_T,
-                                             None if init_idx is None else init_idx[i:i + max_imgs],
-                                             None if hint_pos is None else hint_pos[i:i + max_imgs])
-                     for i in range(0, n, max_imgs)]
-            return tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
+            # images are independent: run the batch in slices and concatenate
+            parts, evs = [], []
+            for i in range(0, n, max_imgs):
+                j = min(n, i + max_imgs)
+                o, e = self.forward_once(gray[i:j], ab[i:j], test_mode, sampled_T, None if init_idx is None else init_idx[i:j],
+                                         None if hint_pos is None else hint_pos[i:j], fallback_stream,
+                                         None if fallback_bases is None else fallback_bases[i:j], want_events)
+                parts.append(o); evs.append(e)
+            outs = tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
+            return outs, (np.concatenate(evs) if want_events and not self.random_hint else (np.zeros(n, np.int32) if want_events else None))
         n2 = n * rep
         L = _ffi.lib()
+        events = None
         with torch.cuda.device(dev):
             ctx = self._context(dev)
             L.disco_set_profiling(ctx, int(getattr(self, "_profiling", 0)))
@@ -357,42 +391,70 @@ class AnchorColorProb(nn.Module):
             a.d_workspace, a.workspace_bytes = wsb.data_ptr(), wsb.numel()
             a.stream = stream_ptr
             if self.random_hint:
-                hint_pos = self._random_hints(n, l) if hint_pos is None else np.ascontiguousarray(hint_pos, dtype=np.int32)
                 a.h_hint_pos = hint_pos.ctypes.data
                 _ffi.check(L.disco_forward(ctx, C.byref(a)))
                 self._keep = (hint_pos,)
+                events = np.zeros(n, np.int32) if want_events else None
             else:
-                init_idx = self._kmeans_init(n, l) if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.int32)
-                if init_idx.shape != (n, self.hint_num):
-                    raise ValueError("init_idx must be (n, n_clusters)")
-                MAX_FALLBACK = KMEANS_ITERS * self.hint_num
+                MF = self.max_fallback()
                 a.h_init_idx = init_idx.ctypes.data
-                a.max_fallback = MAX_FALLBACK
-                draws = np.asarray(self._peek_randint(l, MAX_FALLBACK * 2), dtype=np.int32)
-                bases = [0] * n
-                events = np.zeros(n, np.int32)
-                for _ in range(n + 1):
-                    while len(draws) < max(bases) + MAX_FALLBACK:
-                        draws = np.asarray(self._peek_randint(l, len(draws) * 2), dtype=np.int32)
-                    rows = np.ascontiguousarray(draws[np.asarray(bases)[:, None] + np.arange(MAX_FALLBACK)[None, :]])
-                    a.h_fallback_rows = rows.ctypes.data
-                    a.h_kmeans_events = events.ctypes.data if self.sync_kmeans_events else None
-                    _ffi.check(L.disco_forward(ctx, C.byref(a)))
-                    if not self.sync_kmeans_events:
-                        break
-                    if int(events.max()) > MAX_FALLBACK:
-                        raise _ffi.DiscoError("k-means used more than %d empty-cluster draws" % MAX_FALLBACK)
-                    new_bases = [0] + list(np.cumsum(events)[:-1])
-                    if new_bases == bases:
-                        break
-                    bases = [int(b) for b in new_bases]   # an earlier image consumed draws: shift and redo
-                if self.sync_kmeans_events:
-                    for _ in range(int(events.sum())):      # consume what the reference would have consumed
-                        torch.randint(l, (1,))
+                a.max_fallback = MF
+                bases = np.zeros(n, np.int64) if fallback_bases is None else np.asarray(fallback_bases, dtype=np.int64)
+                if bases.shape != (n,):
+                    raise ValueError("fallback_bases must be (n,)")
+                stream_arr = np.asarray(fallback_stream if fallback_stream is not None else self._peek_randint(l, MF), dtype=np.int32)
+                if len(stream_arr) < int(bases.max()) + MF:
+                    raise ValueError("fallback_stream holds %d draws, image bases need %d" % (len(stream_arr), int(bases.max()) + MF))
+                rows = np.ascontiguousarray(stream_arr[bases[:, None] + np.arange(MF)[None, :]])
+                a.h_fallback_rows = rows.ctypes.data
+                events = np.zeros(n, np.int32) if want_events else None
+                a.h_kmeans_events = events.ctypes.data if want_events else None
+                _ffi.check(L.disco_forward(ctx, C.byref(a)))
+                if want_events and int(events.max()) > MF:
+                    raise _ffi.DiscoError("k-means used more than %d empty-cluster draws" % MF)
                 self._keep = (init_idx, rows, events)
         if rep > 1:
             aff_out = aff.expand(rep, -1, -1, -1) if n == 1 else aff.repeat_interleave(rep, 0)
             mask_out = mask.expand(rep, -1, -1, -1) if n == 1 else mask.repeat_interleave(rep, 0)
         else:
             aff_out, mask_out = aff, mask
-        return pal, ref, pred, aff_out, spix, mask_out
+        return (pal, ref, pred, aff_out, spix, mask_out), events
+
+    @torch.no_grad()
+    def forward_with_draws(self, input_grays, input_colors, test_mode=True, sampled_T=0, init_idx=None, hint_pos=None):
+        """The reference's single-process semantics: host-side draws come from the global generators the reference
+        consumes (NumPy legacy RandomState for the k-means rows, Python `random` for random hints, torch's CPU generator
+        for empty-cluster fallbacks, clusterkit.py:181-182) unless supplied, and torch's generator advances by exactly the
+        number of fallback draws the reference would have made, in image order.  With sync_kmeans_events = False there is
+        no host synchronisation: every image reads fallback rows from the start of the stream and nothing is consumed -
+        exact only while no empty-cluster event occurs (check `last_kmeans_events()` / bench.py's `kmeans_events`)."""
+        test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
+        n, _, H, W = gray.shape
+        l = (H // self.sp_size) * (W // self.sp_size)
+        if self.random_hint:
+            hint_pos = self._random_hints(n, l) if hint_pos is None else hint_pos
+            return self.forward_once(gray, ab, test_mode, sampled_T, None, hint_pos, want_events=False)[0]
+        init_idx = self._kmeans_init(n, l) if init_idx is None else init_idx
+        MF = self.max_fallback()
+        if not self.sync_kmeans_events:
+            return self.forward_once(gray, ab, test_mode, sampled_T, init_idx, None, self._peek_randint(l, MF), None, want_events=False)[0]
+        stream = np.asarray(self._peek_randint(l, MF * 2), dtype=np.int32)
+        bases = np.zeros(n, np.int64)
+        for _ in range(n + 1):
+            while len(stream) < int(bases.max()) + MF:
+                stream = np.asarray(self._peek_randint(l, len(stream) * 2), dtype=np.int32)
+            out, events = self.forward_once(gray, ab, test_mode, sampled_T, init_idx, None, stream, bases)
+            new_bases = np.concatenate(([0], np.cumsum(events)[:-1])).astype(np.int64)
+            # an image's rows matter only if it drew any: redo when an image that consumed draws started at the wrong place
+            if not np.any((events > 0) & (new_bases != bases)):
+                break
+            bases = new_bases
+        for _ in range(int(events.sum())):      # consume what the reference would have consumed
+            torch.randint(l, (1,))
+        self._last_events = events
+        return out
+
+    def last_kmeans_events(self):
+        """Per-image empty-cluster draws of the latest synchronised forward (None if there was none)."""
+        return getattr(self, "_last_events", None)
+

@@ -130,3 +130,27 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 assert not pat.search(open(os.path.join(root, f)).read()), f
+
+
+def test_dataparallel_and_train_are_refused_with_a_pointer_to_the_runner():
+    """inference.py:76-82 wraps the model in nn.DataParallel on multi-GPU hosts; its replicas carry no parameters, so the
+    native context cannot be rebuilt there: the replication hook must fail loudly and name the supported way.  train()
+    raises like INTEGRATION.md says (eval() stays a no-op)."""
+    from disentangledcolorization_amd.model import AnchorColorProb
+
+    m = AnchorColorProb(n_clusters=8, enhanced=True, init_weights=False)
+    assert m.eval() is m
+    with pytest.raises(NotImplementedError, match="inference only"):
+        m.train()
+    with pytest.raises(NotImplementedError, match="ShardedColorizer"):
+        torch.nn.DataParallel(m).module._replicate_for_data_parallel()
+
+
+def test_mx_weight_pack_and_fp8_codec(lib):
+    """The host side of the fp8-corrected conv: packed size, and that the packer is callable without a device (bytes only)."""
+    nb = C.c_size_t()
+    assert lib.disco_op_conv3x3_mx_pack(None, 64, 65, None, None, C.byref(nb)) == 0
+    assert nb.value == 2 * (96 // 16) * 9 * 2 * 1024     # 2 cout blocks x 3 groups of 32 channels x {H,Q} chunks x 9 taps x 2 KiB
+    assert lib.disco_op_conv3x3_mx(None, None, None, None, None, None, None, None, None, None, None, None) < 0
+    ab = C.c_size_t()
+    assert lib.disco_op_act_bytes(2, 64, 8, 8, _ffi.PLANE_LO | _ffi.PLANE_Q, C.byref(ab)) == 0 and ab.value == 2 * 64 * 64 * 6

@@ -1,8 +1,12 @@
-"""The N>1 path on CPU: world_size-2 gloo processes shard a batch, run a forward, all-gather — results must equal
-the single-process run bit for bit (anchors included).  The forward here is the CPU oracle's token path on
-precomputed features (the HIP forward needs a GPU); what is under test is runner.py's sharding, global draws and
-the collective."""
+"""The N>1 path on CPU: world_size-2 (and 3) gloo processes shard a batch, run a forward, exchange k-means event counts,
+all-gather the packed results - everything must equal the single-process run bit for bit (anchors included).
+The forward here is a cheap CPU stand-in with the model's contract (the HIP forward needs a GPU) whose results depend on
+the per-image k-means rows AND on the empty-cluster fallback rows it is handed; what is under test is runner.py: sharding,
+global draws, the rank-invariant fallback stream, the packed collective, ragged and empty shards, and bench.py's
+distributed scaffolding (the same code path the 8-GPU run takes, on the gloo backend)."""
+import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -14,64 +18,155 @@ import torch.multiprocessing as mp
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-from disentangledcolorization_amd.runner import ShardedColorizer, global_draws, shard_bounds  # noqa: E402
+from disentangledcolorization_amd.runner import ShardedColorizer, global_draws, peek_randint, shard_bounds  # noqa: E402
 
 
-def _fake_forward(gray, ab, T, idx, pos):
-    """Cheap deterministic stand-in with the model's output contract; depends on the per-image draws."""
+def _n_events(gray_i):
+    """Images whose mean is positive 'hit empty clusters': 1..3 fallback draws, decided by the data alone."""
+    m = float(gray_i.mean())
+    return 0 if m <= 0 else 1 + int(abs(m) * 1e4) % 3
+
+
+def _fake_forward(gray, ab, T, idx, pos, fstream, fbases, want):
+    """Deterministic stand-in with the model's output contract; depends on the per-image draws and on the fallback rows."""
     n, _, H, W = gray.shape
     h, w = H // 16, W // 16
-    base = gray.mean(dim=(1, 2, 3)).reshape(n, 1, 1, 1)
     d = torch.as_tensor(idx if idx is not None else pos, dtype=torch.float32)
-    pred = torch.tanh(gray.repeat(1, 2, 1, 1) * 0.5 + d.sum(1).reshape(n, 1, 1, 1) * 1e-3)
+    extra = torch.zeros(n)
+    events = np.zeros(n, np.int32)
+    if fstream is not None:
+        bases = np.zeros(n, np.int64) if fbases is None else np.asarray(fbases)
+        for i in range(n):
+            events[i] = _n_events(gray[i])
+            extra[i] = float(np.sum(fstream[bases[i]: bases[i] + events[i]].astype(np.float64) * (1 + np.arange(events[i]))))
+    rep = 3 if T > 0 else 1
+    pred = torch.tanh(gray.repeat(1, 2, 1, 1) * 0.5 + d.sum(1).reshape(n, 1, 1, 1) * 1e-3 + extra.reshape(n, 1, 1, 1) * 1e-4)
     mask = torch.zeros(n, h * w)
     mask.scatter_add_(1, torch.as_tensor(idx if idx is not None else pos, dtype=torch.long), torch.ones(n, d.shape[1]))
-    return (None, None, pred, None, None, mask.reshape(n, 1, h, w))
+    pred, mask = pred.repeat_interleave(rep, 0), mask.repeat_interleave(rep, 0)
+    return (None, None, pred, None, None, mask.reshape(n * rep, 1, h, w)), (events if want else None)
 
 
-def _worker(rank, world, port, n_global, random_hint, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import random
-    np.random.seed(130); random.seed(130)
+def _inputs(n_global):
     g = torch.Generator().manual_seed(1)
     gray = torch.rand(n_global, 1, 64, 64, generator=g) * 2 - 1
-    ab = torch.zeros(n_global, 2, 64, 64)
+    gray += torch.linspace(-0.02, 0.02, n_global).reshape(-1, 1, 1, 1)       # a mix of images with and without "events"
+    return gray, torch.zeros(n_global, 2, 64, 64)
+
+
+def _seed():
+    import random
+    np.random.seed(130); random.seed(130); torch.manual_seed(130)
+
+
+def _expected(n_global, random_hint, T=0):
+    """The reference semantics computed directly: one sequential pass over the global batch."""
+    gray, ab = _inputs(n_global)
+    _seed()
+    idx, pos = global_draws(n_global, 16, 4, random_hint)
+    stream = peek_randint(16, 20 * 4 * 4)
+    ev = np.array([0 if random_hint else _n_events(gray[i]) for i in range(n_global)])
+    bases = np.concatenate(([0], np.cumsum(ev)[:-1]))
+    (_, _, pred, _, _, mask), _ = _fake_forward(gray, ab, T, idx, pos, None if random_hint else stream, bases, True)
+    return pred, mask, int(ev.sum())
+
+
+def _worker(rank, world, port, n_global, random_hint, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gray, ab = _inputs(n_global)
     lo, hi = shard_bounds(n_global, world, rank)
-    sc = ShardedColorizer(_fake_forward, n_clusters=4, random_hint=random_hint)
-    pred, mask = sc.colorize(gray[lo:hi], ab[lo:hi], n_global)
+    sc = ShardedColorizer(_fake_forward, n_clusters=4, random_hint=random_hint, max_fallback=16)
+    _seed()
+    stream = peek_randint(16, 64)
+    pred, mask = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, T)
+    consumed = 0 if random_hint else int(sc.last_events.sum())
+    nxt = int(torch.randint(16, (1,)))                 # the torch generator advanced by exactly the global number of draws
+    assert nxt == int(stream[consumed]), (nxt, consumed)
     # pipelined form used by bench.py: two batches in flight, collectives only enqueued, completed by wait()
-    np.random.seed(130); random.seed(130)
-    p1, m1 = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, async_gather=True)
-    np.random.seed(130); random.seed(130)
-    p2, m2 = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, async_gather=True)
+    _seed()
+    p1, m1 = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, T, async_gather=True)
+    _seed()
+    p2, m2 = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, T, async_gather=True)
     sc.wait()
     assert not sc._pending
     for a, b in ((p1, pred), (p2, pred), (m1, mask), (m2, mask)):
         assert torch.equal(a, b)
-    q.put((rank, pred.numpy(), mask.numpy()))
+    q.put((rank, pred.numpy(), mask.numpy(), consumed))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_global,random_hint", [(6, False), (5, False), (4, True)])
-def test_two_rank_gloo_equals_single_process(n_global, random_hint):
-    import random
-    np.random.seed(130); random.seed(130)
-    g = torch.Generator().manual_seed(1)
-    gray = torch.rand(n_global, 1, 64, 64, generator=g) * 2 - 1
-    ab = torch.zeros(n_global, 2, 64, 64)
-    want_pred, want_mask = ShardedColorizer(_fake_forward, 4, random_hint).colorize(gray, ab, n_global)
+@pytest.mark.parametrize("n_global,world,random_hint,T", [(6, 2, False, 0), (5, 2, False, 0), (4, 2, True, 0), (7, 3, False, 0),
+                                                          (2, 3, False, 0), (3, 2, False, 2)])
+def test_multi_rank_gloo_equals_reference_semantics(n_global, world, random_hint, T):
+    """(5,2) and (7,3): ragged shards; (2,3): one rank holds no image at all; (3,2,T=2): diverse (3 outputs per image)."""
+    want_pred, want_mask, want_events = _expected(n_global, random_hint, T)
+    assert random_hint or want_events > 0, "the case must exercise the fallback stream"
+    # a single process through the runner must agree with the direct computation as well
+    gray, ab = _inputs(n_global)
+    _seed()
+    sp, sm = ShardedColorizer(_fake_forward, 4, random_hint, max_fallback=16).colorize(gray, ab, n_global, T)
+    assert torch.equal(sp, want_pred) and torch.equal(sm, want_mask)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_global, random_hint, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + n_global * 13 + world) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, random_hint, T, q)) for r in range(world)]
     for p in procs: p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
+    got = [q.get(timeout=180) for _ in range(world)]
     for p in procs: p.join(timeout=60)
-    for rank, pred, mask in got:
+    for rank, pred, mask, consumed in got:
         assert np.array_equal(pred, want_pred.numpy()), rank
         assert np.array_equal(mask, want_mask.numpy()), rank
+        assert consumed == want_events
+
+
+def test_ranks_with_different_seeds_are_detected():
+    """The exchange carries a checksum of the draws: a rank that seeded differently must fail loudly, not diverge."""
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import test_dist_gloo as T
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo")
+gray, ab = T._inputs(4)
+lo, hi = T.shard_bounds(4, 2, rank)
+np.random.seed(130 + rank); torch.manual_seed(130)
+try:
+    T.ShardedColorizer(T._fake_forward, 4, False, max_fallback=16).colorize(gray[lo:hi], ab[lo:hi], 4)
+    print("NOT DETECTED")
+except RuntimeError as e:
+    print("DETECTED" if "seed" in str(e) else "OTHER " + str(e))
+dist.destroy_process_group()
+''' % (REPO, REPO)
+    port = 31500 + os.getpid() % 1000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all("DETECTED" in o and "NOT DETECTED" not in o for o in outs), outs
+
+
+def test_bench_distributed_scaffolding_on_gloo():
+    """bench.py's own N>1 code path (process group, shard, async packed all-gather, closing barrier, max-over-ranks time)
+    with an injected CPU forward on the gloo backend: world 2 must report the same result checksum as world 1 on the same
+    global batch."""
+    lines = {}
+    for world in (1, 2):
+        port = 33500 + (os.getpid() + world) % 1000
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), DISCO_BENCH_FAKE="1")
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+               "--global-batch", "6", "--size", "64", "--no-cpu-baseline"]
+        procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for r in range(world)]
+        outs = [p.communicate(timeout=300) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+        line = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+        assert len(line) == 1, outs[0]
+        assert all(not [l for l in o[0].splitlines() if l.startswith("{")] for o in outs[1:]), "only rank 0 prints"
+        lines[world] = json.loads(line[0])
+    assert lines[1]["n_gpus"] == 1 and lines[2]["n_gpus"] == 2
+    assert lines[1]["result_checksum"] == lines[2]["result_checksum"]
+    assert lines[2]["config"]["global_batch"] == 6 and lines[2]["value"] > 0
 
 
 def test_shard_bounds_cover_batch():
