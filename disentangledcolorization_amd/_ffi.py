@@ -107,6 +107,7 @@ SIGNATURES = {
     "disco_op_lab2rgb": (_I, [_P, _P, _I, _I, _I, _P]),
     "disco_op_rgb8_to_lab": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_lab_to_rgb8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "disco_op_rgb8_resize_to_lab": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_mark_color_hints": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
 }
 

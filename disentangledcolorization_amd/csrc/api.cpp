@@ -1516,6 +1516,12 @@ int disco_op_rgb8_to_lab(const uint8_t* d_rgb8, float* d_gray, float* d_ab, floa
     return launch_rgb8_to_lab(d_rgb8, d_gray, d_ab, d_rgb, n, h, w, hp, wp, (hipStream_t)stream);
 }
 
+int disco_op_rgb8_resize_to_lab(const uint8_t* d_rgb8, uint8_t* d_resized, float* d_gray, float* d_ab, float* d_rgb, int n, int h, int w,
+                                int ho, int wo, void* stream) {
+    if (!d_rgb8 || !d_gray || !d_ab) { set_error("null argument"); return DISCO_EINVAL; }
+    return launch_rgb8_resize_to_lab(d_rgb8, d_resized, d_gray, d_ab, d_rgb, n, h, w, ho, wo, (hipStream_t)stream);
+}
+
 int disco_op_lab_to_rgb8(const float* d_lab, uint8_t* d_rgb8, int n, int hp, int wp, int h, int w, void* stream) {
     if (!d_lab || !d_rgb8) { set_error("null argument"); return DISCO_EINVAL; }
     return launch_lab_to_rgb8(d_lab, d_rgb8, n, hp, wp, h, w, (hipStream_t)stream);

@@ -93,6 +93,71 @@ __global__ void rgb8_to_lab_kernel(const unsigned char* __restrict__ src, float*
     }
 }
 
+// The DEFAULT input path of main/colorizer/inference.py:32-36: cv2.resize(rgb, (256,256), interpolation=INTER_LINEAR) on the
+// uint8 image, then /255 and RGB->Lab.  cv2 is a third-party dependency (opencv-python==4.6.0.66, environment.yaml:89) that is
+// not available offline; this restates its published algorithm for 8-bit images (modules/imgproc/src/resize.cpp):
+//   * exact 2x downscale in both directions: INTER_LINEAR is replaced by the area path, dst = (a + b + c + d + 2) >> 2;
+//   * otherwise, per axis: f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s, clamped to the image (f = 0 at the borders);
+//     coefficients (1-f, f) are rounded to 11-bit fixed point (x 2048, round half to even); the horizontal pass keeps
+//     S[s] a0 + S[s+1] a1 as a 32-bit integer; the vertical pass is
+//     dst = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2        (VResizeLinear<uchar,...>, bit-exact integer math)
+// with scale = 1 / (dst / src) in double precision.  One thread per destination pixel; the Lab conversion is fused in.
+struct ResizeAxis { int s0, s1; int c0, c1; };
+__device__ inline ResizeAxis resize_axis(int d, int n_src, int n_dst) {
+    const double scale = 1.0 / ((double)n_dst / (double)n_src);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    ResizeAxis a;
+    a.s0 = s; a.s1 = s + 1 < n_src ? s + 1 : n_src - 1;
+    a.c0 = __float2int_rn((1.f - f) * 2048.f);
+    a.c1 = __float2int_rn(f * 2048.f);
+    return a;
+}
+
+__global__ void rgb8_resize_to_lab_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ resized,
+                                          float* __restrict__ gray, float* __restrict__ ab, float* __restrict__ rgbn, int n,
+                                          int H, int W, int Ho, int Wo) {
+    const long hw = (long)Ho * Wo, total = (long)n * hw;
+    const bool area2 = H == 2 * Ho && W == 2 * Wo;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long img = t / hw, p = t - img * hw;
+        const int y = (int)(p / Wo), x = (int)(p - (long)y * Wo);
+        const unsigned char* im = src + img * (long)H * W * 3;
+        int v[3];
+        if (area2) {
+            const unsigned char* q = im + ((long)(2 * y) * W + 2 * x) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = (q[k] + q[3 + k] + q[(long)W * 3 + k] + q[(long)W * 3 + 3 + k] + 2) >> 2;
+        } else {
+            const ResizeAxis ax = resize_axis(x, W, Wo), ay = resize_axis(y, H, Ho);
+            const unsigned char* r0 = im + (long)ay.s0 * W * 3;
+            const unsigned char* r1 = im + (long)ay.s1 * W * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int h0 = r0[ax.s0 * 3 + k] * ax.c0 + r0[ax.s1 * 3 + k] * ax.c1;
+                const int h1 = r1[ax.s0 * 3 + k] * ax.c0 + r1[ax.s1 * 3 + k] * ax.c1;
+                v[k] = (((ay.c0 * (h0 >> 4)) >> 16) + ((ay.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            }
+        }
+        float r[3], l[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (resized) resized[t * 3 + k] = (unsigned char)v[k];
+            r[k] = (float)((double)v[k] / 255.0);
+        }
+        rgb2lab_px(r, l);
+        gray[img * hw + p] = l[0];
+        ab[img * 2 * hw + p] = l[1]; ab[img * 2 * hw + hw + p] = l[2];
+        if (rgbn) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rgbn[(img * 3 + k) * hw + p] = r[k] * 2.f - 1.f;
+        }
+    }
+}
+
 // save_normLabs_from_batch (utils/util.py:91-106) before the encode, with batch_depadding folded in: normalised Lab
 // (n,3,Hp,Wp) -> Lab->RGB -> (rgb*255).astype(uint8) -> (n,H,W,3), top-left crop.  Values above 1 saturate at 255
 // (numpy's float->uint8 cast of out-of-range values is undefined; cv2's LAB2RGB clips to [0,1] before it).
@@ -167,6 +232,14 @@ int launch_rgb8_to_lab(const unsigned char* src, float* gray, float* ab, float* 
     if (n < 1 || H < 1 || W < 1 || Hp < H || Wp < W) { set_error("rgb8_to_lab: bad sizes %dx%dx%d -> %dx%d", n, H, W, Hp, Wp); return DISCO_ESHAPE; }
     hipLaunchKernelGGL(rgb8_to_lab_kernel, dim3(grid_for((long)n * Hp * Wp)), dim3(256), 0, s, src, gray, ab, rgbn, n, H, W, Hp, Wp);
     DISCO_LAUNCH_CHECK("rgb8_to_lab_kernel");
+    return DISCO_OK;
+}
+
+int launch_rgb8_resize_to_lab(const unsigned char* src, unsigned char* resized, float* gray, float* ab, float* rgbn, int n, int H, int W,
+                              int Ho, int Wo, hipStream_t s) {
+    if (n < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || H > 32768 || W > 32768) { set_error("rgb8_resize_to_lab: bad sizes %dx%dx%d -> %dx%d", n, H, W, Ho, Wo); return DISCO_ESHAPE; }
+    hipLaunchKernelGGL(rgb8_resize_to_lab_kernel, dim3(grid_for((long)n * Ho * Wo)), dim3(256), 0, s, src, resized, gray, ab, rgbn, n, H, W, Ho, Wo);
+    DISCO_LAUNCH_CHECK("rgb8_resize_to_lab_kernel");
     return DISCO_OK;
 }
 

@@ -251,6 +251,9 @@ int launch_lab2rgb(const float* lab, float* rgb, long npix_total, long hw, hipSt
 int launch_rgb8_to_lab(const unsigned char* src, float* gray, float* ab, float* rgbn, int n, int H, int W, int Hp, int Wp,
                        hipStream_t s);
 int launch_lab_to_rgb8(const float* lab, unsigned char* dst, int n, int Hp, int Wp, int H, int W, hipStream_t s);
+// cv2.resize(INTER_LINEAR) of uint8 RGB (n,H,W,3) to (Ho,Wo) fused with /255 -> Lab -> split (inference.py:32-40); resized: optional uint8 out
+int launch_rgb8_resize_to_lab(const unsigned char* src, unsigned char* resized, float* gray, float* ab, float* rgbn, int n, int H, int W,
+                              int Ho, int Wo, hipStream_t s);
 int launch_mark_hints(const float* gray, const float* target, const float* gate, const float* base, float* out, int n, int H,
                       int W, int ks, hipStream_t s);
 // annealed-mean decoding (ColorLabel.decode_ind2ab with non-integer T, basic.py:210-217)

@@ -1,29 +1,30 @@
-// conv_mfma2.hip — second-generation 3x3 implicit-GEMM conv for gfx950: same math and packed-weight format
-// as conv_mfma.hip, restructured around the CDNA4 async copy engine:
+// conv_mfma2.hip — 3x3 implicit-GEMM conv for gfx950 on fp16 hi/lo split operands ("f16x3": hi*lo + lo*hi + hi*hi, three
+// v_mfma_f32_32x32x16_f16 per product, fp32 accumulate), built around the CDNA4 async copy engine:
 //
-//   * both operands of a 16-channel chunk (input halo tile, 9 taps of weights) travel HBM/L2 -> LDS with
-//     global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass);
-//   * LDS is double buffered: the DMA of chunk k+1 is issued right after the single barrier of chunk k and
-//     lands while the waves run chunk k's 9 taps of MFMAs; each wave waits only for its own DMA pieces
-//     (s_waitcnt vmcnt(0)) right before that barrier;
-//   * the halo tile is stored 32 B per pixel (16 channels) with a 16-byte XOR swizzle on pixel bit 3 — applied
-//     on the DMA *source* address (the LDS image of a DMA piece is lane-linear) and on the fragment read — so
-//     the 64-lane ds_read_b128 of an A fragment is bank-conflict free; stride-2 tiles are additionally
-//     de-interleaved by column parity so consecutive output pixels read consecutive LDS pixels;
-//   * activations are channel-blocked, [N][C/16][H][W][16] fp16 (hi plane, lo plane), so a tile row of one
-//     16-channel chunk is one contiguous run of 32-byte pixels: the halo DMA and the epilogue's 16-byte
-//     stores touch whole cache lines;
-//   * out-of-image halo pixels DMA from a 16-byte zero word;
+//   * both operands of a 16-channel chunk (input halo tile, 9 taps of weights) travel HBM/L2 -> LDS by LDS-DMA through raw
+//     buffer descriptors (raw_ptr_buffer_load_lds, 16 bytes per lane: no VGPR round trip, no ds_write pass); a lane whose
+//     offset is out of range reads 0 - the hardware range check IS the conv's zero padding;
+//   * LDS is double buffered: the DMA of chunk k+1 is issued in ninths between the 9 taps of chunk k and lands while the
+//     waves run its MFMAs; each wave waits only for its own DMA pieces (s_waitcnt vmcnt(0)) right before the single
+//     barrier of a chunk;
+//   * the halo tile is stored 32 B per pixel (16 channels) with a 16-byte XOR swizzle on pixel bit 3 — applied on the DMA
+//     *source* address (the LDS image of a DMA piece is lane-linear) and on the fragment read — so the 64-lane
+//     ds_read_b128 of a fragment is bank-conflict free; stride-2 tiles are additionally de-interleaved by column parity
+//     so consecutive output pixels read consecutive LDS pixels;
+//   * activations are channel-blocked, [N][C/16][H][W][16] fp16 (hi plane, lo plane), so a tile row of one 16-channel
+//     chunk is one contiguous run of 32-byte pixels: the halo DMA and the epilogue's 16-byte stores touch whole lines;
 //   * 8 waves (2 per SIMD) on a 16x32-pixel x 64-channel tile where the image is large enough;
-//   * persistent workgroups: a workgroup owns one tile position (and N tile) and walks over the images of the
-//     batch; descriptors are computed once, and the DMA prefetch runs across image boundaries, so neither the
-//     launch of a workgroup nor the first DMA round trip of a tile is exposed (they cost ~30% on the 4-chunk
-//     64-channel layers).
+//   * persistent workgroups: a workgroup owns one tile position (and N tile) and walks over the images of the batch;
+//     descriptors are computed once, and the DMA prefetch runs across image boundaries, so neither the launch of a
+//     workgroup nor the first DMA round trip of a tile is exposed (they cost ~30% on the 4-chunk 64-channel layers).
 //
-// Epilogue variants: NHWC fp16 hi/lo planes (default), fp32 NCHW (network outputs), depth-to-space
+// This kernel serves the stacks that decide the anchors (SpixelNet, ColorProbNet) in the default precision mode and every
+// stack under DISCO_PREC_F16X3; conv_mx.hip (fp16 main product + fp8 corrections) serves the HourGlass2.
+// Epilogue variants: channel-blocked fp16 hi/lo planes (default), fp32 NCHW (network outputs), depth-to-space
 // (ConvTranspose2d 4x4 s2 p1 expressed as a 4-phase 3x3 conv, network.py:254-258).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 #include "common.h"
@@ -31,8 +32,6 @@
 namespace disco {
 
 namespace {
-
-__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 constexpr int WBLK = 1024;
 constexpr int W_NB = 9 * 2 * WBLK;
@@ -505,13 +504,14 @@ int launch_cfg3(const ConvArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_mfma2_kernel<TW, TH, NT, STRIDE, X3, WM, WN, MASKED>;
-    static bool attr_set[DISCO_MAX_DEVICES] = {};      // function attributes are per device (one context per device, possibly
-    const int dev = current_device();                   // several devices in one process)
-    if (!attr_set[dev]) {
-        DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set[dev] = true;
-    }
+    // function attributes are per device and per kernel instantiation (this static lives in the instantiation); call_once:
+    // two host threads may launch the same layer shape on one device
+    static std::once_flag attr_once[DISCO_MAX_DEVICES];
+    hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once[current_device()], [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    });
+    DISCO_HIP_CHECK(attr_err);
     // grid.x = tile positions x N tiles; grid.y = image groups: enough groups to give every CU one persistent
     // workgroup (LDS-limited residency), each walking n = g, g + groups, ... over the batch
     const int combos = cdiv(a.w_out, TW) * cdiv(a.h_out, TH) * cdiv(a.c_out, 32 * NT);

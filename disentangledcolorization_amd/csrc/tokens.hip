@@ -13,6 +13,7 @@
 //   nearest_bin_kernel    argmax of encode_ab2ind = nearest gamut bin (basic.py:177-194, model.py:166)
 #include <cmath>
 #include <vector>
+#include <mutex>
 #include "common.h"
 
 namespace disco {
@@ -982,13 +983,15 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
     const size_t lists = ((size_t)2 * l + (size_t)nseg * k) * sizeof(int);
     const size_t best = (size_t)4 * 256 * (sizeof(float) + sizeof(int));
     constexpr int MAX_SMEM = 128 * 1024;      // dynamic part; the kernels hold up to 27 KB of static LDS besides
-    auto launch = [&](auto kern, size_t smem) -> int {
-        static bool attr_set[DISCO_MAX_DEVICES] = {};      // per device and per instantiation (one lambda body each)
-        const int dev = current_device();
-        if (!attr_set[dev]) {
-            DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM));
-            attr_set[dev] = true;
-        }
+    // the dynamic-LDS limit is a per-device attribute of each kernel: the three instantiations share one function-pointer
+    // type (so one lambda body), hence the table is keyed by variant index, not by a static inside the lambda
+    auto launch = [&](auto kern, int variant, size_t smem) -> int {
+        static std::once_flag attr_once[3][DISCO_MAX_DEVICES];
+        hipError_t err = hipSuccess;
+        std::call_once(attr_once[variant][current_device()], [&] {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM);
+        });
+        DISCO_HIP_CHECK(err);
         hipLaunchKernelGGL(kern, dim3(n), dim3(1024), smem, s, x, d, img_stride, t_stride, c_stride, sizes, init_idx,
                            fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
         return DISCO_OK;
@@ -996,12 +999,22 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
     const size_t tile = (size_t)256 * (d + 1) * sizeof(float);
     const size_t glist_smem = tile + (size_t)nseg * k * sizeof(int) + best;
     int rc = DISCO_OK;
-    if (l <= KM_LDS_TOKENS) rc = launch(kmeans_anchor_kernel<true, false>, (size_t)l * (d + 1) * sizeof(float) + lists + best);
-    else if (l <= KM_LIST_TOKENS) rc = launch(kmeans_anchor_kernel<false, false>, tile + lists + best);
-    else if (glist_smem <= (size_t)MAX_SMEM) rc = launch(kmeans_anchor_kernel<false, true>, glist_smem);
-    else
-        hipLaunchKernelGGL(kmeans_anchor_scan_kernel<false>, dim3(n), dim3(256), (size_t)l * sizeof(int), s, x, d, img_stride,
+    if (l <= KM_LDS_TOKENS) rc = launch(kmeans_anchor_kernel<true, false>, 0, (size_t)l * (d + 1) * sizeof(float) + lists + best);
+    else if (l <= KM_LIST_TOKENS) rc = launch(kmeans_anchor_kernel<false, false>, 1, tile + lists + best);
+    else if (glist_smem <= (size_t)MAX_SMEM) rc = launch(kmeans_anchor_kernel<false, true>, 2, glist_smem);
+    else {
+        // scan fallback: one int of LDS per token on top of the kernel's static arrays
+        const size_t scan_smem = (size_t)l * sizeof(int);
+        if (scan_smem > (size_t)MAX_SMEM) { set_error("kmeans: %d tokens exceed what one workgroup can index in LDS (%d)", l, MAX_SMEM / 4); return DISCO_ESHAPE; }
+        static std::once_flag scan_once[DISCO_MAX_DEVICES];
+        hipError_t err = hipSuccess;
+        std::call_once(scan_once[current_device()], [&] {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_anchor_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM);
+        });
+        DISCO_HIP_CHECK(err);
+        hipLaunchKernelGGL(kmeans_anchor_scan_kernel<false>, dim3(n), dim3(256), scan_smem, s, x, d, img_stride,
                            t_stride, c_stride, sizes, init_idx, fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
+    }
     if (rc) return rc;
     DISCO_LAUNCH_CHECK("kmeans_anchor_kernel");
     return DISCO_OK;

@@ -22,8 +22,10 @@
  *     pointer-to-new-memory.
  *   - errors: 0 on success, negative DISCO_E* otherwise; never exit()/throw across the ABI.
  *     disco_last_error() gives a thread-local message for the last failing call.
- *   - threading: launchers are asynchronous on the given hipStream_t (passed as void*), hold no
- *     global mutable state and are re-entrant across streams/devices.  One context per device.
+ *   - threading: launchers are asynchronous on the given hipStream_t (passed as void*) and re-entrant across
+ *     streams/devices; the only process-global state is one-time per-device setup (function attributes, the
+ *     op-level gamut table: std::call_once / mutex) and the diagnostic probe pointer of
+ *     disco_op_conv3x3_set_probe (a debugging aid: set it from one thread, before launching).  One context per device.
  *     No hidden host synchronisation except in disco_forward's k-means fallback bookkeeping
  *     (documented there) and disco_sync.
  *   - host-side randomness (k-means initial rows, empty-cluster fallback rows, random hints) is
@@ -286,6 +288,12 @@ int disco_op_rgb8_to_lab(const uint8_t *d_rgb8, float *d_gray, float *d_ab, floa
                          int wp, void *stream);
 /* save_normLabs_from_batch before the image encode (utils/util.py:91-106) with batch_depadding folded in:
  * normalised Lab (n,3,hp,wp) -> RGB -> uint8 (n,h,w,3) of the top-left h x w crop, truncating, saturating at 255 */
+/* The default input path of main/colorizer/inference.py:32-40: cv2.resize(rgb8, (wo,ho), INTER_LINEAR) (opencv-python 4.6's
+ * published 8-bit algorithm: 11-bit fixed-point coefficients, the 2x2 area path for exact 2x downscales) fused with /255 ->
+ * RGB->Lab -> gray / ab / rgb*2-1 split.  d_rgb8: uint8 (n,h,w,3); d_resized: optional uint8 (n,ho,wo,3) copy of the resized
+ * image; d_rgb may be NULL. */
+int disco_op_rgb8_resize_to_lab(const uint8_t *d_rgb8, uint8_t *d_resized, float *d_gray, float *d_ab, float *d_rgb, int n, int h,
+                                int w, int ho, int wo, void *stream);
 int disco_op_lab_to_rgb8(const float *d_lab, uint8_t *d_rgb8, int n, int hp, int wp, int h, int w, void *stream);
 /* basic.mark_color_hints(input_grays, target_ABs, gate_maps, kernel_size, base_ABs) (models/basic.py:95-117):
  * gray (n,1,h,w), target/base ab (n,2,h,w), gate (n,1,h,w) -> marked Lab (n,3,h,w); d_base_ab may be NULL */

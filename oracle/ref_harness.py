@@ -1,8 +1,8 @@
 """Import the *real* reference (/root/reference) on a CPU-only box — TEST INFRASTRUCTURE.
 
 Only usable in the build container (the reference tree does not travel to the GPU box and is
-never copied into this repo).  Used by oracle/make_golden.py to produce tests/golden/*.npz and
-by tests/test_oracle_vs_reference.py (skipped when /root/reference is absent).
+never copied into this repo).  Used by oracle/make_golden.py to produce tests/golden/*.npz, which tests/test_oracle_golden.py
+replays against the oracle on any box.
 
 Shims: stub modules for imports the forward never uses (torchvision, cv2, skimage,
 tensorboardX), identity `.cuda()`, `cuda*` -> cpu in Tensor.to, cwd = main/colorizer because the

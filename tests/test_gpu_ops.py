@@ -357,8 +357,8 @@ def test_basic_mirror_hint_overlay_and_image_io(H, golden_dir):
     rs = np.random.RandomState(3)
     for h, w in [(37, 50), (32, 50), (37, 48), (32, 48), (250, 333)]:
         img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
-        want = R.fetch_from_rgb8(img)
-        got = basic.fetch_data_from_rgb8(img)
+        want = R.fetch_from_rgb8(img, org_size=True)
+        got = basic.fetch_data_from_rgb8(img, org_size=True)
         assert got[3] == want[3] == (h, w)
         for a, b in zip(got[:3], want[:3]):
             assert a.shape == b.shape and H.max_err(a, b) < 5e-6
@@ -368,8 +368,16 @@ def test_basic_mirror_hint_overlay_and_image_io(H, golden_dir):
         # truncation to uint8: a 1-ulp difference of the float result may cross an integer boundary
         assert back.shape == ref8.shape and np.abs(back.astype(int) - ref8.astype(int)).max() <= 1
         assert np.abs(back[0].astype(int) - img.astype(int)).max() <= 1          # the uint8 round trip
-    with pytest.raises(NotImplementedError):
-        basic.fetch_data_from_rgb8(np.zeros((32, 32, 3), np.uint8), org_size=False)
+    # the default (resize to 256x256) branch: the resized uint8 image must equal the oracle's cv2 restatement BIT FOR BIT
+    # (integer fixed-point arithmetic), gray / ab / rgb follow within float tolerance
+    for h, w in [(37, 53), (480, 640), (612, 612), (512, 512), (256, 256), (1200, 900)]:
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        want = R.fetch_from_rgb8(img, org_size=False)
+        got = basic.fetch_data_from_rgb8(img, org_size=False, return_resized=True)
+        assert got[3] == want[3] == (256, 256)
+        assert np.array_equal(got[4].cpu().numpy(), R.cv2_resize_linear_u8(img, 256, 256)), (h, w)
+        for a, b in zip(got[:3], want[:3]):
+            assert a.shape == b.shape and H.max_err(a, b) < 5e-6
 
 
 def test_spixelseg_dropin(H, golden_dir, synth_sd):

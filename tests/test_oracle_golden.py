@@ -87,13 +87,42 @@ def test_mark_color_hints_and_image_io(golden_dir):
     rs = np.random.RandomState(3)
     for (h, w), (hp, wp) in {(37, 50): (48, 64), (32, 50): (48, 64), (37, 48): (48, 64), (32, 48): (32, 48)}.items():
         img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
-        gr, ab, rgb, hw = R.fetch_from_rgb8(img)
+        gr, ab, rgb, hw = R.fetch_from_rgb8(img, org_size=True)
         assert gr.shape == (1, 1, hp, wp) and ab.shape == (1, 2, hp, wp) and rgb.shape == (1, 3, hp, wp) and hw == (h, w)
         assert torch.equal(gr[..., h:, :], gr[..., h - 1:h, :].expand(-1, -1, hp - h, -1))      # edge replication
         back = R.labs_to_rgb8(torch.cat((gr, ab), 1), h, w)
         assert back.shape == (1, h, w, 3) and np.abs(back[0].astype(int) - img.astype(int)).max() <= 1
-    with pytest.raises(NotImplementedError):
-        R.fetch_from_rgb8(np.zeros((32, 32, 3), np.uint8), org_size=False)
+
+
+def test_cv2_resize_restatement_hand_vectors():
+    """inference.py:32-33 (the default input path): cv2.resize(..., (256,256), INTER_LINEAR) on uint8.  cv2 is absent offline,
+    so the restatement (oracle cv2_resize_linear_u8, citing opencv 4.6 resize.cpp) is pinned on vectors worked out by hand
+    from the published fixed-point algorithm, and cross-checked against float bilinear interpolation (<= 1 LSB)."""
+    import torch.nn.functional as F
+    # 1x2 -> 1x4 (upscale): f = (d+0.5)*0.5-0.5 = -0.25, 0.25, 0.75, 1.25 -> (s,f) = (0,0) (0,.25) (0,.75) (1,0);
+    # coefficients x2048: (2048,0) (1536,512) (512,1536) (2048,0); rows D = 0, 130560, 391680, 522240;
+    # one source row: b = (2048,0): ((2048*(D>>4))>>16 + 2)>>2 = (0+2)>>2, (255+2)>>2, (765+2)>>2, (1020+2)>>2
+    assert R.cv2_resize_linear_u8(np.array([[[0], [255]]], np.uint8), 1, 4).ravel().tolist() == [0, 64, 191, 255]
+    # 1x5 -> 1x2 (downscale, scale 2.5): f = 0.75, 3.25 -> (s,f) = (0,.75) (3,.25); D = 10*512+20*1536 = 35840, 40*1536+50*512 = 87040;
+    # ((2048*(35840>>4))>>16 + 2)>>2 = (70+2)>>2 = 18;  ((2048*(87040>>4))>>16 + 2)>>2 = (170+2)>>2 = 43   (float: 17.5 / 42.5, rounded half up)
+    assert R.cv2_resize_linear_u8(np.array([[[10], [20], [30], [40], [50]]], np.uint8), 1, 2).ravel().tolist() == [18, 43]
+    # 3x1 -> 2x1 (vertical only, scale 1.5): f = 0.25, 1.75 -> (0,.25) (1,.75); rows D = v*2048; b = (1536,512), (512,1536):
+    # ((1536*(0>>4))>>16) + ((512*(204800>>4))>>16) + 2 = 0 + 100 + 2 -> 25;  ((512*(204800>>4))>>16) + ((1536*(409600>>4))>>16) + 2 = 100+600+2 -> 175
+    assert R.cv2_resize_linear_u8(np.array([[[0]], [[100]], [[200]]], np.uint8), 2, 1).ravel().tolist() == [25, 175]
+    # exact 2x downscale in both directions: cv::resize switches INTER_LINEAR to the area path, (a+b+c+d+2)>>2
+    assert R.cv2_resize_linear_u8(np.array([[[1], [2]], [[3], [5]]], np.uint8), 1, 1).ravel().tolist() == [3]
+    rs = np.random.RandomState(0)
+    for (h, w, ho, wo) in [(37, 53, 256, 256), (480, 640, 256, 256), (612, 612, 256, 256), (512, 512, 256, 256), (100, 300, 64, 48), (256, 256, 256, 256)]:
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        got = R.cv2_resize_linear_u8(img, ho, wo)
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+        ref = F.avg_pool2d(t, 2) if (h == 2 * ho and w == 2 * wo) else F.interpolate(t, size=(ho, wo), mode="bilinear", align_corners=False)
+        assert got.shape == (ho, wo, 3) and got.dtype == np.uint8
+        assert np.abs(got.astype(np.float64) - ref[0].permute(1, 2, 0).numpy()).max() <= 1.0
+        if (h, w) == (ho, wo):
+            assert np.array_equal(got, img)             # identity resize is exact
+    gr, ab, rgb, hw = R.fetch_from_rgb8(rs.randint(0, 256, (100, 75, 3)).astype(np.uint8), org_size=False)
+    assert gr.shape == (1, 1, 256, 256) and ab.shape == (1, 2, 256, 256) and hw == (256, 256)
 
 
 def test_spixelseg_standalone(golden_dir, synth_sd):

@@ -5,7 +5,8 @@ with every tensor op on the device (image decode/encode through PIL on the host)
     python tools/colorize.py --checkpt disco.pth.rar --out out_dir img1.png img2.jpg        # real DISCO checkpoint
     python tools/colorize.py --out out_dir img.png                                           # synthetic weights (plumbing)
 
-Per image (like the reference with --no_resize): uint8 RGB -> pad to multiples of 16 -> Lab (fetch_data_from_rgb8) ->
+Per image: uint8 RGB -> resize to 256x256 (cv2.resize INTER_LINEAR semantics; the reference's default) or, with --no_resize,
+pad to multiples of 16 -> Lab (fetch_data_from_rgb8) ->
 AnchorColorProb.forward(gray, ab, True, T) -> Lab -> uint8 RGB, de-padded (normLabs_to_rgb8) -> PNG; with --anchors also
 the anchor overlay (upfeat of hint_mask + mark_color_hints, inference.py:128-131)."""
 import argparse
@@ -33,6 +34,8 @@ def main():
     ap.add_argument("--hint2regress", action="store_true")
     ap.add_argument("--spix_pos", action="store_true")
     ap.add_argument("--anchors", action="store_true", help="also save the anchor overlay")
+    ap.add_argument("--no_resize", action="store_true", help="keep the original size (padded to multiples of 16), inference.py:148")
+    ap.add_argument("--psize", type=int, default=256)
     ap.add_argument("--seed", type=int, default=130)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -46,7 +49,7 @@ def main():
     model = model.cuda().eval()
     for path in args.images:
         rgb8 = np.asarray(Image.open(path).convert("RGB"))
-        gray, ab, _, (H, W) = basic.fetch_data_from_rgb8(rgb8, org_size=True)
+        gray, ab, _, (H, W) = basic.fetch_data_from_rgb8(rgb8, org_size=args.no_resize, psize=args.psize)
         _, _, pred_ab, affinity, _, hint_mask = model(gray, ab, True, 2 if args.diverse else 0)
         stem = os.path.splitext(os.path.basename(path))[0]
         for i in range(pred_ab.shape[0]):
