@@ -39,32 +39,39 @@ FP32_MFMA_PEAK = 157.3e12
 CONV_SOURCES = ["conv_mfma2.hip", "conv_mx.hip", "common.h", "api.cpp"]
 
 
-def cpu_baseline(sd, seconds_budget=30.0):
-    """The CPU oracle (port of the reference arithmetic) timed on this box's host cores: N in {1, 8}, every core, best of
-    up to 3 repeats each within a bounded time budget."""
+def cpu_baseline(sd, seconds_budget=40.0):
+    """The CPU oracle (port of the reference arithmetic) timed on this box's host cores, N in {1, 8}, bounded to
+    `seconds_budget`.  Thread counts: every core, and 32 (oneDNN's 3x3 convs of this size stop scaling and start thrashing
+    beyond a few dozen threads: 256 threads measured 0.05 img/s where 32 give ~5); the best rate is reported with the
+    thread count that produced it, every measured point is listed."""
     from disentangledcolorization_amd import synth
     from disentangledcolorization_amd.gamut import gamut_points
     from oracle.disco_ref import DiscoOracle
 
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     oracle = DiscoOracle(sd, gamut_points(), n_clusters=8)
     t_start = time.time()
-    res = {}
-    for n in (1, 8):
-        gray, ab = synth.synth_inputs(n, 256, 256, seed=5)
-        np.random.seed(130)
-        t0 = time.time(); oracle.forward(gray, ab); first = time.time() - t0      # warm-up (thread pool, allocator)
-        best, reps = float("inf"), 0
-        while reps < 3 and (time.time() - t_start) + min(best, first) < seconds_budget * (0.45 if n == 1 else 1.0):
+    points = {}
+    for threads in sorted({min(cores, 32), cores}):
+        torch.set_num_threads(threads)
+        for n in (1, 8):
+            if time.time() - t_start > seconds_budget * 0.8:
+                break
+            gray, ab = synth.synth_inputs(n, 256, 256, seed=5)
             np.random.seed(130)
-            t0 = time.time(); oracle.forward(gray, ab); best = min(best, time.time() - t0); reps += 1
-        res[n] = (n / min(best, first), max(reps, 1))
-    n_best = max(res, key=lambda k: res[k][0])
-    return {"value": round(res[n_best][0], 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "by_batch": {str(k): round(v[0], 3) for k, v in res.items()},
-            "sample": "oracle/disco_ref.py forward (torch CPU, %d threads), 256x256, N=1 and N=8, best of <=3 after a warm-up; value = the better of the two (N=%d)"
-                      % (cores, n_best)}
+            t0 = time.time(); oracle.forward(gray, ab); best = time.time() - t0          # first call doubles as warm-up
+            reps = 0
+            while reps < 2 and (time.time() - t_start) + best < seconds_budget * (0.5 if threads != cores or cores <= 32 else 1.0):
+                np.random.seed(130)
+                t0 = time.time(); oracle.forward(gray, ab); best = min(best, time.time() - t0); reps += 1
+            points["N=%d,threads=%d" % (n, threads)] = (round(n / best, 3), threads)
+            if best > seconds_budget / 4:      # this thread count is hopeless on this box: do not burn the budget on N=8
+                break
+    key = max(points, key=lambda k: points[k][0])
+    return {"value": points[key][0], "unit": "images/s", "cores": points[key][1], "host_cores": cores, "kind": "port",
+            "points": {k: v[0] for k, v in points.items()},
+            "sample": "oracle/disco_ref.py forward (torch CPU), 256x256, N in {1, 8} at min(32, cores) and at all %d host cores, best of <=3 "
+                      "runs each inside a %ds budget; value = the best point (%s)" % (cores, int(seconds_budget), key)}
 
 
 def source_hash():

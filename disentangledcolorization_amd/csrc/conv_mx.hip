@@ -135,8 +135,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 const int plane = u / (G::NPIX * 2);
                 const int rem = u - plane * (G::NPIX * 2);
                 const int p = rem >> 1, j = rem & 1;
-                const int kh = j ^ ((p >> 3) & 1);
                 const int py = p / G::PITCH, q = p - py * G::PITCH;
+                const int kh = j ^ ((q >> 3) & 1);          // 16-byte XOR swizzle on bit 3 of the COLUMN position (see the fragment reads)
                 int px;
                 bool slot_ok = u < A_UNITS;
                 if (STRIDE == 1) px = q;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         for (int i = 0; i < APW; ++i) {
             if (part >= 0 && i / APT != part) continue;
             const int piece = i * NWAVE + wave;
-            if (piece < A_PIECES) {
+            if ((i + 1) * NWAVE <= A_PIECES || piece < A_PIECES) {      // only the last round of pieces needs the run-time test
                 if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(dA + piece * 1024), 16, voff[NS - 1][i], soff, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(dA + piece * 1024), 16, voff[0][i], soff, 0, 0);
             }
@@ -180,16 +180,31 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             if (part >= 0 && i / WPT != part) continue;
             const int piece = i * NWAVE + wave;
             const int nt = piece / 18, q = piece - nt * 18;
-            if (piece < W_PIECES && (!MASKED || ((tmask >> (q >> 1)) & 1u)))
+            if (((i + 1) * NWAVE <= W_PIECES || piece < W_PIECES) && (!MASKED || ((tmask >> (q >> 1)) & 1u)))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(dW + piece * 1024), 16, lane * 16,
                                                          w_tile_b + (unsigned)nt * w_nt_b + (unsigned)ck * W_NB + q * 1024, 0, 0);
         }
     };
 
+    // ---- per-lane fragment addressing ----------------------------------------------------------------------------------------
+    // LDS pixel (row, column q) of a plane lives at (row PITCH + q) 32 + (logical half ^ bit 3 of q) 16: the swizzle depends on
+    // the column only, so a tap (ky, kx) adds a CONSTANT row offset (an instruction immediate) to one of three per-lane column
+    // addresses - no address arithmetic inside the tap loop.  (A 16-lane group of a ds_read_b128 covers 16 consecutive
+    // columns of one row on the 32-wide tiles: bank-conflict free.)
     const int r = lane & 31, kh = lane >> 5;
     const int lox = r % TW, loy = r / TW;
-    const int p_lane = ((wm * MT * G::ROWS_PER_MB + loy) * STRIDE) * G::PITCH + lox;
     const int w_off = lane * 16 + wn * NTW * W_NB;
+    int colH[3], colQ[3];             // byte address (within an LDS buffer) of this lane's 16 bytes for kx = 0, 1, 2; row 0 of its M block 0
+    {
+        const int rowb = ((wm * MT * G::ROWS_PER_MB + loy) * STRIDE) * G::PITCH * 32;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int q = lox + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
+            const int sw = (q >> 3) & 1;
+            colH[kx] = rowb + q * 32 + ((sw ^ kh) << 4);                   // H chunk: logical half kh of plane 0 (plane 1: + PLANE_B)
+            colQ[kx] = rowb + q * 32 + (sw << 4) + kh * PLANE_B;          // Q chunk: logical half 0 of plane kh (half 1: ^ 16)
+        }
+    }
 
     issue(n, 0, 0, -1);
     int buf = 0;
@@ -222,10 +237,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         buf ^= 1;
         constexpr bool ROWREUSE = STRIDE == 1 && G::ROWS_PER_MB == 1 && MT == 2;
         const int asc = (NSRC2 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
-        // the per-tap fragment addresses are a few VALU ops each; hidden from loop-invariant code motion they are recomputed
-        // per chunk instead of being kept in ~40 VGPRs (which spilled)
-        int pl = p_lane, wo = w_off;
-        asm volatile("" : "+v"(pl), "+v"(wo));
+        // this chunk's three column addresses inside the current buffer (the only per-chunk address arithmetic)
+        const int bufoff = (int)(sA - smem);
+        int ca0[3], ca1[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            ca0[kx] = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
+            ca1[kx] = ISQ ? (ca0[kx] ^ 16) : ca0[kx] + PLANE_B;           // all other address terms are multiples of 32
+        }
+        int wo = w_off;
+        asm volatile("" : "+v"(wo));
         i32x4 ra[MT][2];
         i32x4 rb[NTW][2];
 #pragma unroll
@@ -237,24 +258,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #endif
             const bool live = !MASKED || ((tmask >> tap) & 1u);
             if (!ROWREUSE && !live) continue;
-            const int tapoff = ky * G::PITCH + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (ROWREUSE && ky > 0 && mt == 0) { ra[0][0] = ra[1][0]; ra[0][1] = ra[1][1]; continue; }
 #if MX_ABL & 2
                 if (slot > 0) continue;
 #endif
-                const int p = pl + mt * G::ROWS_PER_MB * STRIDE * G::PITCH + tapoff;
-                const int sw = (p >> 3) & 1;
-                if (ISQ) {
-                    const char* base = sA + kh * PLANE_B + (p << 5);
-                    ra[mt][0] = *reinterpret_cast<const i32x4*>(base + (sw << 4));
-                    ra[mt][1] = *reinterpret_cast<const i32x4*>(base + ((sw ^ 1) << 4));
-                } else {
-                    const char* base = sA + (p << 5) + ((sw ^ kh) << 4);
-                    ra[mt][0] = *reinterpret_cast<const i32x4*>(base);
-                    ra[mt][1] = *reinterpret_cast<const i32x4*>(base + PLANE_B);
-                }
+                constexpr int RB = G::PITCH * 32;                           // bytes per tile row
+                const int rowc = (mt * G::ROWS_PER_MB * STRIDE + ky) * RB;   // compile-time constant: the ds_read's immediate offset
+                ra[mt][0] = *reinterpret_cast<const i32x4*>(smem + ca0[kx] + rowc);
+                ra[mt][1] = *reinterpret_cast<const i32x4*>(smem + ca1[kx] + rowc);
             }
             if (ROWREUSE && !live) continue;
 #if MX_ABL & 2

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """HBM bytes per conv launch from two rocprofv3 PMC passes (run on the GPU box, see the recipe below) ->
-profiles/r01_pmc_traffic.json, which bench.py reports as roofline.traffic.
+profiles/r02_pmc_traffic.json, which bench.py reports as roofline.traffic (it carries the hash of the conv sources it was measured
+on; bench.py reports null when the sources have changed since).
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o fetch --output-format csv -- \
@@ -27,7 +28,7 @@ def total(dirname, counter):
     for f in files:
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if row.get("Counter_Name") == counter and "conv3x3_mfma2_kernel" in row.get("Kernel_Name", ""):
+                if row.get("Counter_Name") == counter and ("conv3x3_mfma2_kernel" in row.get("Kernel_Name", "") or "conv3x3_mx_kernel" in row.get("Kernel_Name", "")):
                     s += float(row["Counter_Value"]); launches += 1
     return s, launches
 
@@ -40,12 +41,15 @@ def main():
         raise SystemExit("launch counts differ: %d vs %d" % (nf, nw))
     rd = fetch * 1024 * 2 / nf
     wr = write * 1024 / nw
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     json.dump({
+        "source_hash": bench.source_hash(),
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
                   "`python bench.py --steps 1 --warmup 1` (tools/pmc_traffic.py)",
         "unit_note": "counter unit is KiB; per MI355X_MICROARCH.md the gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of "
                      "wide coalesced streaming reads, so reads are doubled below; WRITE_SIZE is uncalibrated and taken as is",
-        "conv3x3_mfma2_launches": nf, "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
+        "conv_launches (conv3x3_mfma2_kernel + conv3x3_mx_kernel)": nf, "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
         "hbm_read_bytes_per_launch_corrected": int(rd), "hbm_write_bytes_per_launch": int(wr),
         "hbm_bytes_per_launch": int(rd + wr)}, open(out, "w"), indent=1)
     print(open(out).read())
