@@ -68,6 +68,7 @@ SIGNATURES = {
     "disco_expected_tensor": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(_I)]),
     "disco_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "disco_forward": (_I, [_P, C.POINTER(ForwardArgs)]),
+    "disco_calibrate": (_I, [_P, _P, _I, _I, _I]),
     "disco_saturation_count": (_I, [_P, _P, C.POINTER(C.c_uint64)]),
     "disco_calibration_count": (_I, [_P]),
     "disco_calibration_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),

@@ -552,6 +552,10 @@ struct Plan {
         if (ok() && (hipMemcpyAsync(&amax, d_amax, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = hip_fail(hipGetLastError(), "calibration amax");
         drop(d_amax);
         if (!ok()) return;
+        {   // calibrations accumulate: a later disco_calibrate on other images can only widen a tensor's range
+            auto prev = c->amax.find(key);
+            if (prev != c->amax.end() && prev->second > amax) amax = prev->second;
+        }
         c->amax[key] = amax;
         if (!(amax <= 16384.f)) {     // also catches NaN
             set_error("activation range of %s (max |x| = %g) leaves no fp16 headroom: this checkpoint cannot run in fp16 hi/lo arithmetic", key.c_str(), (double)amax);
@@ -874,10 +878,11 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
 // tensor's max |x|, once more with the power-of-two scale that measurement fixes (Plan::calibrate).  The scales are
 // properties of the checkpoint from then on (deterministic: the inputs are generated here); q-plane clamping at run time is
 // counted (disco_saturation_count) so that inputs far outside the calibrated range are noticed.
-int calibrate_ctx(disco_ctx* c) {
+int calibrate_ctx(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, int uh = 0, int uw = 0) {
     if (!any_mx(c) || (c->opt.segnet_only && c->opt.precision != DISCO_PREC_MX8_ALL)) { c->calibrated = true; return DISCO_OK; }
-    const int n = 2, H = 256, W = 256, K = c->opt.n_clusters, L = (H / 16) * (W / 16);
-    std::vector<float> g((size_t)n * H * W);
+    const int n = d_user_gray ? un : 2, H = d_user_gray ? uh : 256, W = d_user_gray ? uw : 256, K = c->opt.n_clusters, L = (H / 16) * (W / 16);
+    std::vector<float> g(d_user_gray ? 0 : (size_t)n * H * W);
+    if (!d_user_gray) {
     unsigned st = 20240607u;
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
@@ -886,6 +891,7 @@ int calibrate_ctx(disco_ctx* c) {
             g[(size_t)y * W + x] = 2.f * u - 1.f;
             g[(size_t)H * W + (size_t)y * W + x] = 0.8f * std::sin(x * (1.f / 9.f)) * std::cos(y * (1.f / 13.f)) + 0.1f * (2.f * u - 1.f);
         }
+    }
     std::vector<int32_t> idx((size_t)n * K);
     for (int i = 0; i < n; ++i) for (int k = 0; k < K; ++k) idx[(size_t)i * K + k] = (k * 7 + i) % L;
     disco_forward_args a{};
@@ -904,7 +910,7 @@ int calibrate_ctx(disco_ctx* c) {
     hipError_t e = hipSuccess;
     for (int i = 0; i < 7 && e == hipSuccess; ++i) e = hipMalloc(&bufs[i], outs[i]);
     if (e == hipSuccess) e = hipMalloc(&bufs[7], peak);
-    if (e == hipSuccess) e = hipMemcpy(bufs[0], g.data(), px * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = d_user_gray ? hipMemcpy(bufs[0], d_user_gray, px * 4, hipMemcpyDeviceToDevice) : hipMemcpy(bufs[0], g.data(), px * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(bufs[1], 0, px * 2 * 4);
     if (e != hipSuccess) rc = hip_fail(e, "calibration buffers");
     if (!rc) {
@@ -1098,6 +1104,14 @@ int disco_finalize(disco_ctx* c) {
     c->sd.clear();   // host copies are no longer needed
     c->finalized = true;
     return calibrate_ctx(c);
+}
+
+int disco_calibrate(disco_ctx* c, const float* d_gray, int n, int h, int w) {
+    if (!c || !c->finalized || !d_gray) { set_error("disco_calibrate: bad argument / context not finalized"); return DISCO_EINVAL; }
+    if (n < 1 || n > 64 || h < 16 || w < 16 || h % 16 || w % 16 || (h / 16) * (w / 16) < c->opt.n_clusters) { set_error("disco_calibrate: bad size %dx%dx%d", n, h, w); return DISCO_ESHAPE; }
+    DISCO_HIP_CHECK(hipSetDevice(c->device));
+    DISCO_HIP_CHECK(hipDeviceSynchronize());      // no forward of this context may be in flight: the scales are about to change
+    return calibrate_ctx(c, d_gray, n, h, w);
 }
 
 int disco_saturation_count(disco_ctx* c, void* stream, uint64_t* count) {

@@ -222,6 +222,25 @@ class AnchorColorProb(nn.Module):
         self._ctx, self._ctx_device = ctx, device
         return ctx
 
+    def calibrate(self, input_grays):
+        """Widen the fp8 activation scales of the mx8 mode with the ranges of the caller's own L images (N<=64,1,H,W);
+        blocking.  The context is already calibrated on synthetic images at load time - use this when `saturation_count()`
+        reports clamping on real data."""
+        g = input_grays.contiguous().float()
+        if not g.is_cuda or g.dim() != 4 or g.shape[1] != 1:
+            raise ValueError("expected a CUDA/HIP tensor (N,1,H,W)")
+        with torch.cuda.device(g.device):
+            ctx = self._context(g.device)
+            _ffi.check(_ffi.lib().disco_calibrate(ctx, _ffi.ptr(g), g.shape[0], g.shape[2], g.shape[3]))
+
+    def saturation_count(self):
+        """fp8 activation elements clamped since the previous call (one device synchronisation on the current stream)."""
+        if self._ctx is None:
+            return 0
+        cnt = C.c_uint64(0)
+        _ffi.check(_ffi.lib().disco_saturation_count(self._ctx, _ffi.current_stream(), C.byref(cnt)))
+        return int(cnt.value)
+
     def set_profiling(self, level=1):
         """0 off, 1 per-stage hipEvents, 2 additionally an event pair around every MFMA conv launch."""
         self._profiling = int(level)

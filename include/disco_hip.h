@@ -142,6 +142,12 @@ int disco_workspace_bytes(disco_ctx *ctx, int n, int h, int w, int sampled_T, si
  * counter is read on `stream` (one synchronisation) and reset.  Non-zero means some activation exceeded ~14x the range the
  * calibration pass saw: the affected correction products lose accuracy (results degrade towards plain-fp16 operands). */
 int disco_saturation_count(disco_ctx *ctx, void *stream, uint64_t *count);
+/* Widen the fp8 scales of an mx8 context with the activation ranges of the caller's own images: d_gray device fp32 (n,1,h,w),
+ * n <= 64, h and w multiples of 16.  Blocking (synchronises the device first: no forward of this context may be in flight).
+ * Calibrations accumulate (a tensor's recorded max |x| only grows), so results of later forwards change at the 1e-5 level only
+ * when a scale actually moves.  disco_finalize has already calibrated on two synthetic images; call this when
+ * disco_saturation_count reports clamping on your data. */
+int disco_calibrate(disco_ctx *ctx, const float *d_gray, int n, int h, int w);
 /* The calibration pass's per-tensor record (diagnostics; the fp16 range guard: disco_finalize fails with
  * DISCO_EUNSUPPORTED when any tensor's max |x| exceeds 16384): producer key, max |x|, chosen scale exponent. */
 int disco_calibration_count(disco_ctx *ctx);

@@ -392,3 +392,15 @@ def test_fp8_saturation_counter_and_calibration_record(synth_sd):
         if amax.value > 0:
             assert 16 <= amax.value * 2.0 ** sexp.value < 32
     assert "enhanceNet.up1.conv2.2" in seen and "upfeat" in seen and "repnet.conv5_3.4" in seen
+    # user calibration on the caller's own images: ranges only widen, results stay within the parity bar and the anchors
+    # (decided upstream on f16x3) do not move
+    _seed(1)
+    before = m(gray.cuda(), ab.cuda(), True, 0)
+    m.calibrate(gray.cuda() * 0.5)
+    key, amax2, sexp2 = C.c_char_p(), C.c_float(), C.c_int()
+    for i in range(n):
+        _ffi.check(L.disco_calibration_entry(m._ctx, i, C.byref(key), C.byref(amax2), C.byref(sexp2)))
+        assert amax2.value >= seen[key.value.decode()][0]
+    _seed(1)
+    after = m(gray.cuda(), ab.cuda(), True, 0)
+    assert torch.equal(before[5], after[5]) and _err(before[2], after[2]) < 2e-4 and m.saturation_count() == 0
