@@ -292,8 +292,10 @@ def test_batch_of_64_at_512_crosses_the_addressing_limit(synth_sd):
             assert torch.equal(a[0], b[i])
 
 
-def test_random_hint_with_host_positions(synth_sd):
-    """BASELINE config 5b: random_hint with K=16 host-provided anchor positions (random.Random(130).sample)."""
+def test_random_hint_with_host_positions(synth_sd, q_to_ab):
+    """BASELINE config 5b at its full image size: random_hint with K=16 host-provided anchor positions
+    (random.Random(130).sample) on 256x256 images - positions exact, and every output against the CPU oracle handed the
+    same hint mask."""
     import random as _r
     n, k = 3, 16
     gray, ab = synth.synth_inputs(n, 256, 256, seed=41)
@@ -306,6 +308,11 @@ def test_random_hint_with_host_positions(synth_sd):
     for i in range(n):
         assert sorted(torch.nonzero(mask[i]).flatten().tolist()) == sorted(pos[i].tolist())
     assert torch.isfinite(out[2]).all()
+    hint = torch.zeros(n, 256)
+    hint.scatter_add_(1, torch.from_numpy(pos).long(), torch.ones(n, k))
+    want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=k, random_hint=True).forward(gray, ab, hint_mask=hint.reshape(n, 1, 16, 16))
+    assert torch.equal(out[5].cpu(), want[5]) and torch.equal(out[4].cpu(), want[4])
+    assert _err(out[0], want[0]) < LOGIT_TOL and _err(out[1], want[1]) < LOGIT_TOL and _err(out[2], want[2]) <= AB_TOL
 
 
 def test_precision_mode_f16x1_runs(synth_sd):
