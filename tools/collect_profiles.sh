@@ -6,7 +6,7 @@ R=$PWD
 O=$R/gpurun_out/r02
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 20 --warmup 5 > $O/final_bench.json 2> $O/final_bench.err
+python $R/bench.py --steps 20 --warmup 5 --cpu-all-cores > $O/final_bench.json 2> $O/final_bench.err
 rocprofv3 --kernel-trace --stats -d $O/ks -o ks --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/ks_bench.json 2> $O/ks.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/write.err
