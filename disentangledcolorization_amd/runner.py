@@ -17,6 +17,7 @@ drawn for the GLOBAL batch in image order from the generators the reference cons
 Every rank must therefore seed NumPy / random / torch identically (checked: the exchange carries a
 checksum of the draws).
 """
+import os
 import random
 import zlib
 
@@ -109,7 +110,7 @@ class ShardedColorizer:
 
     def _exchange_events(self, ev_local, n_global, world, rank, checksum, device):
         """Per-image event counts of the global batch on every rank (+ a check that all ranks made the same draws)."""
-        if world == 1:
+        if world == 1 and not (os.environ.get("DISCO_FORCE_GATHER") == "1" and dist.is_available() and dist.is_initialized()):
             return ev_local.astype(np.int64)
         counts = [shard_bounds(n_global, world, r)[1] - shard_bounds(n_global, world, r)[0] for r in range(world)]
         mx = max(counts)
@@ -171,7 +172,10 @@ class ShardedColorizer:
                 torch.randint(l, (1,))
             self.last_events = events
         pred, mask = out[2], out[5]
-        if not gather or world == 1:
+        # world size 1 normally skips the collective; DISCO_FORCE_GATHER=1 runs it anyway when a process group exists (the only
+        # way to exercise the RCCL path - packed send buffer, async work handle, unpack - on a single-GPU box: tests/test_gpu_dist.py)
+        force = os.environ.get("DISCO_FORCE_GATHER") == "1" and dist.is_available() and dist.is_initialized()
+        if not gather or (world == 1 and not force):
             return pred, mask
         return self._all_gather_packed(pred, mask, n_global, world, rank, rep, async_gather)
 
