@@ -1,6 +1,6 @@
 // conv_direct.hip — the few convolutions that do not fit the MFMA implicit GEMM, as exact-fp32 VALU
 // kernels, plus the converters between fp32 NCHW and the internal activation layout
-// (channel-blocked [N][C/16][H][W][16] fp16, hi plane + lo plane).
+// (channel-blocked [N][C/16][H][W][16] fp16 hi plane, optional lo plane and fp8 q planes: struct Act in common.h).
 //
 //   conv_c1          Cin = 1 first layers  (segnet conv0a, network.py:263; repnet conv1_2.0, :152)
 // (pred_mask0 + softmax9, enhanceNet.outConv and the ConvTranspose2d layers run on the MFMA kernel: conv_mfma2.hip epilogues.)
@@ -16,24 +16,6 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == DISCO_ACT_LRELU) return v >= 0.f ? v : v * slope;
     if (act == DISCO_ACT_TANH) return tanhf(v);
     return v;
-}
-
-__device__ __forceinline__ void store_split8(f16* hi_p, long plane, const float* v) {
-    f16x8 h, l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h[j] = (f16)v[j];
-        l[j] = (f16)(v[j] - (float)h[j]);
-    }
-    *reinterpret_cast<f16x8*>(hi_p) = h;
-    *reinterpret_cast<f16x8*>(hi_p + plane) = l;
-}
-
-__device__ __forceinline__ void load_sum8(const f16* hi_p, long plane, float* v) {
-    const f16x8 h = *reinterpret_cast<const f16x8*>(hi_p);
-    const f16x8 l = *reinterpret_cast<const f16x8*>(hi_p + plane);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (float)h[j] + (float)l[j];
 }
 
 // ---- Cin = 1 ---------------------------------------------------------------------------------------
