@@ -65,6 +65,22 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
     return 0u;
 #endif
 }
+// Products and sums that must round like the reference's separate torch ops (anchor scores, k-means distances, upfeat slot sums,
+// colour distances).  NOT __fmul_rn/__fadd_rn: the HIP headers define those as plain x * y / x + y, which hipcc's default
+// -ffp-contract=fast fuses into v_fma / v_fmac (seen in the ISA of round 1's upfeat kernel); the pragma survives inlining.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 // 8 consecutive channels (the half `half` of a 16-channel block `blk`) of pixel `pix` of image `img` -> the planes of an act
 __device__ __forceinline__ void store_act8(f16* hi_p, long plane, long q_off, int sexp, long img, int blk, int half, long pix, long hw,
                                             int nblk, const float* v, unsigned* sat = nullptr) {

@@ -44,7 +44,61 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
     // thread = (channel ch = tid & 63 (+64 second round), pixel group g = tid >> 6)
     const int g = threadIdx.x >> 6, lanech = threadIdx.x & 63;
     const float inv = 1.f / (float)npix;
-    for (int ch0 = 0; ch0 <= C; ch0 += 64) {
+    int ch_first = 0;
+    if (a.sp == 16 && a.c_act == 64) {
+        // The 64 act channels of a 16x16 cell, 16 bytes per load: thread = (8-channel group q = tid & 7, pixel subset r = tid >> 3),
+        // pixel p = 32 i + r (i = 0..7): a wave reads 8 consecutive pixels x 64 channels = 4 planes x 256 contiguous bytes per
+        // load instruction (the scalar path below moves 2 bytes per lane: 8x the instructions, address-unit bound).  Each thread
+        // keeps 8 channels x 9 slots; the 32 pixel subsets are combined in a fixed order: xor butterfly over the 8 subsets of a
+        // wave, then the 4 waves through LDS.
+        const int q = threadIdx.x & 7, r = threadIdx.x >> 3;
+        const long cell0 = (long)(cy * 16) * a.W + cx * 16;
+        const f16* s16 = a.feat_act + (((long)n * 4 + (q >> 1)) * HW + cell0) * 16 + (q & 1) * 8;
+        float acc[9][8];
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
+#pragma unroll 2
+        for (int i = 0; i < 8; ++i) {
+            const int p = 32 * i + r;
+            const int off = ((p >> 4) * a.W + (p & 15)) * 16;
+            const f16x8 h = *reinterpret_cast<const f16x8*>(s16 + off);
+            const f16x8 l = *reinterpret_cast<const f16x8*>(s16 + off + a.feat_plane);
+            float f[8], pr[9];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (float)h[j] + (float)l[j];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) pr[c] = sp_prob[p * 9 + c];
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[c][j] = fmaf(f[j], pr[c], acc[c][j]);
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = acc[c][j];
+                v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                acc[c][j] = v;
+            }
+        if ((threadIdx.x & 63) < 8) {          // lanes 0..7 of each wave hold the wave's sums of channel group q
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[(g * 9 + c) * 64 + q * 8 + j] = acc[c][j];
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < 9 * 64; o += 256) {
+            const int c = o >> 6, ch = o & 63;
+            const float s = (red[(0 * 9 + c) * 64 + ch] + red[(1 * 9 + c) * 64 + ch]) + (red[(2 * 9 + c) * 64 + ch] + red[(3 * 9 + c) * 64 + ch]);
+            a.partial[((long)cell * 9 + c) * (C + 1) + ch] = s * inv;
+        }
+        __syncthreads();
+        ch_first = 64;
+    }
+    for (int ch0 = ch_first; ch0 <= C; ch0 += 64) {
         // A round with few channels left (the ab + ones tail: 3 of 64 lanes would work while the round costs as much as
         // a full one) splits the lanes as (channel slot, pixel subgroup): nslot = 2^k >= channels left, 64/nslot pixel
         // subgroups per wave, combined below by a fixed-order xor butterfly.
@@ -138,8 +192,8 @@ __global__ void pool_gather_kernel(PoolArgs a) {
             if (si < 0 || si >= hs || sj < 0 || sj >= ws) continue;
             const long cell = ((long)n * hs + si) * ws + sj;
             const float* pp = a.partial + (cell * 9 + c) * (C + 1);
-            num = __fadd_rn(num, pp[ch]);
-            den = __fadd_rn(den, pp[C]);
+            num = add_rn(num, pp[ch]);
+            den = add_rn(den, pp[C]);
             cn += a.cnt[cell * 9 + c];
         }
         const int tok = i * ws + j;
@@ -199,7 +253,7 @@ __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ t
                 }
                 // the reference multiplies then accumulates in slot order (no fused multiply-add)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = s == 0 ? __fmul_rn(tv[j], pw[0]) : __fadd_rn(acc[j], __fmul_rn(tv[j], pw[s]));
+                for (int j = 0; j < 16; ++j) acc[j] = s == 0 ? mul_rn(tv[j], pw[0]) : add_rn(acc[j], mul_rn(tv[j], pw[s]));
             }
             if (out_act) {
                 store_act8(out_act, out_plane, q_off, sexp, img, blk, 0, p, HW, nblk, acc, &sat);
@@ -210,6 +264,47 @@ __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ t
                 for (int j = 0; j < 16; ++j) out_nchw[((long)img * c + blk * 16 + j) * HW + p] = acc[j];
             }
         }
+    }
+    if (sat_out && sat) atomicAdd(sat_out, sat);
+}
+
+// sp == 16, token-major input, act output: ONE WORKGROUP PER CELL (thread = pixel of the cell).  The nine neighbour tokens are then
+// uniform over the workgroup: their addresses depend on blockIdx only, so they arrive through the scalar cache into SGPRs
+// (s_load_dwordx16) instead of 36 sixteen-byte vector loads per pixel and 16-channel block - the pixel-per-thread kernel above is
+// bound by exactly those (a row of 64 pixels spans 4 cells).  Same products and the same slot order as above.
+__global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restrict__ tok, const float* __restrict__ prob, int prob_rep,
+                                                          f16* out_act, long out_plane, long q_off, int sexp, unsigned int* sat_out,
+                                                          int c, int hs, int ws) {
+    const int W = ws * 16, L = hs * ws;
+    const long HW = (long)(hs * 16) * W;
+    const int nblk = c >> 4;
+    const int cell = blockIdx.x;
+    const int cx = cell % ws, cy = (cell / ws) % hs, img = cell / L;
+    const long p = (long)(cy * 16 + (threadIdx.x >> 4)) * W + cx * 16 + (threadIdx.x & 15);
+    const float* pr = prob + (long)(img / prob_rep) * 9 * HW + p;
+    // a neighbour outside the grid is a zero token in the reference; here its WEIGHT is zeroed and the token row is read from a
+    // clamped (valid) address, so that the scalar loads are unconditional: term = tok * 0 = 0 either way
+    float pw[9];
+    const float* trow[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int ty = cy + s / 3 - 1, tx = cx + s % 3 - 1;
+        const bool inside = ty >= 0 && ty < hs && tx >= 0 && tx < ws;               // uniform over the workgroup
+        pw[s] = inside ? pr[s * HW] : 0.f;
+        trow[s] = tok + ((long)img * L + (inside ? ty * ws + tx : cy * ws + cx)) * c;
+    }
+    unsigned sat = 0;
+    for (int hb = 0; hb < 2 * nblk; ++hb) {            // 8 channels per trip: 9 x 8 token values in SGPRs
+        float acc[8];
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float tv = trow[s][hb * 8 + j];
+                acc[j] = s == 0 ? mul_rn(tv, pw[0]) : add_rn(acc[j], mul_rn(tv, pw[s]));
+            }
+        }
+        store_act8(out_act, out_plane, q_off, sexp, img, hb >> 1, hb & 1, p, HW, nblk, acc, &sat);
     }
     if (sat_out && sat) atomicAdd(sat_out, sat);
 }
@@ -231,8 +326,8 @@ __global__ void upfeat_scalar_kernel(const float* __restrict__ tok, const float*
         for (int s = 0; s < 9; ++s) {
             const int ty = cy + s / 3 - 1, tx = cx + s % 3 - 1;
             const float tv = (ty < 0 || ty >= hs || tx < 0 || tx >= ws) ? 0.f : tok[((long)img * c + ch) * L + ty * ws + tx];
-            const float term = __fmul_rn(tv, prob[((long)img * 9 + s) * HW + p]);
-            acc = s == 0 ? term : __fadd_rn(acc, term);
+            const float term = mul_rn(tv, prob[((long)img * 9 + s) * HW + p]);
+            acc = s == 0 ? term : add_rn(acc, term);
         }
         out_nchw[t] = acc;
     }
@@ -285,6 +380,12 @@ int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_
     if (c % 16 == 0) {
         if (out_act && (out_act->c != c || (out_act->q_off && c % 32))) { set_error("upfeat: act of %d channels for c=%d", out_act->c, c); return DISCO_ESHAPE; }
         const long total = (long)n * h * sp * w * sp;
+        if (sp == 16 && tok_layout && out_act && !out_nchw) {
+            hipLaunchKernelGGL(upfeat_cell_kernel, dim3(n * h * w), dim3(256), 0, s, tok, prob, prob_rep, out_act->p, (long)out_act->plane,
+                               (long)out_act->q_off, out_act->sexp, sat, c, h, w);
+            DISCO_LAUNCH_CHECK("upfeat_cell_kernel");
+            return DISCO_OK;
+        }
         hipLaunchKernelGGL(upfeat_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, tok_layout, prob, prob_rep,
                            out_act ? out_act->p : nullptr, out_act ? (long)out_act->plane : 0L, out_act ? (long)out_act->q_off : 0L,
                            out_act ? out_act->sexp : 0, sat, out_nchw, n, c, h, w, sp);

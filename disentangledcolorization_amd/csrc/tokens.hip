@@ -465,7 +465,7 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
 #pragma unroll 16
             for (int c = 0; c < 64; ++c) { const float df = row[c] - cen[j * 64 + c]; d = fmaf(df, df, d); }
         } else {    // few features: plain mul + add like the reference's ((A-B)**2).sum(-1) (clusterkit.py:253-269)
-            for (int c = 0; c < D; ++c) { const float df = row[c] - cen[j * 64 + c]; d = __fadd_rn(d, __fmul_rn(df, df)); }
+            for (int c = 0; c < D; ++c) { const float df = row[c] - cen[j * 64 + c]; d = add_rn(d, mul_rn(df, df)); }
         }
         return d;
     };
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
     for (int j = 0; j < K; ++j) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int t = tid; t < L; t += NTHR) {
-            const float sc = __fadd_rn(asg[t] == j ? 1.f : 0.f, __fmul_rn(sz[t], 0.01f));
+            const float sc = add_rn(asg[t] == j ? 1.f : 0.f, mul_rn(sz[t], 0.01f));
             if (sc > bv) { bv = sc; bi = t; }   // ascending t: keeps the first maximum
         }
         red_v[tid] = bv; red_i[tid] = bi;
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void kmeans_anchor_scan_kernel(const float* __
 #pragma unroll 16
                     for (int c = 0; c < 64; ++c) { const float df = xat(t, c) - cen[j * 64 + c]; d = fmaf(df, df, d); }
                 } else {    // few features: plain mul + add like the reference's ((A-B)**2).sum(-1) (clusterkit.py:253-269)
-                    for (int c = 0; c < D; ++c) { const float df = xat(t, c) - cen[j * 64 + c]; d = __fadd_rn(d, __fmul_rn(df, df)); }
+                    for (int c = 0; c < D; ++c) { const float df = xat(t, c) - cen[j * 64 + c]; d = add_rn(d, mul_rn(df, df)); }
                 }
                 if (d < best) { best = d; bi = j; }
             }
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void kmeans_anchor_scan_kernel(const float* __
     for (int j = 0; j < K; ++j) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int t = tid; t < L; t += 256) {
-            const float sc = __fadd_rn(asg[t] == j ? 1.f : 0.f, __fmul_rn(sz[t], 0.01f));
+            const float sc = add_rn(asg[t] == j ? 1.f : 0.f, mul_rn(sz[t], 0.01f));
             if (sc > bv) { bv = sc; bi = t; }   // ascending t: keeps the first maximum
         }
         red_v[tid] = bv; red_i[tid] = bi;
@@ -788,15 +788,15 @@ __global__ __launch_bounds__(256) void select_colors_kernel(const float* __restr
     float d1[10]; int j1 = 0; float b1 = -1.f;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const float da = __fsub_rn(ca[r], ca[0]), db = __fsub_rn(cb[r], cb[0]);
-        d1[r] = sqrtf(__fadd_rn(__fmul_rn(da, da), __fmul_rn(db, db)));
+        const float da = sub_rn(ca[r], ca[0]), db = sub_rn(cb[r], cb[0]);
+        d1[r] = sqrtf(add_rn(mul_rn(da, da), mul_rn(db, db)));
         if (d1[r] > b1) { b1 = d1[r]; j1 = r; }
     }
     int j2 = 0; float b2 = -1.f;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const float da = __fsub_rn(ca[r], ca[j1]), db = __fsub_rn(cb[r], cb[j1]);
-        const float d2 = __fadd_rn(d1[r], sqrtf(__fadd_rn(__fmul_rn(da, da), __fmul_rn(db, db))));
+        const float da = sub_rn(ca[r], ca[j1]), db = sub_rn(cb[r], cb[j1]);
+        const float d2 = add_rn(d1[r], sqrtf(add_rn(mul_rn(da, da), mul_rn(db, db))));
         if (d2 > b2) { b2 = d2; j2 = r; }
     }
     const int pick[3] = {0, j1, j2};
@@ -816,11 +816,11 @@ __global__ void nearest_bin_kernel(const float* __restrict__ ab, const float* __
     const long total = (long)n * L;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long img = i / L, t = i % L;
-        const float a = __fmul_rn(ab[(img * 2 + 0) * L + t], 110.f), b = __fmul_rn(ab[(img * 2 + 1) * L + t], 110.f);
+        const float a = mul_rn(ab[(img * 2 + 0) * L + t], 110.f), b = mul_rn(ab[(img * 2 + 1) * L + t], 110.f);
         float best = INFINITY; int bi = 0;
         for (int q = 0; q < N_VOCAB; ++q) {
-            const float da = __fsub_rn(q_to_ab[q * 2], a), db = __fsub_rn(q_to_ab[q * 2 + 1], b);
-            const float d = __fadd_rn(__fmul_rn(da, da), __fmul_rn(db, db));
+            const float da = sub_rn(q_to_ab[q * 2], a), db = sub_rn(q_to_ab[q * 2 + 1], b);
+            const float d = add_rn(mul_rn(da, da), mul_rn(db, db));
             if (d < best) { best = d; bi = q; }
         }
         labels[i] = bi;
