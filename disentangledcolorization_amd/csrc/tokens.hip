@@ -155,7 +155,15 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
 // 64 x 256 hidden tile in LDS: 3 launches and 2 HBM round trips per layer become one launch.  Same MFMA order per
 // output element (k ascending, fp32 v_mfma_f32_32x32x2) and the same LayerNorm arithmetic as the separate
 // token_gemm_kernel<RELU / RES_LN> launches, so results are bit-identical to them.
-constexpr int HP = 257;   // padded row of the hidden tile
+//
+// The kernel is a serial chain of nine 64x64x64 GEMM steps per workgroup and its duration is the same for 4 and for 256
+// workgroups (one per CU), so what counts is the length of that chain:
+//   * weight tiles are DOUBLE-BUFFERED: tile i+1 travels global -> registers while step i's MFMAs run and is written to
+//     the other LDS buffer afterwards (before: load, barrier, compute, barrier - nine exposed global-load latencies);
+//   * operand tiles live in LDS as [k parity][row][k >> 1]: lane (row, k parity) of v_mfma_f32_32x32x2 reads its 32
+//     k-values of a step with eight ds_read_b128 up front instead of one ds_read_b32 in front of every MFMA.
+constexpr int RS = 36;              // operand row: 32 k-values of one parity + 4 pad floats (16-byte aligned rows, conflict-free b128)
+constexpr int OT = 2 * 64 * RS;     // floats of one 64 x 64 operand tile
 struct PostAttnArgs {
     const float* att;    // (T,64) attention output
     const float* x;      // (T,64) layer input (residual)
@@ -163,40 +171,63 @@ struct PostAttnArgs {
     float* out;          // (T,64)
     int T;
 };
+constexpr size_t POST_ATTN_SMEM = (size_t)8 * OT * sizeof(float);
+static_assert(64 * GP <= OT, "the C staging reuses an operand tile");
+
+__device__ __forceinline__ int op_idx(int row, int k) { return ((k & 1) * 64 + row) * RS + (k >> 1); }
 
 __global__ __launch_bounds__(256) void post_attention_kernel(const PostAttnArgs g) {
     extern __shared__ float smem_pa[];
-    float* sA = smem_pa;                 // [64][GP]  A tile / C staging
-    float* sB = sA + 64 * GP;            // [64][GP]  weight tile
-    float* sX = sB + 64 * GP;            // [64][GP]  x1
-    float* sH = sX + 64 * GP;            // [64][HP]  relu(x1 W1^T + b1)
+    float* sW = smem_pa;                 // 2 x OT  weight tiles (double buffer)
+    float* sA = sW + 2 * OT;             // OT      attention tile (operand layout); later the row-major [64][GP] C staging
+    float* sX = sA + OT;                 // OT      x1 (operand layout)
+    float* sH = sX + OT;                 // 4 x OT  relu(x1 W1^T + b1), one operand tile per 64 hidden units
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int row0 = blockIdx.x * 64;
     const int r = tid >> 2, cq = (tid & 3) * 16;             // epilogue mapping: thread = (row, 16 columns)
     const int row = row0 + r;
     const bool rok = row < g.T;
+    const int rows_valid = min(64, g.T - row0);
 
-    auto stage = [&](float* dst, const float* src, int ld, int rows_valid) {    // 64 x 64 tile, rows beyond rows_valid zero
-        for (int u = tid; u < 64 * 16; u += 256) {
-            const int rr = u >> 4, c4 = (u & 15) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < rows_valid) v = *reinterpret_cast<const float4*>(src + (size_t)rr * ld + c4);
-            float* d = dst + rr * GP + c4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    // weight tile i of the chain: 0 = Wo, 1..4 = W1 rows 64(i-1).., 5..8 = W2 columns 64(i-5)..
+    float4 wreg[4];
+    auto wload = [&](int i) {
+        const float* src = i == 0 ? g.wo : (i <= 4 ? g.w1 + (size_t)(i - 1) * 64 * 64 : g.w2 + (size_t)(i - 5) * 64);
+        const int ld = i <= 4 ? 64 : 256;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int u = tid + 256 * t;
+            wreg[t] = *reinterpret_cast<const float4*>(src + (size_t)(u >> 4) * ld + (u & 15) * 4);
         }
     };
-    auto mma = [&](f32x16& acc, const float* a_tile, int lda) {    // acc += a_tile[wm rows][0..63] * sB[wn cols][0..63]^T
-        const float* pa = a_tile + (wm * 32 + (lane & 31)) * lda + (lane >> 5);
-        const float* pb = sB + (wn * 32 + (lane & 31)) * GP + (lane >> 5);
-#pragma unroll 8
-        for (int k = 0; k < 64; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+    auto put4 = [&](float* tile, int rr, int c4, const float4& v) {         // columns c4..c4+3 of row rr into the operand layout
+        *reinterpret_cast<float2*>(tile + rr * RS + (c4 >> 1)) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2*>(tile + (64 + rr) * RS + (c4 >> 1)) = make_float2(v.y, v.w);
     };
-    auto to_lds = [&](const f32x16& acc, float* dst, int ld, int col_off) {   // C tile: row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int u = tid + 256 * t; put4(sW + buf * OT, u >> 4, (u & 15) * 4, wreg[t]); }
+    };
+    auto mma = [&](f32x16& acc, const float* a_tile, const float* b_tile) {    // acc += a_tile[wm rows] * b_tile[wn rows]^T, k ascending
+        const float4* pa = reinterpret_cast<const float4*>(a_tile + ((lane >> 5) * 64 + wm * 32 + (lane & 31)) * RS);
+        const float4* pb = reinterpret_cast<const float4*>(b_tile + ((lane >> 5) * 64 + wn * 32 + (lane & 31)) * RS);
+        float4 av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { av[q] = pa[q]; bv[q] = pb[q]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
+        }
+    };
+    auto to_staging = [&](const f32x16& acc) {   // C tile: row = (e&3) + 8*(e>>2) + 4*(lane>>5), row-major [64][GP] in sA
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int rr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            dst[rr * ld + col_off + wn * 32 + (lane & 31)] = acc[e];
+            sA[rr * GP + wn * 32 + (lane & 31)] = acc[e];
         }
     };
     auto layer_norm = [&](float* v, const float* w, const float* b) {      // biased variance, eps 1e-5, over the 64 columns
@@ -213,18 +244,26 @@ __global__ __launch_bounds__(256) void post_attention_kernel(const PostAttnArgs 
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = (v[j] - mean) * rstd * w[cq + j] + b[cq + j];
     };
-    const int rows_valid = min(64, g.T - row0);
     f32x16 acc;
 
     // ---- x1 = LN1(x + att Wo^T + bo) ----
-    stage(sA, g.att + (size_t)row0 * 64, 64, rows_valid);
-    stage(sB, g.wo, 64, 64);
+    wload(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                               // attention tile, rows beyond T zero
+        const int u = tid + 256 * t, rr = u >> 4, c4 = (u & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < rows_valid) v = *reinterpret_cast<const float4*>(g.att + (size_t)(row0 + rr) * 64 + c4);
+        put4(sA, rr, c4, v);
+    }
+    wstore(0);
     __syncthreads();
+    wload(1);
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    mma(acc, sA, GP);
-    __syncthreads();
-    to_lds(acc, sA, GP, 0);
+    mma(acc, sA, sW);
+    wstore(1);
+    __syncthreads();                                             // every wave is done with the attention tile
+    to_staging(acc);
     __syncthreads();
     {
         float v[16];
@@ -237,40 +276,42 @@ __global__ __launch_bounds__(256) void post_attention_kernel(const PostAttnArgs 
         }
         layer_norm(v, g.n1w, g.n1b);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) sX[r * GP + cq + j] = rok ? v[j] : 0.f;
+        for (int j = 0; j < 16; ++j) sX[op_idx(r, cq + j)] = rok ? v[j] : 0.f;
     }
-    // ---- h = relu(x1 W1^T + b1): four 64-column blocks ----
+    // ---- h = relu(x1 W1^T + b1): four 64-column blocks (weight tiles 1..4) ----
     for (int cb = 0; cb < 4; ++cb) {
-        __syncthreads();                                         // sX complete / sB of the previous block consumed
-        stage(sB, g.w1 + (size_t)cb * 64 * 64, 64, 64);
-        __syncthreads();
+        const int i = 1 + cb;
+        __syncthreads();                 // sX complete / tile i complete in buffer i&1 / buffer (i+1)&1 no longer read
+        wload(i + 1);
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        mma(acc, sX, GP);
+        mma(acc, sX, sW + (i & 1) * OT);
         // + bias, relu, straight from the accumulator layout into the hidden tile
+        const int col = cb * 64 + wn * 32 + (lane & 31);
+        const float bias = g.b1[col];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int rr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            const int col = cb * 64 + wn * 32 + (lane & 31);
-            sH[rr * HP + col] = fmaxf(acc[e] + g.b1[col], 0.f);
+            sH[cb * OT + op_idx(rr, col & 63)] = fmaxf(acc[e] + bias, 0.f);
         }
+        wstore((i + 1) & 1);
     }
-    // ---- out = LN2(x1 + h W2^T + b2): K = 256 in four chunks ----
+    // ---- out = LN2(x1 + h W2^T + b2): K = 256 in four chunks (weight tiles 5..8) ----
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int kc = 0; kc < 4; ++kc) {
-        __syncthreads();                                         // sH complete / sB of the previous chunk consumed
-        stage(sB, g.w2 + (size_t)kc * 64, 256, 64);
-        __syncthreads();
-        mma(acc, sH + kc * 64, HP);
+        const int i = 5 + kc;
+        __syncthreads();                 // sH complete / tile i complete / the other buffer no longer read
+        if (kc < 3) wload(i + 1);
+        mma(acc, sH + kc * OT, sW + (i & 1) * OT);
+        if (kc < 3) wstore((i + 1) & 1);
     }
-    __syncthreads();
-    to_lds(acc, sA, GP, 0);
+    to_staging(acc);                     // sA has not been read since LN1
     __syncthreads();
     {
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = sA[r * GP + cq + j] + g.b2[cq + j] + sX[r * GP + cq + j];
+        for (int j = 0; j < 16; ++j) v[j] = sA[r * GP + cq + j] + g.b2[cq + j] + sX[op_idx(r, cq + j)];
         layer_norm(v, g.n2w, g.n2b);
         if (rok) {
             float* o = g.out + (size_t)row * 64 + cq;
@@ -905,14 +946,14 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         float* dst = layer == ENC_LAYERS - 1 ? out : pp[layer & 1];
         {
             PostAttnArgs pa{att, cur, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, dst, T};
-            constexpr size_t smem = (size_t)(3 * 64 * GP + 64 * HP) * sizeof(float);
-            static bool attr_set[DISCO_MAX_DEVICES] = {};      // per device
-            const int dev = current_device();
-            if (!attr_set[dev]) {
-                DISCO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(post_attention_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                attr_set[dev] = true;
-            }
+            constexpr size_t smem = POST_ATTN_SMEM;
+            static std::once_flag attr_once[DISCO_MAX_DEVICES];      // per device; two host threads may get here together
+            hipError_t attr_err = hipSuccess;
+            std::call_once(attr_once[current_device()], [&] {
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(post_attention_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            });
+            DISCO_HIP_CHECK(attr_err);
             hipLaunchKernelGGL(post_attention_kernel, dim3(cdiv(T, 64)), dim3(256), smem, s, pa);
             DISCO_LAUNCH_CHECK("post_attention_kernel");
         }
