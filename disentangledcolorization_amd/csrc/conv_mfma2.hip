@@ -243,11 +243,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_mfma2_kernel(const ConvA
         // (the 16x32-pixel configurations, 88% of the conv time): the pixel fragment of (mt = 1, ky) is the fragment of
         // (mt = 0, ky + 1) - row y + ky + 1, same column shift - so it stays in registers and every step loads ONE new
         // row instead of two (24 instead of 36 pixel-fragment reads per chunk, -17% LDS read traffic).
-        constexpr bool ROWREUSE = STRIDE == 1 && G::ROWS_PER_MB == 1 && MT == 2;
+        // the tap ORDER is a property of the tile width alone (never of how the tile is split over waves): every instantiation
+        // that can serve a given layer shape accumulates in the same order, so a result does not depend on the batch size
+        constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
+        constexpr bool ROWREUSE = COLMAJOR && MT == 2;
         f16x8 ah[MT], al[MT];
 #pragma unroll
         for (int slot = 0; slot < 9; ++slot) {
-            const int ky = ROWREUSE ? slot % 3 : slot / 3, kx = ROWREUSE ? slot / 3 : slot % 3;
+            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
             const int tap = ky * 3 + kx;
             issue(dma_img, dma_ck, buf, slot);           // one ninth of the next chunk's DMA per step (buf already flipped)
             const bool live = !MASKED || ((cmask >> tap) & 1u);   // wave-uniform: all-zero taps (sub-pixel up-conv / deconv / s2d phases) skip the MFMAs
@@ -564,8 +567,8 @@ int dispatch2(const ConvArgs& a, hipStream_t s) {
             case 1: return launch_cfg2<32, 16, 1, 1, X3, 8, 1>(a, s);
             case 2: return launch_cfg2<32, 8, 2, 1, X3, 4, 2>(a, s);
             case 3: return launch_cfg2<16, 16, 2, 1, X3, 4, 2>(a, s);
-            case 4: return launch_cfg2<32, 8, 1, 1, X3, 4, 1>(a, s);
-            default: return launch_cfg2<16, 16, 1, 1, X3, 4, 1>(a, s);
+            case 4: return launch_cfg2<32, 8, 1, 1, X3, 8, 1>(a, s);
+            default: return launch_cfg2<16, 16, 1, 1, X3, 8, 1>(a, s);
         }
     }
     if (wide) return nt2 ? launch_cfg2<32, 4, 2, 2, X3, 4, 2>(a, s) : launch_cfg2<32, 4, 1, 2, X3, 4, 1>(a, s);

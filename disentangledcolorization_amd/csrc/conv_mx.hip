@@ -235,7 +235,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         const char* sA = smem + buf * BUF_BYTES;
         const char* sW = sA + A_BYTES;
         buf ^= 1;
-        constexpr bool ROWREUSE = STRIDE == 1 && G::ROWS_PER_MB == 1 && MT == 2;
+        // the tap ORDER is a property of the tile width alone (never of how the tile is split over waves): every instantiation
+        // that can serve a given layer shape accumulates in the same order, so a result does not depend on the batch size
+        constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
+        constexpr bool ROWREUSE = COLMAJOR && MT == 2;
         const int asc = (NSRC2 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
         // this chunk's three column addresses inside the current buffer (the only per-chunk address arithmetic)
         const int bufoff = (int)(sA - smem);
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         i32x4 rb[NTW][2];
 #pragma unroll
         for (int slot = 0; slot < 9; ++slot) {
-            const int ky = ROWREUSE ? slot % 3 : slot / 3, kx = ROWREUSE ? slot / 3 : slot % 3;
+            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
             const int tap = ky * 3 + kx;
 #if !(MX_ABL & 1)
             issue(dma_img, dma_ck, buf, slot);
@@ -614,8 +617,8 @@ int dispatch_mx(const ConvMxArgs& a, hipStream_t s) {
             case 1: return launch_mx2<32, 16, 1, 1, 8, 1>(a, s);
             case 2: return launch_mx2<32, 8, 2, 1, 4, 2>(a, s);
             case 3: return launch_mx2<16, 16, 2, 1, 4, 2>(a, s);
-            case 4: return launch_mx2<32, 8, 1, 1, 4, 1>(a, s);
-            default: return launch_mx2<16, 16, 1, 1, 4, 1>(a, s);
+            case 4: return launch_mx2<32, 8, 1, 1, 8, 1>(a, s);
+            default: return launch_mx2<16, 16, 1, 1, 8, 1>(a, s);
         }
     }
     if (wide) return nt2 ? launch_mx2<32, 4, 2, 2, 4, 2>(a, s) : launch_mx2<32, 4, 1, 2, 4, 1>(a, s);
