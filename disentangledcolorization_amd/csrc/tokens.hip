@@ -626,24 +626,34 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
     float* hm = hint_mask + (size_t)img * L;
     for (int t = tid; t < L; t += NTHR) hm[t] = 0.f;
     __syncthreads();
+    // (value, index) maxima under "greater value, then lower index" - an order, so any reduction tree gives the first maximum:
+    // shuffles inside each wave, one LDS round across the 16 waves, all K clusters behind the same two barriers
     for (int j = 0; j < K; ++j) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int t = tid; t < L; t += NTHR) {
             const float sc = add_rn(asg[t] == j ? 1.f : 0.f, mul_rn(sz[t], 0.01f));
             if (sc > bv) { bv = sc; bi = t; }   // ascending t: keeps the first maximum
         }
-        red_v[tid] = bv; red_i[tid] = bi;
-        __syncthreads();
-        for (int s = NTHR / 2; s > 0; s >>= 1) {
-            if (tid < s) {
-                const float ov = red_v[tid + s]; const int oi = red_i[tid + s];
-                if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) { red_v[tid] = ov; red_i[tid] = oi; }
-            }
-            __syncthreads();
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if (tid == 0) { anchor_out[img * K + j] = red_i[0]; hm[red_i[0]] += 1.f; }
-        __syncthreads();
+        if (lane == 0) { red_v[j * NW + wave] = bv; red_i[j * NW + wave] = bi; }
     }
+    __syncthreads();
+    if (tid < K) {
+        float bv = red_v[tid * NW]; int bi = red_i[tid * NW];
+        for (int w = 1; w < NW; ++w) {
+            const float ov = red_v[tid * NW + w]; const int oi = red_i[tid * NW + w];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        anchor_out[img * K + tid] = bi;
+        red_i[tid * NW] = bi;
+    }
+    __syncthreads();
+    if (tid == 0)
+        for (int j = 0; j < K; ++j) hm[red_i[j * NW]] += 1.f;       // sequential: two clusters may share an anchor
     if (tid == 0 && info) { info[img * 2] = passes; info[img * 2 + 1] = s_events; }
 }
 
