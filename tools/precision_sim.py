@@ -8,6 +8,8 @@ Every 3x3 conv of the oracle is replaced by an emulation of how the HIP kernel w
   mx8   : w_h a_h + q8(w_h) q8(a_l) + q8(w_l) q8(a_h)          (1 fp16 MFMA + 2 block-scaled fp8 e4m3 K=64 MFMAs)
           q8 = fp8 e4m3 with a power-of-two scale per 32 consecutive input channels (per pixel / per cout and tap)
   mx8u  : same with ONE power-of-two scale per tensor (per layer input, per layer weight)
+  x2q   : w_h a_h + w_l a_h + q8(w) q8(a_l)    (2 fp16 MFMAs + 1 fp8: the weight residual exact, the activation residual in fp8)
+  x2qw  : w_h a_h + w_h a_l + q8(w_l) q8(a_h)  (the mirror image)
 and the end-to-end deviation of pred_colors from the fp32 oracle and anchor agreement are reported.
 
     python tools/precision_sim.py [--size 128] [--seeds 4] [--modes mx8,mx8u,wh]
@@ -78,6 +80,10 @@ class Emu:
             y = cv(ah, wh + wl)
         elif mode == "mx8":
             y = cv(ah, wh) + cv(q8_block(al, 1), q8_block(wh, 1)) + cv(q8_block(ah, 1), q8_block(wl, 1))
+        elif mode == "x2q":      # weight-side correction exact in fp16, only the activation residual in fp8
+            y = cv(ah, wh) + cv(ah, wl) + cv(q8_tensor(al), q8_tensor(w))
+        elif mode == "x2qw":     # the mirror image: activation-side correction exact, weight residual in fp8
+            y = cv(ah, wh) + cv(al, wh) + cv(q8_tensor(ah), q8_tensor(wl))
         elif mode == "mx8u":
             y = cv(ah, wh) + cv(q8_tensor(al), q8_tensor(wh)) + cv(q8_tensor(ah), q8_tensor(wl))
         else:
@@ -113,6 +119,8 @@ def main():
             if args.scope == "enhance" and not key.startswith("enhanceNet"):
                 return "x3"
             if args.scope == "repnet" and not key.startswith("repnet"):
+                return "x3"
+            if args.scope == "anchor" and not (key.startswith("repnet") or key.startswith("segnet")):
                 return "x3"
             return mode
         worst, flips = 0.0, 0
