@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="fix the TOTAL batch instead (tests; ragged shards allowed)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="mx8", choices=["mx8", "mx8all", "f16x3", "f16x1"])
+    ap.add_argument("--precision", default="mx8", choices=["mx8", "x2q", "mx8all", "f16x3", "f16x1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with one thread per host core (minutes on a 256-core box)")
     ap.add_argument("--micro", type=int, default=1, help="micro-batches per GPU, each on its own HIP stream (2: +1.7%, 1749 vs 1720 img/s, but concurrent streams blur the per-launch conv timings the roofline is computed from, so the default stays 1)")
@@ -238,6 +238,8 @@ def main():
             "vs_baseline": None,
             "dtype": {"mx8": "f16x3 (fp16 hi/lo split, 3 MFMA products) for SpixelNet+ColorProbNet; f16+fp8x2 (fp16 main product + two fp8 e4m3 "
                              "correction products in one K=64 MFMA) for HourGlass2; fp32 accumulate",
+                      "x2q": "f16x3 for SpixelNet; f16x2+fp8 (w_h a_h + w_l a_h in fp16, fp8(w) fp8(a_l) in one K=64 MFMA per 64 channels) for "
+                             "ColorProbNet; f16+fp8x2 for HourGlass2; fp32 accumulate",
                       "mx8all": "f16+fp8x2 (fp16 main product + two fp8 e4m3 correction products), fp32 accumulate - not anchor-safe",
                       "f16x3": "f16x3 (fp16 hi/lo split operands, fp32 accumulate)", "f16x1": "f16"}[args.precision],
             "data": "synthetic",

@@ -117,6 +117,7 @@ struct ConvLayer {
     int kind = 0;                 // 0 plain 3x3, 1 ConvTranspose 4x4 s2 as 4-phase conv, 2 upsample+3x3 as 4-phase conv
     bool s2d = false;             // stride-2 layer: weights packed for the space-to-depth view of the input
     bool mx = false;              // packed for conv3x3_mx_kernel (fp16 main product + fp8 corrections)
+    int x2q = 0;                  // mx: packed for the kernel's f16x2 + fp8 arithmetic (sources with al8-only q planes)
     int c_out_k = 0;              // mx: output channels the kernel computes (c_out padded with zero weights so that act
                                   // outputs carry whole 32-channel blocks; per phase for the depth-to-space kinds)
     int c_real = 0;               // real (reference) output channels, per phase for kinds 1 and 2: FLOP accounting
@@ -272,11 +273,18 @@ void bn_affine(disco_ctx* c, const std::string& key, std::vector<float>& scale, 
 // discrete decision, and the ~3e-5 perturbation of the fp8-corrected arithmetic at the encoder output flipped them in 1 of
 // 108 images against the fp32 oracle (tools/anchor_stability.py, profiles/r02_anchor_stability.txt), f16x3 in none.
 // DISCO_PREC_MX8_ALL runs every layer on the mx kernel (measurements only: not anchor-safe).
-bool any_mx(const disco_ctx* c) { return c->opt.precision == DISCO_PREC_MX8 || c->opt.precision == DISCO_PREC_MX8_ALL; }
-bool use_mx(const disco_ctx* c, const std::string& key) {
-    if (c->opt.precision == DISCO_PREC_MX8_ALL) return true;
-    return c->opt.precision == DISCO_PREC_MX8 && key.compare(0, 11, "enhanceNet.") == 0;
+// DISCO_PREC_X2Q: as MX8, and the ColorProbNet on the kernel's second arithmetic (f16x2 + fp8: both fp16 products of the hi
+// plane, only the activation residual through fp8 - conv_mx.hip), 5 pipe units instead of 6.
+enum { ARITH_F16X3 = 0, ARITH_MX8 = 1, ARITH_X2Q = 2 };
+bool any_mx(const disco_ctx* c) { return c->opt.precision == DISCO_PREC_MX8 || c->opt.precision == DISCO_PREC_MX8_ALL || c->opt.precision == DISCO_PREC_X2Q; }
+int arith_of(const disco_ctx* c, const std::string& key) {
+    if (c->opt.precision == DISCO_PREC_MX8_ALL) return ARITH_MX8;
+    if (c->opt.precision != DISCO_PREC_MX8 && c->opt.precision != DISCO_PREC_X2Q) return ARITH_F16X3;
+    if (key.compare(0, 11, "enhanceNet.") == 0) return ARITH_MX8;
+    if (c->opt.precision == DISCO_PREC_X2Q && key.compare(0, 7, "repnet.") == 0) return ARITH_X2Q;
+    return ARITH_F16X3;
 }
+bool use_mx(const disco_ctx* c, const std::string& key) { return arith_of(c, key) != ARITH_F16X3; }
 int pad_cout_mx(int co) { return co <= 32 ? 32 : round_up(co, 64); }
 
 // upload bias / BN affine padded to `n` channels (bias 0, scale 1, shift 0 beyond the real ones)
@@ -288,12 +296,13 @@ int upload_padded(disco_ctx* c, std::vector<float> v, size_t n, float fill, floa
 // Pack and upload the weights of an mx layer.  w: (co, ci, 3, 3) effective weights; ci_map / c_in_pad describe the packed
 // input channels (multiples of 32 per source); act_out: the layer writes an activation tensor, so its output channels are
 // padded to whole blocks with zero weights (fp32 NCHW outputs keep their real channel count).
-int finish_mx(disco_ctx* c, ConvLayer& L, const std::vector<float>& w, int co, int ci, const int* ci_map, int c_in_pad, bool act_out) {
-    L.mx = true; L.c_in = ci; L.c_in_pad = c_in_pad;
+int finish_mx(disco_ctx* c, ConvLayer& L, const std::vector<float>& w, int co, int ci, const int* ci_map, int c_in_pad, bool act_out, int x2q = 0) {
+    L.mx = true; L.x2q = x2q; L.c_in = ci; L.c_in_pad = c_in_pad;
     L.c_out_k = act_out ? pad_cout_mx(co) : co;
-    std::vector<char> packed(conv_mx_packed_bytes(L.c_out_k, c_in_pad));
+    if (x2q && c_in_pad % 64) { set_error("the f16x2+fp8 arithmetic needs a multiple of 64 input channels (%d)", c_in_pad); return DISCO_ESHAPE; }
+    std::vector<char> packed(conv_mx_packed_bytes(L.c_out_k, c_in_pad, x2q));
     std::vector<int32_t> wexp((size_t)round_up(L.c_out_k, 32));
-    conv_mx_pack_host(w.data(), co, ci, ci_map, c_in_pad, packed.data(), wexp.data());     // rows >= co pack as zeros
+    conv_mx_pack_host(w.data(), co, ci, ci_map, c_in_pad, packed.data(), wexp.data(), x2q);     // rows >= co pack as zeros
     int rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w);
     if (rc) return rc;
     return upload_vec(c, wexp, &L.d_wexp);
@@ -322,8 +331,9 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
     L.c_in = ci; L.c_out = co; L.c_real = co;
     int rc;
     if (use_mx(c, key)) {
-        const int cpad = c_in_pad_override ? c_in_pad_override : round_up(ci, 32);
-        if ((rc = finish_mx(c, L, w, co, ci, ci_map ? ci_map->data() : nullptr, cpad, act_out))) return rc;
+        const int x2q = arith_of(c, key) == ARITH_X2Q;
+        const int cpad = c_in_pad_override ? c_in_pad_override : round_up(ci, x2q ? 64 : 32);
+        if ((rc = finish_mx(c, L, w, co, ci, ci_map ? ci_map->data() : nullptr, cpad, act_out, x2q))) return rc;
         if ((rc = upload_padded(c, bias, (size_t)L.c_out_k, 0.f, &L.d_bias))) return rc;
         if (!post_bn.empty()) {
             std::vector<float> sc, sh;
@@ -386,14 +396,14 @@ int make_c1(disco_ctx* c, const std::string& key, const std::string& fold_bn) {
 
 // 4-phase weights (4*co, ci, 3, 3), phase-major, of a depth-to-space layer -> the mx layer: every phase padded to whole
 // 32-channel blocks (zero weights), bias repeated per phase by the kernel (parameters are indexed modulo the phase size)
-int finish_phase_mx(disco_ctx* c, ConvLayer& L, const std::vector<float>& w4, int co, int ci, const std::vector<float>& bias) {
+int finish_phase_mx(disco_ctx* c, ConvLayer& L, const std::vector<float>& w4, int co, int ci, const std::vector<float>& bias, int x2q = 0) {
     const int cop = round_up(co, 32);
     std::vector<float> wp((size_t)4 * cop * ci * 9, 0.f);
     for (int ph = 0; ph < 4; ++ph)
         for (int o = 0; o < co; ++o)
             std::copy(w4.begin() + ((size_t)(ph * co + o)) * ci * 9, w4.begin() + ((size_t)(ph * co + o) + 1) * ci * 9,
                       wp.begin() + ((size_t)(ph * cop + o)) * ci * 9);
-    int rc = finish_mx(c, L, wp, 4 * cop, ci, nullptr, round_up(ci, 32), true);
+    int rc = finish_mx(c, L, wp, 4 * cop, ci, nullptr, round_up(ci, x2q ? 64 : 32), true, x2q);
     if (rc) return rc;
     L.c_out = 4 * cop; L.c_real = co;
     std::vector<uint32_t> mask(cdiv(L.c_out_k, 32));
@@ -439,7 +449,7 @@ int make_upconv(disco_ctx* c, const std::string& key) {
     L.c_in = ci; L.c_out = 4 * co; L.c_real = co; L.c_in_pad = round_up(ci, 16); L.kind = 2;
     int rc;
     if (use_mx(c, key)) {
-        if ((rc = finish_phase_mx(c, L, w4, co, ci, T(c, key + ".bias").data))) return rc;
+        if ((rc = finish_phase_mx(c, L, w4, co, ci, T(c, key + ".bias").data, arith_of(c, key) == ARITH_X2Q))) return rc;
         c->conv[key] = L;
         return DISCO_OK;
     }
@@ -506,17 +516,19 @@ struct Plan {
         return dry ? (void*)(uintptr_t)(off + 256) : (void*)(base + off);   // dry: fake non-null token
     }
     void drop(void* p) { if (p) arena.release(dry ? (size_t)(uintptr_t)p - 256 : (size_t)((char*)p - base)); }
-    // planes of an activation tensor: F_LO = fp16 lo plane, F_Q = fp8 q planes (scale exponent of producer `key`)
-    enum { F_LO = 1, F_Q = 2 };
-    bool mx_stage = false;        // the stack being planned runs on the mx kernel (set per network by the plan)
-    bool mx() const { return mx_stage; }
-    int cpad(int ch) const { return round_up(ch, mx() ? 32 : 16); }
-    int dfmt() const { return mx() ? (int)F_Q : (int)F_LO; }          // what a conv -> conv tensor carries
+    // planes of an activation tensor: F_LO = fp16 lo plane, F_Q = fp8 q planes a8|al8 (scale exponent of producer `key`),
+    // F_QL = al8-only q planes (the operand of the f16x2+fp8 arithmetic)
+    enum { F_LO = 1, F_Q = 2, F_QL = 4 };
+    int stage_arith = ARITH_F16X3;     // arithmetic of the stack being planned (set per network by the plan)
+    bool mx() const { return stage_arith != ARITH_F16X3; }
+    int cpad(int ch) const { return round_up(ch, stage_arith == ARITH_X2Q ? 64 : (mx() ? 32 : 16)); }
+    int dfmt() const { return stage_arith == ARITH_X2Q ? (int)F_QL : (mx() ? (int)F_Q : (int)F_LO); }          // what a conv -> conv tensor carries
     Act act(int n, int h, int w, int ch, int fmt) {
         Act t; t.n = n; t.h = h; t.w = w; t.c = ch;
         const size_t el = t.elems();
         t.plane = (fmt & F_LO) ? el : 0;
-        t.q_off = (fmt & F_Q) ? el * 2 * ((fmt & F_LO) ? 2 : 1) : 0;
+        t.q_off = (fmt & (F_Q | F_QL)) ? el * 2 * ((fmt & F_LO) ? 2 : 1) : 0;
+        t.q_kind = (fmt & F_QL) ? 1 : 0;
         t.p = (f16*)raw(t.bytes());
         return t;
     }
@@ -580,7 +592,7 @@ struct Plan {
         else if (!out_f32) out = act(in0.n, ho, wo, co_t, ofmt);
         if (dry || !ok()) return out;
         if (in0.c + (in1 ? in1->c : 0) != L.c_in_pad) { set_error("conv %s: input channels %d != %d", key.c_str(), in0.c + (in1 ? in1->c : 0), L.c_in_pad); rc = DISCO_ESHAPE; return out; }
-        if (!out_f32 && (ofmt & F_Q) && !scale_of(key, &out.sexp)) return out;
+        if (!out_f32 && (ofmt & (F_Q | F_QL)) && !scale_of(key, &out.sexp)) return out;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = c->profiling >= 2 && !calib && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
         if (timed) hipEventRecord(e0, s);
@@ -591,7 +603,7 @@ struct Plan {
                 const int ups[2] = {up0, up1};
                 ca.nsrc = in1 ? 2 : 1;
                 for (int i = 0; i < ca.nsrc; ++i) {
-                    if (!src[i]->q_off || src[i]->q_off >= ((size_t)1 << 32)) { set_error("conv %s: source %d has no (addressable) q planes", key.c_str(), i); rc = DISCO_ESHAPE; return; }
+                    if (!src[i]->q_off || src[i]->q_off >= ((size_t)1 << 32) || src[i]->q_kind != L.x2q) { set_error("conv %s: source %d has no (addressable) q planes of kind %d", key.c_str(), i, L.x2q); rc = DISCO_ESHAPE; return; }
                     ca.src[i] = {src[i]->p, (uint32_t)src[i]->q_off, src[i]->c, src[i]->h, src[i]->w, ups[i], src[i]->sexp};
                 }
                 ca.n = in0.n; ca.h_in = hin; ca.w_in = win; ca.c_in = L.c_in_pad;
@@ -599,9 +611,9 @@ struct Plan {
                 ca.w = L.d_w; ca.wexp = L.d_wexp; ca.tapmask = L.d_tapmask; ca.c_out = co_t; ca.c_out_pad = co_t;
                 ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
                 ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
-                ca.out = out.p; ca.out_plane = (long)out.plane; ca.out_q_off = out.q_off; ca.out_sexp = out.sexp;
+                ca.out = out.p; ca.out_plane = (long)out.plane; ca.out_q_off = out.q_off; ca.out_sexp = out.sexp; ca.out_q_kind = out.q_kind;
                 ca.out_f32 = out_f32; ca.d2s_c = d2s ? co_t / 4 : 0; ca.softmax = softmax ? 1 : 0;
-                ca.act = actc; ca.slope = slope; ca.sat = calib ? nullptr : c->d_sat;
+                ca.act = actc; ca.slope = slope; ca.sat = calib ? nullptr : c->d_sat; ca.x2q = L.x2q;
                 rc = launch_conv3x3_mx(ca, s);
             };
             launch();
@@ -634,11 +646,11 @@ struct Plan {
             const double taps = L.kind == 1 ? 16.0 * L.c_real : (L.kind == 2 ? 36.0 * L.c_real : 9.0 * L.c_real);
             // compulsory HBM bytes: every source plane the kernel reads once (4 B per element: hi + lo, or hi + two fp8 planes), every
             // output plane written once, the residual read once, the packed weights once
-            const double bpe_out = out_f32 ? 4.0 : 2.0 * (1 + ((ofmt & F_LO) ? 1 : 0) + ((ofmt & F_Q) ? 1 : 0));
-            double bytes = 4.0 * in0.n * ((double)in0.c * in0.h * in0.w + (in1 ? (double)in1->c * in1->h * in1->w : 0.0));
+            const double bpe_out = out_f32 ? 4.0 : 2.0 * (1 + ((ofmt & F_LO) ? 1 : 0) + ((ofmt & F_Q) ? 1 : 0)) + ((ofmt & F_QL) ? 1.0 : 0.0);
+            double bytes = (L.x2q ? 3.0 : 4.0) * in0.n * ((double)in0.c * in0.h * in0.w + (in1 ? (double)in1->c * in1->h * in1->w : 0.0));
             bytes += bpe_out * in0.n * (double)(out_f32 ? L.c_real : co_t) * ho * wo;
             if (res) bytes += 4.0 * in0.n * (double)co_t * ho * wo;
-            bytes += L.mx ? (double)conv_mx_packed_bytes(co_t, L.c_in_pad) : (double)conv3x3_packed_bytes(L.c_out, L.s2d ? 4 * L.c_in_pad : L.c_in_pad);
+            bytes += L.mx ? (double)conv_mx_packed_bytes(co_t, L.c_in_pad, L.x2q) : (double)conv3x3_packed_bytes(L.c_out, L.s2d ? 4 * L.c_in_pad : L.c_in_pad);
             c->conv_prof.push_back({e0, e1, 2.0 * taps * L.c_in * (double)ho * wo * in0.n, key, bytes});
         }
         return out;
@@ -663,7 +675,7 @@ constexpr int RELU = DISCO_ACT_RELU, LRELU = DISCO_ACT_LRELU, NOACT = DISCO_ACT_
 // ---- a1 SpixelNet (network.py:293-313): gray -> affinity (n,9,H,W), softmax over the 9 neighbour slots -------------
 void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int W, float* d_affinity) {
     const bool dry = P.dry;
-    P.mx_stage = use_mx(c, "segnet.");
+    P.stage_arith = arith_of(c, "segnet.");
     hipStream_t s = P.s;
     const std::string sg = "segnet.net.";
     Act s0a = P.c1(sg + "conv0a.0", d_gray, n, H, W, LRELU, 0.1f);
@@ -712,7 +724,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
 
     // ---- a2 ColorProbNet (network.py:220-236) ----------------------------------------------------------------
     const std::string rp = "repnet.";
-    P.mx_stage = use_mx(c, rp);
+    P.stage_arith = arith_of(c, rp);
     Act t = P.c1(rp + "conv1_2.0", a->d_gray, n, H, W, LRELU, 0.2f);
     Act f = P.conv(rp + "conv1_2.2", t, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(t);
     Act f3{};
@@ -819,7 +831,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     P.mark("hintpath", 2.0 * 0.134e9 * n2);
 
     // ---- a12 upfeat + a13 HourGlass2 + tanh (model.py:194-197) --------------------------------------------------
-    P.mx_stage = use_mx(c, "enhanceNet.");
+    P.stage_arith = arith_of(c, "enhanceNet.");
     Act full = P.act(n2, H, W, 64, P.dfmt());
     Act g16 = P.act(n2, H, W, P.cpad(16), P.dfmt());
     if (!dry && P.ok() && full.q_off && P.scale_of("upfeat", &full.sexp) && P.scale_of("gray16", &g16.sexp)) {}
@@ -978,7 +990,7 @@ int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (!opt || !out) { set_error("null argument"); return DISCO_EINVAL; }
     if (opt->sp_size != 16) { set_error("sp_size %d unsupported (16 only, inference.py:146)", opt->sp_size); return DISCO_EUNSUPPORTED; }
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
-    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_F16X1 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
+    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_F16X1 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL && opt->precision != DISCO_PREC_X2Q) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
     if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }
     if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("segnet_only context takes no colorizer flags"); return DISCO_EINVAL; }
     int ndev = 0;
@@ -1314,7 +1326,8 @@ static Act flat_act(const void* p, int n, int c_pad, int h, int w, int planes, i
     Act t; t.p = (f16*)p; t.n = n; t.h = h; t.w = w; t.c = c_pad; t.sexp = sexp;
     const size_t el = t.elems();
     t.plane = (planes & DISCO_PLANE_LO) ? el : 0;
-    t.q_off = (planes & DISCO_PLANE_Q) ? el * 2 * ((planes & DISCO_PLANE_LO) ? 2 : 1) : 0;
+    t.q_off = (planes & (DISCO_PLANE_Q | DISCO_PLANE_QL)) ? el * 2 * ((planes & DISCO_PLANE_LO) ? 2 : 1) : 0;
+    t.q_kind = (planes & DISCO_PLANE_QL) ? 1 : 0;
     return t;
 }
 
@@ -1326,7 +1339,7 @@ int disco_op_act_bytes(int n, int c_pad, int h, int w, int planes, size_t* bytes
 
 int disco_op_nchw_to_act_mx(const float* d_src, void* d_dst, int n, int ch, int h, int w, int c_pad, int planes, int sexp, void* stream) {
     if (!positive("nchw_to_act_mx", {n, ch, h, w, c_pad})) return DISCO_ESHAPE;
-    if (!d_src || !d_dst || c_pad < ch || c_pad % ((planes & DISCO_PLANE_Q) ? 32 : 16)) { set_error("bad argument (c_pad must be a multiple of 16, 32 with q planes, >= c)"); return DISCO_EINVAL; }
+    if (!d_src || !d_dst || c_pad < ch || c_pad % ((planes & (DISCO_PLANE_Q | DISCO_PLANE_QL)) ? 32 : 16) || (planes & DISCO_PLANE_Q && planes & DISCO_PLANE_QL)) { set_error("bad argument (c_pad must be a multiple of 16, 32 with q planes, >= c)"); return DISCO_EINVAL; }
     return launch_nchw_to_act_mx(d_src, flat_act(d_dst, n, c_pad, h, w, planes, sexp), ch, (hipStream_t)stream);
 }
 
@@ -1342,15 +1355,15 @@ int disco_op_act_mx_to_nchw(const void* d_src, float* d_dst, int n, int ch, int 
     return launch_act_q_to_nchw(t, d_dst, ch, which - 1, (hipStream_t)stream);
 }
 
-int disco_op_conv3x3_mx_pack(const float* h_w, int c_out, int c_in, void* d_packed, int32_t* d_wexp, size_t* bytes) {
+int disco_op_conv3x3_mx_pack(const float* h_w, int c_out, int c_in, int x2q, void* d_packed, int32_t* d_wexp, size_t* bytes) {
     if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }
-    const int cpad = round_up(c_in, 32);
-    *bytes = conv_mx_packed_bytes(c_out, cpad);
+    const int cpad = round_up(c_in, x2q ? 64 : 32);
+    *bytes = conv_mx_packed_bytes(c_out, cpad, x2q ? 1 : 0);
     if (!d_packed) return DISCO_OK;
     if (!h_w || !d_wexp) { set_error("null weight"); return DISCO_EINVAL; }
     std::vector<char> packed(*bytes);
     std::vector<int32_t> wexp((size_t)round_up(c_out, 32));
-    conv_mx_pack_host(h_w, c_out, c_in, nullptr, cpad, packed.data(), wexp.data());
+    conv_mx_pack_host(h_w, c_out, c_in, nullptr, cpad, packed.data(), wexp.data(), x2q ? 1 : 0);
     DISCO_HIP_CHECK(hipMemcpy(d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice));
     DISCO_HIP_CHECK(hipMemcpy(d_wexp, wexp.data(), wexp.size() * 4, hipMemcpyHostToDevice));
     return DISCO_OK;
@@ -1363,14 +1376,15 @@ int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const v
     if (!positive("conv3x3_mx", {d->n, d->h_in, d->w_in, d->c_in0, d->c_out}) || d->c_in1 < 0) { if (d->c_in1 < 0) set_error("conv3x3_mx: c_in1 %d", d->c_in1); return DISCO_ESHAPE; }
     ConvMxArgs ca{};
     const int h0 = d->up0 ? d->h_in / 2 : d->h_in, w0 = d->up0 ? d->w_in / 2 : d->w_in;
-    const Act s0 = flat_act(d_src0, d->n, d->c_in0, h0, w0, DISCO_PLANE_Q, d->sexp0);
+    const int src_planes = d->x2q ? DISCO_PLANE_QL : DISCO_PLANE_Q;
+    const Act s0 = flat_act(d_src0, d->n, d->c_in0, h0, w0, src_planes, d->sexp0);
     if (s0.q_off >= ((size_t)1 << 32)) { set_error("conv3x3_mx: source too large"); return DISCO_ESHAPE; }
     ca.src[0] = {s0.p, (uint32_t)s0.q_off, d->c_in0, h0, w0, d->up0, d->sexp0};
     ca.nsrc = 1;
     if (d->c_in1) {
         if (!d_src1) { set_error("null second source"); return DISCO_EINVAL; }
         const int h1 = d->up1 ? d->h_in / 2 : d->h_in, w1 = d->up1 ? d->w_in / 2 : d->w_in;
-        const Act s1 = flat_act(d_src1, d->n, d->c_in1, h1, w1, DISCO_PLANE_Q, d->sexp1);
+        const Act s1 = flat_act(d_src1, d->n, d->c_in1, h1, w1, src_planes, d->sexp1);
         if (s1.q_off >= ((size_t)1 << 32)) { set_error("conv3x3_mx: source too large"); return DISCO_ESHAPE; }
         ca.src[1] = {s1.p, (uint32_t)s1.q_off, d->c_in1, h1, w1, d->up1, d->sexp1};
         ca.nsrc = 2;
@@ -1382,13 +1396,13 @@ int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const v
     if (d->out_f32) ca.out_f32 = (float*)d_out;
     else {
         const Act o = flat_act(d_out, d->n, d->c_out, ca.h_out, ca.w_out, d->out_planes, d->out_sexp);
-        ca.out = o.p; ca.out_plane = (long)o.plane; ca.out_q_off = o.q_off; ca.out_sexp = d->out_sexp;
+        ca.out = o.p; ca.out_plane = (long)o.plane; ca.out_q_off = o.q_off; ca.out_sexp = d->out_sexp; ca.out_q_kind = o.q_kind;
     }
     if (d_res) {
         const Act rr = flat_act(d_res, d->n, d->c_out, ca.h_out, ca.w_out, d->res_planes, 0);
         ca.res = rr.p; ca.res_plane = (long)rr.plane;
     }
-    ca.act = d->act; ca.slope = d->slope; ca.sat = d_sat;
+    ca.act = d->act; ca.slope = d->slope; ca.sat = d_sat; ca.x2q = d->x2q ? 1 : 0;
     return launch_conv3x3_mx(ca, (hipStream_t)stream);
 }
 

@@ -41,14 +41,18 @@ static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 // q planes (optional, `q_off` != 0): fp8 e4m3 [N][C/32][2][H][W][32] at (char*)p + q_off: for every 32-channel block the
 //   plane a8 = fp8(x * 2^sexp) followed by the plane al8 = fp8((x - hi) * 2^(sexp + 11))   (the correction operands of
 //   conv3x3_mx_kernel).  sexp is a per-tensor power of two fixed at calibration time.
+//   q_kind 1: ONLY the al8 planes, [N][C/32][H][W][32] (1 byte per element): the operand of the f16x2+fp8 arithmetic, which
+//   keeps both fp16 products of the hi plane and sends just the activation residual through fp8.
 struct Act {
     f16* p = nullptr;  // hi plane; lo plane at p + plane
     int n = 0, h = 0, w = 0, c = 0;
     size_t plane = 0;  // elements between the hi and the lo plane (= n*h*w*c), 0: no lo plane
     size_t q_off = 0;  // bytes between p and the q planes, 0: none
     int sexp = 0;
+    int q_kind = 0;    // 0: a8 | al8 per 32-channel block, 1: al8 only
     size_t elems() const { return (size_t)n * h * w * c; }
-    size_t bytes() const { return elems() * sizeof(f16) * (1 + (plane ? 1 : 0) + (q_off ? 1 : 0)); }
+    size_t q_bytes() const { return q_off ? elems() * (q_kind ? 1 : 2) : 0; }
+    size_t bytes() const { return elems() * sizeof(f16) * (1 + (plane ? 1 : 0)) + q_bytes(); }
 };
 constexpr int MX_LO_SHIFT = 11;     // al8 carries 2^11 more scale than a8 (|x - fp16(x)| <= 2^-11 |x|)
 
@@ -83,7 +87,7 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
 
 // 8 consecutive channels (the half `half` of a 16-channel block `blk`) of pixel `pix` of image `img` -> the planes of an act
 __device__ __forceinline__ void store_act8(f16* hi_p, long plane, long q_off, int sexp, long img, int blk, int half, long pix, long hw,
-                                            int nblk, const float* v, unsigned* sat = nullptr) {
+                                            int nblk, const float* v, unsigned* sat = nullptr, int q_kind = 0) {
     f16x8 h, l;
     float lo[8];
 #pragma unroll
@@ -93,12 +97,15 @@ __device__ __forceinline__ void store_act8(f16* hi_p, long plane, long q_off, in
     if (plane) *reinterpret_cast<f16x8*>(o + plane) = l;
     if (q_off) {
         const float qs = ldexpf(1.f, sexp), qls = ldexpf(1.f, sexp + MX_LO_SHIFT);
-        unsigned char* q = reinterpret_cast<unsigned char*>(hi_p) + q_off + (((long)img * (nblk >> 1) + (blk >> 1)) * 2) * hw * 32 + pix * 32 + (blk & 1) * 16 + half * 8;
+        unsigned char* q = reinterpret_cast<unsigned char*>(hi_p) + q_off + (((long)img * (nblk >> 1) + (blk >> 1)) * (q_kind ? 1 : 2)) * hw * 32 + pix * 32 + (blk & 1) * 16 + half * 8;
         uint2 a, b;
-        a.x = pack_fp8x4(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, sat); a.y = pack_fp8x4(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs, sat);
         b.x = pack_fp8x4(lo[0] * qls, lo[1] * qls, lo[2] * qls, lo[3] * qls, sat); b.y = pack_fp8x4(lo[4] * qls, lo[5] * qls, lo[6] * qls, lo[7] * qls, sat);
-        *reinterpret_cast<uint2*>(q) = a;
-        *reinterpret_cast<uint2*>(q + hw * 32) = b;
+        if (q_kind) *reinterpret_cast<uint2*>(q) = b;
+        else {
+            a.x = pack_fp8x4(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, sat); a.y = pack_fp8x4(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs, sat);
+            *reinterpret_cast<uint2*>(q) = a;
+            *reinterpret_cast<uint2*>(q + hw * 32) = b;
+        }
     }
 }
 
@@ -176,10 +183,14 @@ struct ConvMxArgs {
     int softmax;
     unsigned int* sat;        // optional device counter: q-plane elements that had to be clamped to +-448
     uint32_t src_bytes[2], w_bytes, out_bytes, res_bytes;   // filled by the launcher: buffer-descriptor ranges
+    // arithmetic: 0 = f16 + fp8x2 (sources carry a8|al8 planes), 1 = f16x2 + fp8 ("x2q": w_h a_h + w_l a_h in fp16, fp8(w) fp8(a_l);
+    // one source with al8-only planes, c_in a multiple of 64, weights packed with x2q = 1)
+    int x2q;
+    int out_q_kind;           // layout of the output's q planes (Act::q_kind)
 };
-size_t conv_mx_packed_bytes(int c_out, int c_in_pad);
-// h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map as in conv3x3_pack_host; c_in_pad multiple of 32; h_wexp: cdiv(c_out,32)*32 ints
-void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp);
+size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int x2q = 0);
+// h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map as in conv3x3_pack_host; c_in_pad multiple of 32 (x2q: 64); h_wexp: cdiv(c_out,32)*32 ints
+void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int x2q = 0);
 int launch_conv3x3_mx(const ConvMxArgs& a, hipStream_t s);
 unsigned char fp8_e4m3_from_float(float x);      // round to nearest even, saturating to +-448
 float fp8_e4m3_to_float(unsigned char v);

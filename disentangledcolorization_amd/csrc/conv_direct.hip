@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
                                                       const float* __restrict__ bias, const float* __restrict__ bsc,
                                                       const float* __restrict__ bsh, f16* out, long out_plane, long q_off, int sexp,
                                                       unsigned int* sat_out, int n, int h, int wd, int c_out, int c_pad, int act,
-                                                      float slope) {
+                                                      float slope, int q_kind) {
     __shared__ float sw[16 * 9 + 48];
     const int nblk = c_pad >> 4;
     const int blk = blockIdx.y % nblk;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
             s = apply_act(s, act, slope);
             v[j] = real ? s * sw[160 + c] + sw[176 + c] : 0.f;
         }
-        store_act8(out, out_plane, q_off, sexp, img, blk, half, p, hw, nblk, v, &sat);
+        store_act8(out, out_plane, q_off, sexp, img, blk, half, p, hw, nblk, v, &sat, q_kind);
     }
     if (sat_out && sat) atomicAdd(sat_out, sat);
 }
@@ -116,7 +116,7 @@ int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, c
     // few fat workgroups per (image, block): the 192-float parameter staging + barrier is paid once per workgroup
     dim3 grid((unsigned)std::min<long>((2 * hw + 255) / 256, 64), (unsigned)(out.n * (out.c / 16)));
     hipLaunchKernelGGL(conv_c1_kernel, grid, dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale, d_bn_shift, out.p, (long)out.plane,
-                       (long)out.q_off, out.sexp, sat, out.n, out.h, out.w, c_out, out.c, act, slope);
+                       (long)out.q_off, out.sexp, sat, out.n, out.h, out.w, c_out, out.c, act, slope, out.q_kind);
     DISCO_LAUNCH_CHECK("conv_c1_kernel");
     return DISCO_OK;
 }

@@ -16,6 +16,17 @@
 // 2^-(sexp + wexp[co] + 11) to every fp8 product through the instruction's E8M0 scale operands (uniform for the pixel
 // operand, per lane = per output channel for the weight operand).
 //
+// XQ = true selects a second arithmetic on the same skeleton, for the layers whose output decides discrete results downstream:
+//
+//     w a  ~=  w_h a_h + w_l a_h                        four K = 16 fp16 MFMAs per 32 channels (w_l = fp16(w - w_h): an "L" chunk that
+//                                                        re-reads the hi plane against the residual weights)
+//            + q8(w) q8(a - a_h)                         ONE K = 64 fp8 MFMA per 64 channels (its K halves are two 32-channel blocks)
+//
+// i.e. only the ACTIVATION residual goes through fp8.  The weight residual's rounding error is the same at every pixel and
+// multiplies non-negative activations, so it survives spatial pooling (profiles/r02_precision_sim.txt: it is what moves the
+// anchors under the arithmetic above); the activation residual's is zero-mean per pixel.  5 pipe units per 32 channels and tap
+// (f16x3: 6).  Its sources carry the hi plane and al8-only q planes (Act::q_kind 1); chunk order per 64 channels: H L H L Q.
+//
 // Pipeline (same skeleton as conv_mfma2.hip): a "chunk" is 64 bytes per halo pixel and 64 bytes per (tap, output channel):
 // either the fp16 hi values of 32 channels (H chunk: two 16-channel planes) or their two fp8 planes (Q chunk).  Chunks
 // travel HBM/L2 -> LDS by LDS-DMA through raw buffer descriptors (out-of-range lanes read 0 = zero padding), double
@@ -59,8 +70,9 @@ struct GeoMx {
 };
 
 // NSRC2: the layer concatenates two sources on read (the descriptor and offsets of the second source exist only then).
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2>
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, bool XQ>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
+    static_assert(!(XQ && NSRC2), "the f16x2+fp8 arithmetic takes one source");
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = GeoMx<TW, TH, STRIDE>;
     constexpr int NWAVE = WM * WN;
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
-    const int nchunks = a.c_in >> 4;               // two chunks (H, Q) per 32 input channels
+    const int nchunks = XQ ? (a.c_in >> 6) * 5 : a.c_in >> 4;    // two chunks (H, Q) per 32 input channels; XQ: H L H L Q per 64
 
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
@@ -157,13 +169,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 
     // one ninth (part 0..8) of the DMA of chunk `ck` of image `img` into LDS buffer `buf`; part < 0: all of it
     auto issue = [&](int img, int ck, int buf, int part) {
-        const int c0 = (ck >> 1) << 5;                 // first channel of the chunk's 32-channel group
-        const bool isq = ck & 1;
+        int c0 = (ck >> 1) << 5;                       // first channel of the chunk's 32-channel group
+        bool isq = ck & 1;
+        if (XQ) {                                      // chunk 5 g64 + i: i = 0, 1: H, L of channels 64 g64 ..; 2, 3: of 64 g64 + 32 ..; 4: Q of all 64
+            const int g64 = ck / 5, i = ck - 5 * g64;
+            isq = i == 4;
+            c0 = (g64 << 6) + (isq ? 0 : (i >> 1) << 5);
+        }
         const bool s1 = NSRC2 && c0 >= c_src0;
         // hi plane: image stride C*H*W*2 bytes, 16-channel block stride H*W*32; q planes: the same image stride (2 x 1 byte
-        // per element) and 2 x H*W*32 per 32-channel block - the SAME offsets, shifted by q_off
+        // per element) and 2 x H*W*32 per 32-channel block - the SAME offsets, shifted by q_off.  XQ: al8-only planes, one byte
+        // per element: half the image stride, H*W*32 per 32-channel block.
         unsigned soff = s1 ? (unsigned)img * img_b1 + (unsigned)((c0 - c_src0) >> 4) * blk_b1 + (isq ? qo1 : 0u)
                            : (unsigned)img * img_b0 + (unsigned)(c0 >> 4) * blk_b0 + (isq ? qo0 : 0u);
+        if (XQ && isq) soff = (unsigned)img * (img_b0 >> 1) + (unsigned)(c0 >> 5) * blk_b0 + qo0;
         char* dA = smem + buf * BUF_BYTES;
         char* dW = dA + A_BYTES;
 #pragma unroll
@@ -311,9 +330,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 }
         }
     };
-    for (int ck = 0; ck < nchunks; ck += 2) {
-        chunk(std::false_type{}, ck);
-        chunk(std::true_type{}, ck + 1);
+    if constexpr (XQ) {
+        for (int ck = 0; ck < nchunks; ck += 5) {
+#pragma unroll 1
+            for (int h = 0; h < 4; ++h) chunk(std::false_type{}, ck + h);     // H, L, H, L: the same code, other weights
+            chunk(std::true_type{}, ck + 4);
+        }
+    } else {
+        for (int ck = 0; ck < nchunks; ck += 2) {
+            chunk(std::false_type{}, ck);
+            chunk(std::true_type{}, ck + 1);
+        }
     }
 
     // ---- epilogue: bias (+res) -> activation -> BN affine -> split into the output planes -> store ------------------------
@@ -341,6 +368,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         const int oh = MODE == 1 ? 2 * a.h_out : a.h_out, ow = MODE == 1 ? 2 * a.w_out : a.w_out;
         const unsigned ohw = (unsigned)(oh * ow);
         const bool wr_lo = MODE != 2 && a.out_plane != 0, wr_q = MODE != 2 && a.out_q_off != 0;
+        const bool ql_only = a.out_q_kind != 0;              // al8-only q planes: one byte per element, no a8 plane
         const float qs = __builtin_ldexpf(1.f, a.out_sexp), qls = __builtin_ldexpf(1.f, a.out_sexp + MX_LO_SHIFT);
         const __amdgpu_buffer_rsrc_t ro = MODE == 2 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.out_f32, 0, a.out_bytes, 0x00020000)
                                                     : __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 int cb = cv; unsigned php = 0;
                 if (MODE == 1) { const int ph = cv / a.d2s_c; cb = cv - ph * a.d2s_c; php = (unsigned)((ph >> 1) * ow + (ph & 1)) * 32u; }
                 so_hi[nt][q] = ((unsigned)(n * oc) + (unsigned)cb) * ohw * 2u + php;
-                so_q[nt][q] = (unsigned)a.out_q_off + ((unsigned)(n * oc) + (unsigned)(cb & ~31)) * ohw * 2u + (unsigned)(cb & 16) + php;
+                so_q[nt][q] = (unsigned)a.out_q_off + ((unsigned)(n * oc) + (unsigned)(cb & ~31)) * ohw * (ql_only ? 1u : 2u) + (unsigned)(cb & 16) + php;
             }
         // per-lane pixel offset (bytes, 32 per pixel) of M block mt, or OOB
         unsigned vo[MT];
@@ -452,7 +480,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                                 const float x = v[4 * g + j] * qs, y = lo[j] * qls;
                                 s[j] = __builtin_amdgcn_fmed3f(x, -448.f, 448.f);
                                 t[j] = __builtin_amdgcn_fmed3f(y, -448.f, 448.f);
-                                sat += (s[j] != x) + (t[j] != y);
+                                sat += (ql_only ? 0 : (s[j] != x)) + (t[j] != y);
                             }
                             int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(s[0], s[1], 0, false);
                             w0 = __builtin_amdgcn_cvt_pk_fp8_f32(s[2], s[3], w0, true);
@@ -524,8 +552,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                             // q planes: this lane owns bytes 8 kh .. 8 kh + 7 of its pixel's 16-byte half (cb & 16)
                             const i32x2 q0 = {__float_as_int(t[8 + 2 * q]), __float_as_int(t[9 + 2 * q])};
                             const i32x2 q1 = {__float_as_int(t[12 + 2 * q]), __float_as_int(t[13 + 2 * q])};
-                            __builtin_amdgcn_raw_buffer_store_b64(q0, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q], 0);
-                            __builtin_amdgcn_raw_buffer_store_b64(q1, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q] + ohw * 32u, 0);
+                            if (!ql_only) __builtin_amdgcn_raw_buffer_store_b64(q0, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q], 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(q1, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q] + (ql_only ? 0u : ohw * 32u), 0);
                         }
                     }
                 } else {
@@ -561,13 +589,13 @@ inline int num_cus_mx() {
     return n;
 }
 
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2>
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, bool XQ = false>
 int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
     using G = GeoMx<TW, TH, STRIDE>;
     constexpr int A_BYTES = ((2 * G::NPIX * 2 + 63) / 64) * 1024;
     constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2>;
+    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, XQ>;
     // function attributes are per device and per kernel instantiation (this static lives in the instantiation)
     static std::once_flag attr_once[DISCO_MAX_DEVICES];
     hipError_t attr_err = hipSuccess;
@@ -593,6 +621,7 @@ int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
 
 template <int TW, int TH, int NT, int STRIDE, int WM, int WN>
 int launch_mx2(const ConvMxArgs& a, hipStream_t s) {
+    if (a.x2q) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, true>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, true>(a, s);
     if (a.nsrc > 1) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, true>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, true>(a, s);
     return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false>(a, s);
 }
@@ -627,7 +656,7 @@ int dispatch_mx(const ConvMxArgs& a, hipStream_t s) {
 
 // ---- layout conversion / calibration helpers ------------------------------------------------------------------------------
 __global__ void nchw_to_act_mx_kernel(const float* __restrict__ src, f16* __restrict__ dst, long plane, long q_off, int sexp,
-                                      int n, int c, int h, int w, int c_pad) {
+                                      int n, int c, int h, int w, int c_pad, int q_kind) {
     // one thread per (image, 16-channel block, pixel): reads 16 strided fp32, writes 32 B hi (+ lo) (+ 16 B of each q plane)
     const long hw = (long)h * w, nblk = c_pad / 16;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,9 +684,14 @@ __global__ void nchw_to_act_mx_kernel(const float* __restrict__ src, f16* __rest
         for (int j = 0; j < 16; ++j) o[plane + j] = lo[j];
     }
     if (q_off) {
-        unsigned char* q = reinterpret_cast<unsigned char*>(dst) + q_off + (((long)img * (c_pad / 32) + (blk >> 1)) * 2) * hw * 32 + pix * 32 + (blk & 1) * 16;
+        unsigned char* q = reinterpret_cast<unsigned char*>(dst) + q_off + (((long)img * (c_pad / 32) + (blk >> 1)) * (q_kind ? 1 : 2)) * hw * 32 + pix * 32 + (blk & 1) * 16;
+        if (q_kind) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { q[j] = a8[j]; q[hw * 32 + j] = l8[j]; }
+            for (int j = 0; j < 16; ++j) q[j] = l8[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { q[j] = a8[j]; q[hw * 32 + j] = l8[j]; }
+        }
     }
 }
 
@@ -671,26 +705,26 @@ __global__ void act_amax_kernel(const f16* __restrict__ p, long elems, float* __
 
 // test helper: dequantised views of an act's q planes as fp32 NCHW: which = 0: a8 2^-sexp; 1: hi + al8 2^-(sexp+11)
 __global__ void act_q_to_nchw_kernel(const f16* __restrict__ src, long q_off, int sexp, float* __restrict__ dst, int n, int c, int h, int w,
-                                     int c_pad, int which) {
+                                     int c_pad, int which, int q_kind) {
     const long hw = (long)h * w;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * c * hw) return;
     const long pix = idx % hw; const long t = idx / hw; const int ch = (int)(t % c); const int img = (int)(t / c);
-    const unsigned char* q = reinterpret_cast<const unsigned char*>(src) + q_off + (((long)img * (c_pad / 32) + (ch >> 5)) * 2) * hw * 32 + pix * 32 + (ch & 31);
+    const unsigned char* q = reinterpret_cast<const unsigned char*>(src) + q_off + (((long)img * (c_pad / 32) + (ch >> 5)) * (q_kind ? 1 : 2)) * hw * 32 + pix * 32 + (ch & 31);
     auto dq = [](unsigned char v) -> float {
         const int sg = v >> 7, e = (v >> 3) & 15, m = v & 7;
         const float f = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.f + m / 8.f, e - 7);
         return sg ? -f : f;
     };
-    if (which == 0) dst[idx] = ldexpf(dq(q[0]), -sexp);
-    else dst[idx] = (float)src[((long)img * (c_pad / 16) + (ch >> 4)) * hw * 16 + pix * 16 + (ch & 15)] + ldexpf(dq(q[hw * 32]), -(sexp + MX_LO_SHIFT));
+    if (which == 0) dst[idx] = q_kind ? 0.f : ldexpf(dq(q[0]), -sexp);        // al8-only planes have no a8 view
+    else dst[idx] = (float)src[((long)img * (c_pad / 16) + (ch >> 4)) * hw * 16 + pix * 16 + (ch & 15)] + ldexpf(dq(q[q_kind ? 0 : hw * 32]), -(sexp + MX_LO_SHIFT));
 }
 
 }  // namespace
 
 int launch_act_q_to_nchw(const Act& a, float* dst, int c, int which, hipStream_t s) {
     const long total = (long)a.n * c * a.h * a.w;
-    hipLaunchKernelGGL(act_q_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.p, (long)a.q_off, a.sexp, dst, a.n, c, a.h, a.w, a.c, which);
+    hipLaunchKernelGGL(act_q_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.p, (long)a.q_off, a.sexp, dst, a.n, c, a.h, a.w, a.c, which, a.q_kind);
     DISCO_LAUNCH_CHECK("act_q_to_nchw_kernel");
     return DISCO_OK;
 }
@@ -699,7 +733,7 @@ int launch_nchw_to_act_mx(const float* src, const Act& dst, int c, hipStream_t s
     if (dst.c % (dst.q_off ? 32 : 16)) { set_error("nchw_to_act_mx: padded channels %d", dst.c); return DISCO_ESHAPE; }
     const long total = (long)dst.n * (dst.c / 16) * dst.h * dst.w;
     hipLaunchKernelGGL(nchw_to_act_mx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst.p, (long)dst.plane, (long)dst.q_off, dst.sexp,
-                       dst.n, c, dst.h, dst.w, dst.c);
+                       dst.n, c, dst.h, dst.w, dst.c, dst.q_kind);
     DISCO_LAUNCH_CHECK("nchw_to_act_mx_kernel");
     return DISCO_OK;
 }
@@ -733,11 +767,11 @@ unsigned char fp8_e4m3_from_float(float x) {
     return sign | (unsigned char)(((ex + 7) << 3) | ((int)rq - 8));
 }
 
-size_t conv_mx_packed_bytes(int c_out, int c_in_pad) {
-    return (size_t)cdiv(c_out, 32) * (c_in_pad / 16) * W_NB;
+size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int x2q) {
+    return (size_t)cdiv(c_out, 32) * (x2q ? (c_in_pad / 64) * 5 : c_in_pad / 16) * W_NB;
 }
 
-void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp) {
+void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int x2q) {
     unsigned char* dst = reinterpret_cast<unsigned char*>(h_packed);
     const int nb_n = cdiv(c_out, 32), ngrp = c_in_pad / 32;
     // per output channel: 2^wexp maps the largest |w| into [128, 256) (fp8 e4m3 tops out at 448)
@@ -753,6 +787,37 @@ void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map,
         const int ci = ci_map ? ci_map[cip] : (cip < c_in ? cip : -1);
         return (co < c_out && ci >= 0) ? h_w[((size_t)co * c_in + ci) * 9 + tap] : 0.f;
     };
+    if (x2q) {
+        // chunks of 64-channel group g64: 5 g64 + {0: w_h of channels 0-31, 1: w_l of the same, 2: w_h of 32-63, 3: w_l, 4: w8 of all 64}
+        const int nck = (c_in_pad / 64) * 5;
+        for (int nb = 0; nb < nb_n; ++nb)
+            for (int g64 = 0; g64 < c_in_pad / 64; ++g64)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = nb * 32 + (lane & 31), kh = lane >> 5;
+                        const float ws = std::ldexp(1.f, h_wexp[co]);
+                        for (int half = 0; half < 2; ++half) {          // the two 32-channel blocks of the group
+                            unsigned char* hb = dst + (((size_t)nb * nck + 5 * g64 + 2 * half) * 9 + tap) * 2 * WBLK;
+                            unsigned char* lb = dst + (((size_t)nb * nck + 5 * g64 + 2 * half + 1) * 9 + tap) * 2 * WBLK;
+                            for (int j = 0; j < 2; ++j) {               // piece j = fp16 weights of channels 16 j + 8 kh + 0..7 of the block
+                                f16* hp = reinterpret_cast<f16*>(hb + j * WBLK + lane * 16);
+                                f16* lp = reinterpret_cast<f16*>(lb + j * WBLK + lane * 16);
+                                for (int i = 0; i < 8; ++i) {
+                                    const float w = wat(co, g64 * 64 + half * 32 + 16 * j + 8 * kh + i, tap);
+                                    hp[i] = (f16)w;
+                                    lp[i] = (f16)(w - (float)hp[i]);
+                                }
+                            }
+                        }
+                        // Q chunk: the lane's 32 bytes = w8 of the 32 channels of block kh; piece j = bytes 16 j .. 16 j + 15
+                        unsigned char* qb = dst + (((size_t)nb * nck + 5 * g64 + 4) * 9 + tap) * 2 * WBLK;
+                        for (int j = 0; j < 2; ++j) {
+                            unsigned char* qp = qb + j * WBLK + lane * 16;
+                            for (int i = 0; i < 16; ++i) qp[i] = fp8_e4m3_from_float(wat(co, g64 * 64 + kh * 32 + 16 * j + i, tap) * ws);
+                        }
+                    }
+        return;
+    }
     for (int nb = 0; nb < nb_n; ++nb)
         for (int g = 0; g < ngrp; ++g)
             for (int tap = 0; tap < 9; ++tap)
@@ -782,9 +847,9 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
     int csum = 0;
     for (int i = 0; i < a.nsrc; ++i) {
         const MxSrc& sp = a.src[i];
-        if (sp.c % 32 || !sp.q_off) { set_error("conv3x3_mx: source %d needs q planes and a multiple of 32 channels (got %d)", i, sp.c); return DISCO_ESHAPE; }
-        const size_t per = (size_t)a.n * sp.c * sp.h * sp.w * 2;          // bytes of the hi plane = bytes of the q planes
-        const size_t bytes = (size_t)sp.q_off + per;
+        if (sp.c % (a.x2q ? 64 : 32) || !sp.q_off) { set_error("conv3x3_mx: source %d needs q planes and a multiple of %d channels (got %d)", i, a.x2q ? 64 : 32, sp.c); return DISCO_ESHAPE; }
+        const size_t per = (size_t)a.n * sp.c * sp.h * sp.w * 2;          // bytes of the hi plane = bytes of the a8|al8 planes (al8 only: half)
+        const size_t bytes = (size_t)sp.q_off + (a.x2q ? per / 2 : per);
         if (bytes >= ((size_t)1 << 32) || sp.q_off < per) { set_error("conv3x3_mx: activation tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", bytes); return DISCO_ESHAPE; }
         a.src_bytes[i] = (uint32_t)bytes;
         if ((size_t)sp.h * sp.w * 32 >= (1u << 30)) { set_error("conv3x3_mx: image too large for 30-bit in-image offsets"); return DISCO_ESHAPE; }
@@ -792,15 +857,16 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
         csum += sp.c;
     }
     if (csum != a.c_in) { set_error("conv3x3_mx: sources carry %d channels, layer takes %d", csum, a.c_in); return DISCO_ESHAPE; }
+    if (a.x2q && a.nsrc != 1) { set_error("conv3x3_mx: the f16x2+fp8 arithmetic takes one source"); return DISCO_ESHAPE; }
     {
-        const size_t wb = conv_mx_packed_bytes(a.c_out, a.c_in);
+        const size_t wb = conv_mx_packed_bytes(a.c_out, a.c_in, a.x2q);
         if (wb >= ((size_t)1 << 32)) { set_error("conv3x3_mx: packed weights too large"); return DISCO_ESHAPE; }
         a.w_bytes = (uint32_t)wb;
     }
     {
         const size_t oelems = (size_t)a.n * (a.d2s_c > 0 ? (size_t)a.d2s_c * 4 : (size_t)a.c_out_pad) * a.h_out * a.w_out;
         size_t ob = a.out_f32 ? (size_t)a.n * a.c_out * a.h_out * a.w_out * 4 : oelems * 2;
-        if (!a.out_f32) ob = std::max(ob, std::max((size_t)a.out_plane * 2 + (a.out_plane ? oelems * 2 : 0), a.out_q_off + (a.out_q_off ? oelems * 2 : 0)));
+        if (!a.out_f32) ob = std::max(ob, std::max((size_t)a.out_plane * 2 + (a.out_plane ? oelems * 2 : 0), a.out_q_off + (a.out_q_off ? oelems * (a.out_q_kind ? 1 : 2) : 0)));
         const size_t rb = a.res ? (size_t)a.res_plane * 2 + oelems * 2 : 16;
         if (ob >= ((size_t)1 << 32) || rb >= ((size_t)1 << 32)) { set_error("conv3x3_mx: output tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", ob); return DISCO_ESHAPE; }
         if (!a.out_f32 && !a.out) { set_error("conv3x3_mx: null output"); return DISCO_EINVAL; }

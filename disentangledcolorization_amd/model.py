@@ -43,7 +43,7 @@ class SpixelSeg(nn.Module):
         super().__init__()
         if inChannel != 1 or outChannel != 9 or not batchNorm:
             raise NotImplementedError("SpixelSeg(inChannel=1, outChannel=9, batchNorm=True) only")
-        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL}[precision]
+        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}[precision]
         for key, shape, dt, kind in state_dict_spec():
             if not key.startswith("segnet."):
                 continue
@@ -145,7 +145,7 @@ class AnchorColorProb(nn.Module):
         self.enhanced, self.hint2regress, self.spix_pos, self.use_token_mask = True, bool(hint2regress), bool(spix_pos), False
         self.n_vocab = 313
         self.rank = rank
-        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL}[precision]
+        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}[precision]
         self.sync_kmeans_events = True   # emulate the reference's torch.randint fallback draws (one sync per forward)
         self._build_tree()
         self._ctx = None

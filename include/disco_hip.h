@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 4
+#define DISCO_ABI_VERSION 5
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -71,6 +71,9 @@ typedef struct disco_ctx disco_ctx;
                               stay on DISCO_PREC_F16X3.  Measured: max |ab - reference| ~1e-4, anchors identical. */
 #define DISCO_PREC_MX8_ALL 3 /* every conv stack on the fp8-corrected kernel: ~6% faster again, but the ~3e-5 perturbation it
                               leaves at the encoder output flips k-means anchors in ~1% of images (measurements only) */
+#define DISCO_PREC_X2Q 4     /* as DISCO_PREC_MX8, and the ColorProbNet on the same kernel's second arithmetic: w_h a_h + w_l a_h
+                              in fp16 and only the activation residual in fp8 (5 matrix-pipe units per 32 channels and tap
+                              instead of 6).  ~1.2e-5 at the encoder output where F16X3 leaves ~5e-6: opt-in. */
 
 int disco_abi_version(void);
 const char *disco_last_error(void);
@@ -211,6 +214,7 @@ int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d
  * power-of-two scale per tensor.  C is padded to a multiple of 16 (32 with q planes). */
 #define DISCO_PLANE_LO 1
 #define DISCO_PLANE_Q 2
+#define DISCO_PLANE_QL 4   /* instead of DISCO_PLANE_Q: only the al8 planes, [N][C/32][H][W][32] (operands of the x2q arithmetic) */
 int disco_op_act_bytes(int n, int c_pad, int h, int w, int planes, size_t *bytes);
 int disco_op_nchw_to_act_mx(const float *d_src, void *d_dst, int n, int c, int h, int w, int c_pad, int planes, int sexp,
                             void *stream);
@@ -229,9 +233,12 @@ typedef struct disco_conv_mx_desc {
     int32_t out_sexp;
     int32_t out_f32;           /* 1: d_out is fp32 NCHW */
     int32_t res_planes;        /* DISCO_PLANE_* bits of the residual buffer (its lo plane is used when present) */
+    int32_t x2q;               /* 1: the f16x2 + fp8 arithmetic: one source with DISCO_PLANE_QL planes, c_in0 a multiple of 64,
+                                  weights packed with x2q = 1 */
 } disco_conv_mx_desc;
 /* d_packed == NULL: only *bytes.  d_wexp: device int32 [round_up(c_out, 32)], the per-output-channel weight scale exponents */
-int disco_op_conv3x3_mx_pack(const float *h_w_oihw, int c_out, int c_in, void *d_packed, int32_t *d_wexp, size_t *bytes);
+int disco_op_conv3x3_mx_pack(const float *h_w_oihw, int c_out, int c_in, int x2q, void *d_packed, int32_t *d_wexp,
+                             size_t *bytes);
 int disco_op_conv3x3_mx(const disco_conv_mx_desc *d, const void *d_src0, const void *d_src1, const void *d_packed_w,
                         const int32_t *d_wexp, const float *d_bias, const float *d_bn_scale, const float *d_bn_shift,
                         const void *d_res, void *d_out, uint32_t *d_sat, void *stream);

@@ -104,27 +104,28 @@ def to_act_mx(x, planes=_ffi.PLANE_Q, sexp=None, c_pad=None):
     return a
 
 
-def pack_conv_mx(w):
+def pack_conv_mx(w, x2q=False):
     w = w.detach().cpu().float().contiguous()
     co, ci = w.shape[:2]
     nbytes = C.c_size_t()
-    _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(None, co, ci, None, None, C.byref(nbytes)))
+    _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(None, co, ci, int(x2q), None, None, C.byref(nbytes)))
     buf = torch.empty(nbytes.value, device=DEV, dtype=torch.uint8)
     wexp = torch.empty((co + 31) // 32 * 32, device=DEV, dtype=torch.int32)
-    _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(_ffi.ptr(w), co, ci, _ffi.ptr(buf), _ffi.ptr(wexp), C.byref(nbytes)))
+    _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(_ffi.ptr(w), co, ci, int(x2q), _ffi.ptr(buf), _ffi.ptr(wexp), C.byref(nbytes)))
     return buf, wexp
 
 
 def conv3x3_mx(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, act=_ffi.ACT_NONE, slope=0.0, bn_scale=None,
-               bn_shift=None, res=None, out_planes=_ffi.PLANE_LO, out_sexp=0, out_f32=False, packed=None):
-    """src*: MxAct with q planes; res: MxAct (hi [+ lo]).  Returns (MxAct | fp32 NCHW tensor, saturation count)."""
+               bn_shift=None, res=None, out_planes=_ffi.PLANE_LO, out_sexp=0, out_f32=False, packed=None, x2q=False):
+    """src*: MxAct with q planes (x2q: one source with al8-only planes, PLANE_QL); res: MxAct (hi [+ lo]).
+    Returns (MxAct | fp32 NCHW tensor, saturation count)."""
     h_in, w_in = src0.h * (2 if up0 else 1), src0.w * (2 if up0 else 1)
     co = w.shape[0]
-    buf, wexp = packed or pack_conv_mx(w)
+    buf, wexp = packed or pack_conv_mx(w, x2q)
     ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
     d = _ffi.ConvMxDesc(src0.n, h_in, w_in, src0.c_pad, src1.c_pad if src1 is not None else 0, int(up0), int(up1), src0.sexp,
                         src1.sexp if src1 is not None else 0, co, stride, act, slope, out_planes, out_sexp, int(out_f32),
-                        res.planes if res is not None else 0)
+                        res.planes if res is not None else 0, int(x2q))
     out = torch.empty(src0.n, co, ho, wo, device=DEV, dtype=torch.float32) if out_f32 else MxAct(src0.n, co, ho, wo, out_planes, out_sexp)
     sat = torch.zeros(1, device=DEV, dtype=torch.int32)
     dv = lambda t: None if t is None else t.to(DEV).float().contiguous()

@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.disco_abi_version() == 4
+    assert lib.disco_abi_version() == 5
 
 
 def test_native_layout_matches_python_spec(lib):
@@ -149,7 +149,7 @@ def test_dataparallel_and_train_are_refused_with_a_pointer_to_the_runner():
 def test_mx_weight_pack_and_fp8_codec(lib):
     """The host side of the fp8-corrected conv: packed size, and that the packer is callable without a device (bytes only)."""
     nb = C.c_size_t()
-    assert lib.disco_op_conv3x3_mx_pack(None, 64, 65, None, None, C.byref(nb)) == 0
+    assert lib.disco_op_conv3x3_mx_pack(None, 64, 65, 0, None, None, C.byref(nb)) == 0
     assert nb.value == 2 * (96 // 16) * 9 * 2 * 1024     # 2 cout blocks x 3 groups of 32 channels x {H,Q} chunks x 9 taps x 2 KiB
     assert lib.disco_op_conv3x3_mx(None, None, None, None, None, None, None, None, None, None, None, None) < 0
     ab = C.c_size_t()

@@ -99,6 +99,54 @@ def test_conv3x3_mx_matches_torch(H, case):
         assert H.max_err(out32, want) < TOL * scale
 
 
+X2Q_CASES = [
+    # cin, cout, h, w, stride, act, slope, bn, res, out_planes  (QL: al8-only q planes, what the next x2q layer reads)
+    (64, 64, 32, 32, 1, _ffi.ACT_LRELU, 0.2, True, False, _ffi.PLANE_QL),
+    (128, 64, 24, 40, 1, _ffi.ACT_RELU, 0.0, True, False, LO | _ffi.PLANE_QL),
+    (64, 128, 32, 64, 2, _ffi.ACT_LRELU, 0.2, True, False, _ffi.PLANE_QL),
+    (256, 512, 16, 16, 2, _ffi.ACT_RELU, 0.0, False, False, _ffi.PLANE_QL),
+    (192, 64, 17, 33, 1, _ffi.ACT_NONE, 0.0, False, True, LO),       # ragged, 3 groups of 64, residual
+    (512, 512, 8, 8, 1, _ffi.ACT_LRELU, 0.2, True, False, _ffi.PLANE_QL),
+    (64, 64, 64, 64, 1, _ffi.ACT_RELU, 0.0, False, False, LO),       # the 16x32-pixel tile with row reuse
+    (256, 256, 32, 32, 1, _ffi.ACT_RELU, 0.0, False, False, _ffi.PLANE_QL),
+]
+
+
+@pytest.mark.parametrize("case", X2Q_CASES)
+def test_conv3x3_x2q_matches_torch(H, case):
+    """The kernel's second arithmetic (w_h a_h + w_l a_h in fp16, fp8(w) fp8(a_l)): only the activation residual is
+    quantised, so the error is ~2^-16 of the |w||a_l 2^11| mass - the check is 4x tighter than for the mx arithmetic."""
+    cin, cout, h, w, stride, act, slope, use_bn, use_res, planes = case
+    QL = _ffi.PLANE_QL
+    gen = g(cin * 1000 + cout + h + 7)
+    n = 3
+    x = torch.randn(n, cin, h, w, generator=gen)
+    if cin >= 128: x = F.relu(x)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    bn = (torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.1) if use_bn else None
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = torch.randn(n, cout, ho, wo, generator=gen) if use_res else None
+    want = _ref(x, wt, b, stride, act, slope, bn, res)
+    scale = max(1.0, want.abs().max().item())
+    src = H.to_act_mx(x, QL)
+    assert H.max_err(src.read(2).cpu(), x) < x.abs().max().item() * 2 ** -15          # hi + al8 view of the al8-only layout
+    kw = dict(stride=stride, act=act, slope=slope, bn_scale=bn[0] if bn else None, bn_shift=bn[1] if bn else None, x2q=True)
+    out, sat = H.conv3x3_mx(src, wt, b, res=H.to_act_mx(res, LO) if use_res else None, out_planes=planes, out_sexp=H.sexp_for(want), **kw)
+    assert sat == 0
+    if planes & LO:
+        assert H.max_err(out.read(0), want) < TOL / 4 * scale
+    if planes & QL:
+        assert H.max_err(out.read(2), want) < (TOL / 4 + 2 ** -14) * scale
+    if not use_res:
+        out32, _ = H.conv3x3_mx(src, wt, b, out_f32=True, **kw)
+        assert H.max_err(out32, want) < TOL / 4 * scale
+    # and it is closer to the exact result than the f16 + fp8x2 arithmetic on the same data
+    if not use_res:
+        mx32, _ = H.conv3x3_mx(H.to_act_mx(x), wt, b, out_f32=True, **{**kw, "x2q": False})
+        assert H.max_err(out32, want) <= H.max_err(mx32, want)
+
+
 def test_conv3x3_mx_upsample_and_concat_on_read(H):
     gen = g(5)
     a = torch.randn(2, 64, 12, 20, generator=gen)      # half-resolution source, nearest x2 on read
