@@ -113,11 +113,15 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="fix the TOTAL batch instead (tests; ragged shards allowed)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="mx8", choices=["mx8", "x2q", "mx8all", "f16x3", "f16x1"])
+    ap.add_argument("--precision", default=None, choices=["mx8", "x2q", "mx8all", "f16x3", "f16x1"],
+                    help="conv arithmetic per stack (disentangledcolorization_amd/model.py); default: the package default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with one thread per host core (minutes on a 256-core box)")
     ap.add_argument("--micro", type=int, default=1, help="micro-batches per GPU, each on its own HIP stream (2: +1.7%, 1749 vs 1720 img/s, but concurrent streams blur the per-launch conv timings the roofline is computed from, so the default stays 1)")
     args = ap.parse_args()
+    if args.precision is None:
+        from disentangledcolorization_amd.model import default_precision
+        args.precision = default_precision()
     fake = os.environ.get("DISCO_BENCH_FAKE") == "1"
 
     # stdout carries exactly one JSON line: native libraries (RCCL's version banner, HIP runtime notices) write to fd 1

@@ -15,6 +15,7 @@ builds, model.py:122-124, is rejected by the pinned torch 1.8 `masked_fill`), te
 hint2regress (model.py:178 reads an undefined name there), training (set_train / gradients).
 """
 import ctypes as C
+import os
 import random
 
 import numpy as np
@@ -31,6 +32,21 @@ KMEANS_ITERS = 20  # clusterkit.py:43 iter_limit -> at most (K-1)*20 empty-clust
 MAX_ACT_BYTES = (1 << 32) - (1 << 20)
 
 
+# conv arithmetic per stack (include/disco_hip.h DISCO_PREC_*): "mx8" = f16x3 on SpixelNet + ColorProbNet (the anchor-deciding
+# stacks), f16+fp8x2 on HourGlass2; "x2q" = additionally the ColorProbNet on f16x2+fp8; "f16x3" everywhere; "mx8all" / "f16x1":
+# measurements only
+_PRECISIONS = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}
+DEFAULT_PRECISION = "mx8"
+
+
+def default_precision():
+    """The precision a model gets when the caller names none: DEFAULT_PRECISION, or $DISCO_PRECISION (A/B runs of whole test suites)."""
+    p = os.environ.get("DISCO_PRECISION", DEFAULT_PRECISION)
+    if p not in _PRECISIONS:
+        raise ValueError("DISCO_PRECISION=%r: choose from %s" % (p, sorted(_PRECISIONS)))
+    return p
+
+
 class _Node(nn.Module):
     """Bare container so that dotted checkpoint keys map onto a module tree."""
 
@@ -39,11 +55,11 @@ class SpixelSeg(nn.Module):
     """Drop-in for `models/model.py::SpixelSeg` (model.py:12-29): the superpixel network alone, as used by
     main/spixelseg/inference.py:45-89.  state_dict keys `net.*` (94 tensors); forward(gray) -> (N,9,H,W) affinity."""
 
-    def __init__(self, inChannel=1, outChannel=9, batchNorm=True, precision="mx8"):
+    def __init__(self, inChannel=1, outChannel=9, batchNorm=True, precision=None):
         super().__init__()
         if inChannel != 1 or outChannel != 9 or not batchNorm:
             raise NotImplementedError("SpixelSeg(inChannel=1, outChannel=9, batchNorm=True) only")
-        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}[precision]
+        self.precision = _PRECISIONS[precision or default_precision()]
         for key, shape, dt, kind in state_dict_spec():
             if not key.startswith("segnet."):
                 continue
@@ -128,7 +144,7 @@ class SpixelSeg(nn.Module):
 class AnchorColorProb(nn.Module):
     def __init__(self, inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=False,
                  learning_pos=False, n_clusters=8, random_hint=False, hint2regress=False, enhanced=False,
-                 use_mask=False, rank=0, precision="mx8", init_weights=True):
+                 use_mask=False, rank=0, precision=None, init_weights=True):
         super().__init__()
         unsupported = []
         if inChannel != 1: unsupported.append("inChannel=%r" % inChannel)
@@ -145,7 +161,7 @@ class AnchorColorProb(nn.Module):
         self.enhanced, self.hint2regress, self.spix_pos, self.use_token_mask = True, bool(hint2regress), bool(spix_pos), False
         self.n_vocab = 313
         self.rank = rank
-        self.precision = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}[precision]
+        self.precision = _PRECISIONS[precision or default_precision()]
         self.sync_kmeans_events = True   # emulate the reference's torch.randint fallback draws (one sync per forward)
         self._build_tree()
         self._ctx = None

@@ -327,6 +327,26 @@ def test_precision_mode_f16x1_runs(synth_sd):
     assert _err(a[3], b[3]) < 2e-2
 
 
+def test_precision_mode_x2q_against_oracle(synth_sd, q_to_ab):
+    """precision="x2q": the ColorProbNet on the f16x2+fp8 arithmetic (only the activation residual in fp8).  Against the fp32
+    oracle: anchors identical, |ab| within the 1e-3 bar; pal_logit within 5e-5 (measured 1.4e-5; the f16x3 stack: 5e-6)."""
+    n = 4
+    gray, ab = synth.synth_inputs(n, 256, 256, seed=77)
+    m = AnchorColorProb(n_clusters=8, enhanced=True, precision="x2q", init_weights=False)
+    m.load_state_dict(synth_sd); m = m.cuda().eval()
+    _seed(130); out = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    assert m.saturation_count() == 0
+    _seed(130); want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=8).forward(gray, ab)
+    assert torch.equal(out[5].cpu(), want[5]), "anchors"
+    assert _err(out[0], want[0]) < 5e-5 and _err(out[2], want[2]) <= AB_TOL
+    # a single image of the batch run alone: bit-identical (same accumulation order whatever tile serves the layer)
+    _seed(130); np.random.choice(256, 8, replace=False)
+    one = m(gray[1:2].cuda(), ab[1:2].cuda(), True, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(one[2][0], out[2][1]) and torch.equal(one[5][0], out[5][1])
+
+
 def test_error_paths(synth_sd):
     m = _model(synth_sd, 8)
     gray, ab = synth.synth_inputs(1, 64, 64)
