@@ -117,7 +117,7 @@ def main():
                     help="conv arithmetic per stack (disentangledcolorization_amd/model.py); default: the package default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with one thread per host core (minutes on a 256-core box)")
-    ap.add_argument("--micro", type=int, default=1, help="micro-batches per GPU, each on its own HIP stream (2: +1.7%, 1749 vs 1720 img/s, but concurrent streams blur the per-launch conv timings the roofline is computed from, so the default stays 1)")
+    ap.add_argument("--micro", type=int, default=1, help="micro-batches per GPU, each on its own HIP stream (2: +1.7%%, 1749 vs 1720 img/s, but concurrent streams blur the per-launch conv timings the roofline is computed from, so the default stays 1)")
     args = ap.parse_args()
     if args.precision is None:
         from disentangledcolorization_amd.model import default_precision
@@ -265,7 +265,7 @@ def main():
                 "algorithmic_hbm_bytes_per_launch": int(conv_bytes),
                 "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK, 4),
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
-                "power_limited_mfma_ceilings_tflops_algorithmic": {"f16x3": 439, "f16+fp8x2": 891,
+                "power_limited_mfma_ceilings_tflops_algorithmic": {"f16x3": 439, "f16+fp8x2": 891, "f16x2+fp8": 640,
                                                                    "source": "profiles/r02_mfma_mix.txt (registers-only loops, random operands)"},
             }
             out["stage_ms_per_step"] = {k: round(v / args.steps, 3) for k, v in stage_ms.items()}
