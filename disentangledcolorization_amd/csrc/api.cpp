@@ -234,7 +234,14 @@ int staged_h2d(disco_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipSt
     return DISCO_OK;
 }
 
-int run_conv(const ConvArgs& ca, hipStream_t s) { return launch_conv3x3_v2(ca, s); }
+// f16x3 layers run on conv3x3_mx_kernel's skeleton (AR = 2: same arithmetic and accumulation order as conv_mfma2.hip, i.e. the
+// same bits, without that kernel's 95 spilled SGPRs); conv_mfma2.hip keeps the hi-only mode, the space-to-depth packing and the
+// timing probe.  DISCO_X3_OLD=1 routes everything through it again (A/B).
+int run_conv(const ConvArgs& ca, hipStream_t s) {
+    static const bool old_kernel = [] { const char* e = getenv("DISCO_X3_OLD"); return e && atoi(e) != 0; }();
+    if (!old_kernel && ca.precision == DISCO_PREC_F16X3 && !ca.s2d && !ca.dbg) return launch_conv3x3_x3(ca, s);
+    return launch_conv3x3_v2(ca, s);
+}
 unsigned long long* g_conv_probe = nullptr;   // timing probe buffer for disco_op_conv3x3 (tools/conv_timeline.py)
 
 // effective conv weight (c_out, c_in, 3, 3): plain `.weight`, or spectral-norm weight_orig / (u . (W v))

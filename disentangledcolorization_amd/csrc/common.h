@@ -187,11 +187,15 @@ struct ConvMxArgs {
     // one source with al8-only planes, c_in a multiple of 64, weights packed with x2q = 1)
     int x2q;
     int out_q_kind;           // layout of the output's q planes (Act::q_kind)
+    int x3;                   // 1: the f16x3 arithmetic on this kernel (launch_conv3x3_x3): sources = hi + lo planes, MxSrc::q_off = byte
+                              // distance between them, weights = conv3x3_pack_host's image, no q planes anywhere
 };
 size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int x2q = 0);
 // h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map as in conv3x3_pack_host; c_in_pad multiple of 32 (x2q: 64); h_wexp: cdiv(c_out,32)*32 ints
 void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int x2q = 0);
 int launch_conv3x3_mx(const ConvMxArgs& a, hipStream_t s);
+// the f16x3 layer described by a ConvArgs (no s2d, no probe) on conv3x3_mx_kernel's skeleton; results bit-identical to launch_conv3x3_v2
+int launch_conv3x3_x3(const ConvArgs& a, hipStream_t s);
 unsigned char fp8_e4m3_from_float(float x);      // round to nearest even, saturating to +-448
 float fp8_e4m3_to_float(unsigned char v);
 // fp32 NCHW -> act with optional lo / q planes (q: scale exponent sexp); and amax |x| over an act's hi plane

@@ -70,8 +70,10 @@ struct GeoMx {
 };
 
 // NSRC2: the layer concatenates two sources on read (the descriptor and offsets of the second source exist only then).
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, bool XQ>
+// AR: 0 = f16 + fp8x2, 1 = f16x2 + fp8 (x2q), 2 = f16x3 (below)
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
+    constexpr bool XQ = AR == 1, X3 = AR == 2;
     static_assert(!(XQ && NSRC2), "the f16x2+fp8 arithmetic takes one source");
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = GeoMx<TW, TH, STRIDE>;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
-    const int nchunks = XQ ? (a.c_in >> 6) * 5 : a.c_in >> 4;    // two chunks (H, Q) per 32 input channels; XQ: H L H L Q per 64
+    const int nchunks = XQ ? (a.c_in >> 6) * 5 : a.c_in >> 4;    // two chunks (H, Q) per 32 input channels; XQ: H L H L Q per 64; X3: one per 16
 
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     // E8M0 scale operands of the fp8 products: weight side per lane (= per output channel row), pixel side uniform per source
     int wsc[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) wsc[j] = 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];
+    for (int j = 0; j < NTW; ++j) wsc[j] = X3 ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];
     const int asc0 = 127 - a.src[0].sexp, asc1 = 127 - a.src[NSRC2 ? 1 : 0].sexp;
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[0].p, 0, a.src_bytes[0], 0x00020000);
@@ -157,7 +159,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
                 // both chunk kinds keep their second plane h*w*32 bytes after the first (the next 16-channel block of the hi
                 // plane / the al8 plane of the q block), so one offset serves both
-                voff[si][i] = in ? (unsigned)((plane * sp.h + (gy >> sp.up)) * sp.w + (gx >> sp.up)) * 32u + kh * 16u : OOB;
+                // (X3: the second plane is the tensor's lo plane, q_off bytes after the hi plane)
+                if (X3) voff[si][i] = in ? (unsigned)plane * sp.q_off + (unsigned)((gy >> sp.up) * sp.w + (gx >> sp.up)) * 32u + kh * 16u : OOB;
+                else voff[si][i] = in ? (unsigned)((plane * sp.h + (gy >> sp.up)) * sp.w + (gx >> sp.up)) * 32u + kh * 16u : OOB;
             }
         }
     }
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     auto issue = [&](int img, int ck, int buf, int part) {
         int c0 = (ck >> 1) << 5;                       // first channel of the chunk's 32-channel group
         bool isq = ck & 1;
+        if (X3) { c0 = ck << 4; isq = false; }         // one chunk per 16 channels: planes = hi / lo
         if (XQ) {                                      // chunk 5 g64 + i: i = 0, 1: H, L of channels 64 g64 ..; 2, 3: of 64 g64 + 32 ..; 4: Q of all 64
             const int g64 = ck / 5, i = ck - 5 * g64;
             isq = i == 4;
@@ -245,8 +250,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     //              (K half kh of one K = 64 MFMA: a8 meets wl8, al8 meets w8).
     // The H and Q chunks of a 32-channel group run back to back in one loop iteration (no branch between the two bodies:
     // a branch made the register allocator keep the accumulators in two places).
-    auto chunk = [&](auto isq_tag, int ck) {
-        constexpr bool ISQ = decltype(isq_tag)::value;
+    // KIND 2 (X3): the f16x3 arithmetic of conv_mfma2.hip on this skeleton - planes = hi / lo of 16 channels, weight tile = w_hi / w_lo
+    //              fragments (conv3x3_pack_host's image), three K = 16 MFMAs per tap in conv_mfma2's order (w_lo a_hi, w_hi a_lo,
+    //              w_hi a_hi), so results are bit-identical to that kernel's
+    auto chunk = [&](auto kind_tag, int ck) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool ISQ = KIND == 1;
         if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const bool more = ck + 1 < nchunks;
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         // that can serve a given layer shape accumulates in the same order, so a result does not depend on the batch size
         constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
         constexpr bool ROWREUSE = COLMAJOR && MT == 2;
-        const int asc = (NSRC2 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
+        const int asc = (NSRC2 && !X3 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
         // this chunk's three column addresses inside the current buffer (the only per-chunk address arithmetic)
         const int bufoff = (int)(sA - smem);
         int ca0[3], ca1[3];
@@ -313,6 +322,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         const i32x8 bw = {rb[nt][0][0], rb[nt][0][1], rb[nt][0][2], rb[nt][0][3], rb[nt][1][0], rb[nt][1][1], rb[nt][1][2], rb[nt][1][3]};
                         const i32x8 ap = {ra[mt][0][0], ra[mt][0][1], ra[mt][0][2], ra[mt][0][3], ra[mt][1][0], ra[mt][1][1], ra[mt][1][2], ra[mt][1][3]};
                         acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], 0, 0, 0, wsc[nt], 0, asc);
+                    } else if (KIND == 2) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
                     } else {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
@@ -330,16 +343,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 }
         }
     };
-    if constexpr (XQ) {
+    using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>;
+    if constexpr (X3) {
+        for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck);
+    } else if constexpr (XQ) {
         for (int ck = 0; ck < nchunks; ck += 5) {
 #pragma unroll 1
-            for (int h = 0; h < 4; ++h) chunk(std::false_type{}, ck + h);     // H, L, H, L: the same code, other weights
-            chunk(std::true_type{}, ck + 4);
+            for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h);     // H, L, H, L: the same code, other weights
+            chunk(KQ{}, ck + 4);
         }
     } else {
         for (int ck = 0; ck < nchunks; ck += 2) {
-            chunk(std::false_type{}, ck);
-            chunk(std::true_type{}, ck + 1);
+            chunk(KH{}, ck);
+            chunk(KQ{}, ck + 1);
         }
     }
 
@@ -397,6 +413,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             vo[mt] = pok ? (MODE == 2 ? pi * 4u : pi * 32u) : OOB;
         }
         // ---- phase 1: math ----
+        unsigned lpark[MT][NTW][8];                          // lo words of the tile (live only when the output has a lo plane)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
@@ -415,12 +432,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         const unsigned so = so_hi[nt][g4 >> 1];
                         const unsigned vof = vo[mt] == OOB ? OOB : vo[mt] + 16u * (g4 & 1) + 8u * kh;
                         const f16x4 rh = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, vof, so, 0));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) x[j] += (float)rh[j];
-                        if (a.res_plane) {
+                        if (X3) {                                    // conv_mfma2's form: x + (hi + lo)
                             const f16x4 rl = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, vof, so + (unsigned)a.res_plane * 2u, 0));
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) x[j] += (float)rl[j];
+                            for (int j = 0; j < 4; ++j) x[j] += (float)rh[j] + (float)rl[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) x[j] += (float)rh[j];
+                            if (a.res_plane) {
+                                const f16x4 rl = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, vof, so + (unsigned)a.res_plane * 2u, 0));
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) x[j] += (float)rl[j];
+                            }
                         }
                     }
                     if (act == DISCO_ACT_RELU) {
@@ -509,14 +532,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                             l8[2 * q] = sl[0]; l8[2 * q + 1] = sl[1];
                         }
                     }
+                    // The lo words are parked like the hi and q words and stored in phase 3.  (They used to be stored right here,
+                    // "to free their registers": a buffer store issued while the prefetch DMA of the next image is still queued in
+                    // the memory pipe reads its data registers only when it reaches the head of that queue - the registers had been
+                    // reused by then, and lanes 12-15 / 28-31 of the first data dword arrived stale in the lo plane, differently from
+                    // run to run.  Phase 3 stores are issued behind s_waitcnt vmcnt(0), into an empty queue.  Found when the f16x3
+                    // arithmetic - where every layer writes a lo plane - moved onto this kernel; neither the compiler nor a fixed
+                    // number of wait states covers it.)
                     if (wr_lo) {
-                        // the lo plane (residual inputs, pooled features: a handful of layers) is stored right away: only the
-                        // hi and q words are parked for the store phase
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const i32x4 d4 = {(int)ld[4 * q], (int)ld[4 * q + 1], (int)ld[4 * q + 2], (int)ld[4 * q + 3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(d4, ro, vo[mt] == OOB ? OOB : vo[mt] + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u, 0);
-                        }
+                        for (int d = 0; d < 8; ++d) lpark[mt][nt][d] = ld[d];
                     }
 #pragma unroll
                     for (int d = 0; d < 8; ++d) acc[mt][nt][d] = __builtin_bit_cast(float, hd[d]);
@@ -548,6 +573,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         const unsigned vb = (vo[mt] == OOB || !cok) ? OOB : vo[mt];
                         const i32x4 d4 = {__float_as_int(t[4 * q]), __float_as_int(t[4 * q + 1]), __float_as_int(t[4 * q + 2]), __float_as_int(t[4 * q + 3])};
                         __builtin_amdgcn_raw_buffer_store_b128(d4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q], 0);
+                        if (wr_lo) {
+                            const i32x4 l4 = {(int)lpark[mt][nt][4 * q], (int)lpark[mt][nt][4 * q + 1], (int)lpark[mt][nt][4 * q + 2], (int)lpark[mt][nt][4 * q + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(l4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u, 0);
+                        }
                         if (wr_q) {
                             // q planes: this lane owns bytes 8 kh .. 8 kh + 7 of its pixel's 16-byte half (cb & 16)
                             const i32x2 q0 = {__float_as_int(t[8 + 2 * q]), __float_as_int(t[9 + 2 * q])};
@@ -589,13 +618,13 @@ inline int num_cus_mx() {
     return n;
 }
 
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, bool XQ = false>
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0>
 int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
     using G = GeoMx<TW, TH, STRIDE>;
     constexpr int A_BYTES = ((2 * G::NPIX * 2 + 63) / 64) * 1024;
     constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, XQ>;
+    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR>;
     // function attributes are per device and per kernel instantiation (this static lives in the instantiation)
     static std::once_flag attr_once[DISCO_MAX_DEVICES];
     hipError_t attr_err = hipSuccess;
@@ -621,7 +650,11 @@ int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
 
 template <int TW, int TH, int NT, int STRIDE, int WM, int WN>
 int launch_mx2(const ConvMxArgs& a, hipStream_t s) {
-    if (a.x2q) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, true>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, true>(a, s);
+    if (a.x2q) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, 1>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, 1>(a, s);
+    if (a.x3) {
+        if (a.nsrc > 1) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, true, 2>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, true, 2>(a, s);
+        return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, 2>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, 2>(a, s);
+    }
     if (a.nsrc > 1) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, true>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, true>(a, s);
     return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false>(a, s);
 }
@@ -880,6 +913,50 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
     if (a.act == DISCO_ACT_LRELU && !(a.slope >= 0.f && a.slope <= 1.f)) { set_error("conv3x3_mx: LeakyReLU slope %g outside [0, 1]", (double)a.slope); return DISCO_ESHAPE; }
     if (a.c_out > 32 && a.c_out % 64) { set_error("conv3x3_mx: c_out %d (>32) must be a multiple of 64", a.c_out); return DISCO_ESHAPE; }
     if (a.out_sexp < -100 || a.out_sexp > 100) { set_error("conv3x3_mx: output scale exponent %d", a.out_sexp); return DISCO_EINVAL; }
+    return dispatch_mx(a, s);
+}
+
+int launch_conv3x3_x3(const ConvArgs& c, hipStream_t s) {
+    ConvMxArgs a{};
+    if (c.nsrc < 1 || c.nsrc > 2 || c.s2d) { set_error("conv3x3_x3: %d sources / s2d %d", c.nsrc, c.s2d); return DISCO_EINVAL; }
+    int csum = 0;
+    for (int i = 0; i < c.nsrc; ++i) {
+        const ConvSrc& sp = c.src[i];
+        if (sp.c % 16 || sp.c <= 0 || sp.plane <= 0) { set_error("conv3x3_x3: source %d needs hi + lo planes and a multiple of 16 channels (got %d)", i, sp.c); return DISCO_ESHAPE; }
+        const size_t per = (size_t)c.n * sp.c * sp.h * sp.w * 2;
+        const size_t bytes = (size_t)sp.plane * 2 + per;
+        if (bytes >= ((size_t)1 << 32)) { set_error("conv3x3: activation tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", bytes); return DISCO_ESHAPE; }
+        if ((size_t)sp.h * sp.w * 32 >= (1u << 30)) { set_error("conv3x3: image too large for 30-bit in-image offsets"); return DISCO_ESHAPE; }
+        a.src[i] = {sp.p, (uint32_t)((size_t)sp.plane * 2), sp.c, sp.h, sp.w, sp.up, 0};
+        a.src_bytes[i] = (uint32_t)bytes;
+        csum += sp.c;
+    }
+    if (csum != c.c_in) { set_error("conv3x3: sources carry %d channels, layer takes %d", csum, c.c_in); return DISCO_ESHAPE; }
+    a.nsrc = c.nsrc; a.n = c.n; a.h_in = c.h_in; a.w_in = c.w_in; a.c_in = c.c_in;
+    a.h_out = c.h_out; a.w_out = c.w_out; a.stride = c.stride;
+    a.w = c.w; a.wexp = nullptr; a.tapmask = c.tapmask; a.c_out = c.c_out; a.c_out_pad = c.c_out_pad;
+    a.bias = c.bias; a.bn_scale = c.bn_scale; a.bn_shift = c.bn_shift;
+    a.res = c.res; a.res_plane = c.res_plane; a.out = c.out; a.out_plane = c.out_plane; a.out_f32 = c.out_f32;
+    a.d2s_c = c.d2s_c; a.act = c.act; a.slope = c.slope; a.softmax = c.softmax; a.x3 = 1;
+    {
+        const size_t wb = (size_t)cdiv(c.c_out, 32) * (c.c_in / 16) * W_NB;          // = conv3x3_packed_bytes
+        if (wb >= ((size_t)1 << 32)) { set_error("conv3x3: packed weights too large"); return DISCO_ESHAPE; }
+        a.w_bytes = (uint32_t)wb;
+    }
+    {
+        const size_t oelems = (size_t)c.n * (c.d2s_c > 0 ? (size_t)c.d2s_c * 4 : (size_t)c.c_out_pad) * c.h_out * c.w_out;
+        const size_t ob = c.out_f32 ? (size_t)c.n * c.c_out * c.h_out * c.w_out * 4 : (size_t)c.out_plane * 2 + oelems * 2;
+        const size_t rb = c.res ? (size_t)c.res_plane * 2 + oelems * 2 : 16;
+        if (ob >= ((size_t)1 << 32) || rb >= ((size_t)1 << 32)) { set_error("conv3x3: output tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", ob); return DISCO_ESHAPE; }
+        if (!c.out_f32 && (!c.out || c.out_plane <= 0)) { set_error("conv3x3_x3: the output needs hi + lo planes"); return DISCO_EINVAL; }
+        if (c.res && c.res_plane <= 0) { set_error("conv3x3_x3: the residual needs hi + lo planes"); return DISCO_EINVAL; }
+        a.out_bytes = (uint32_t)ob; a.res_bytes = (uint32_t)rb;
+    }
+    if (c.stride != 1 && c.stride != 2) { set_error("conv3x3: stride %d", c.stride); return DISCO_ESHAPE; }
+    if (c.softmax && (!c.out_f32 || c.c_out > 32)) { set_error("conv3x3: the fused softmax needs the fp32 NCHW output and c_out <= 32"); return DISCO_ESHAPE; }
+    if (c.d2s_c > 0 && (c.d2s_c % 16 || c.out_f32)) { set_error("conv3x3: depth-to-space needs a multiple of 16 channels (got %d) and an activation output", c.d2s_c); return DISCO_ESHAPE; }
+    if (c.act == DISCO_ACT_LRELU && !(c.slope >= 0.f && c.slope <= 1.f)) { set_error("conv3x3: LeakyReLU slope %g outside [0, 1]", (double)c.slope); return DISCO_ESHAPE; }
+    if (c.c_out > 32 && c.c_out % 64) { set_error("conv3x3: c_out %d (>32) must be a multiple of 64", c.c_out); return DISCO_ESHAPE; }
     return dispatch_mx(a, s);
 }
 

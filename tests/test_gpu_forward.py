@@ -347,6 +347,24 @@ def test_precision_mode_x2q_against_oracle(synth_sd, q_to_ab):
     assert torch.equal(one[2][0], out[2][1]) and torch.equal(one[5][0], out[5][1])
 
 
+@pytest.mark.parametrize("prec", ["mx8", "x2q", "f16x3"])
+def test_forward_is_run_to_run_deterministic(synth_sd, prec):
+    """Every output of three forwards on the same inputs and draws must agree bit for bit, in every precision mode (a store-data
+    hazard in the conv epilogue once made the lo planes - and with them everything downstream - differ from run to run)."""
+    gray, ab = synth.synth_inputs(24, 256, 256, seed=9)
+    m = AnchorColorProb(n_clusters=8, enhanced=True, precision=prec, init_weights=False)
+    m.load_state_dict(synth_sd); m = m.cuda().eval()
+    gray, ab = gray.cuda(), ab.cuda()
+    outs = []
+    for _ in range(3):
+        _seed(130)
+        outs.append([t.clone() for t in m(gray, ab, True, 0)])
+        torch.cuda.synchronize()
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a, b)
+
+
 def test_error_paths(synth_sd):
     m = _model(synth_sd, 8)
     gray, ab = synth.synth_inputs(1, 64, 64)
