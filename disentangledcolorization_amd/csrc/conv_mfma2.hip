@@ -18,8 +18,11 @@
 //     descriptors are computed once, and the DMA prefetch runs across image boundaries, so neither the launch of a
 //     workgroup nor the first DMA round trip of a tile is exposed (they cost ~30% on the 4-chunk 64-channel layers).
 //
-// This kernel serves the stacks that decide the anchors (SpixelNet, ColorProbNet) in the default precision mode and every
-// stack under DISCO_PREC_F16X3; conv_mx.hip (fp16 main product + fp8 corrections) serves the HourGlass2.
+// Round 1's conv kernel.  Since the second half of round 2 the forward's f16x3 layers run on conv_mx.hip's skeleton (its AR = 2
+// mode: the same arithmetic and accumulation order, bit-identical results, none of this kernel's 95 spilled SGPRs); this file
+// keeps what only it has: the hi-only mode (DISCO_PREC_F16X1), the space-to-depth packing of stride-2 layers, the per-chunk
+// timing probe (tools/conv_timeline.py), the weight packers (conv3x3_pack_host & co, shared with conv_mx.hip) - and it is the
+// A/B reference: DISCO_X3_OLD=1 routes every f16x3 layer through it again.
 // Epilogue variants: channel-blocked fp16 hi/lo planes (default), fp32 NCHW (network outputs), depth-to-space
 // (ConvTranspose2d 4x4 s2 p1 expressed as a 4-phase 3x3 conv, network.py:254-258).
 #include <algorithm>

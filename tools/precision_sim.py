@@ -10,6 +10,7 @@ Every 3x3 conv of the oracle is replaced by an emulation of how the HIP kernel w
   mx8u  : same with ONE power-of-two scale per tensor (per layer input, per layer weight)
   x2q   : w_h a_h + w_l a_h + q8(w) q8(a_l)    (2 fp16 MFMAs + 1 fp8: the weight residual exact, the activation residual in fp8)
   x2qw  : w_h a_h + w_h a_l + q8(w_l) q8(a_h)  (the mirror image)
+  mx8w1 : w_h a_h + q8(w_l) q8(a_h)            (activation residual dropped altogether)
 and the end-to-end deviation of pred_colors from the fp32 oracle and anchor agreement are reported.
 
     python tools/precision_sim.py [--size 128] [--seeds 4] [--modes mx8,mx8u,wh]
@@ -84,6 +85,8 @@ class Emu:
             y = cv(ah, wh) + cv(ah, wl) + cv(q8_tensor(al), q8_tensor(w))
         elif mode == "x2qw":     # the mirror image: activation-side correction exact, weight residual in fp8
             y = cv(ah, wh) + cv(al, wh) + cv(q8_tensor(ah), q8_tensor(wl))
+        elif mode == "mx8w1":    # only the weight residual corrected (fp8), the activation residual dropped: 3 units per 32 channels
+            y = cv(ah, wh) + cv(q8_tensor(ah), q8_tensor(wl))
         elif mode == "mx8u":
             y = cv(ah, wh) + cv(q8_tensor(al), q8_tensor(wh)) + cv(q8_tensor(ah), q8_tensor(wl))
         else:
