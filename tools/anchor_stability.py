@@ -14,6 +14,7 @@ ap.add_argument("--n256", type=int, default=64)
 ap.add_argument("--n512", type=int, default=8)
 ap.add_argument("--oracle", type=int, default=1)
 ap.add_argument("--modes", default="f16x3,mx8")
+ap.add_argument("--seed", type=int, default=1000, help="input seed of the 256^2 set (the 512^2 set uses seed + 1000)")
 args = ap.parse_args()
 sd = synth.synth_state_dict(130)
 models = {}
@@ -21,7 +22,7 @@ for prec in args.modes.split(","):
     m = AnchorColorProb(n_clusters=8, enhanced=True, precision=prec, init_weights=False)
     m.load_state_dict(sd); models[prec] = m.cuda().eval()
 torch.set_num_threads(min(os.cpu_count() or 1, 32))
-for (n, size, seed) in ((args.n256, 256, 1000), (args.n512, 512, 2000)):
+for (n, size, seed) in ((args.n256, 256, args.seed), (args.n512, 512, args.seed + 1000)):
     if n <= 0: continue
     gray, ab = synth.synth_inputs(n, size, size, seed=seed)
     res = {}
