@@ -73,7 +73,8 @@ typedef struct disco_ctx disco_ctx;
                               leaves at the encoder output flips k-means anchors in ~1% of images (measurements only) */
 #define DISCO_PREC_X2Q 4     /* as DISCO_PREC_MX8, and the ColorProbNet on the same kernel's second arithmetic: w_h a_h + w_l a_h
                               in fp16 and only the activation residual in fp8 (5 matrix-pipe units per 32 channels and tap
-                              instead of 6).  ~1.2e-5 at the encoder output where F16X3 leaves ~5e-6: opt-in. */
+                              instead of 6).  ~1.4e-5 at the encoder output where F16X3 leaves ~5e-6; anchors differ from the fp32 reference
+                              in 0.66 % of images (F16X3: 0.10 %): opt-in. */
 
 int disco_abi_version(void);
 const char *disco_last_error(void);
