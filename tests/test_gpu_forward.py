@@ -418,6 +418,9 @@ def test_fp8_saturation_counter_and_calibration_record(synth_sd):
     fp16 range guard) and the chosen exponent."""
     import ctypes as C
     from disentangledcolorization_amd import _ffi
+    from disentangledcolorization_amd.model import default_precision
+    if default_precision() in ("f16x3", "f16x1"):
+        pytest.skip("no fp8 planes under $DISCO_PRECISION=%s" % default_precision())
     m = _model(synth_sd, 8)
     gray, ab = synth.synth_inputs(2, 128, 128, seed=3)
     _seed(1)
