@@ -57,6 +57,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
+// buffer_store_dwordx4 with two wait states glued behind it.  gfx950 hazard (tools/store_hazard_repro.hip, profiles/r02_store_hazard.txt):
+// when the instruction right behind a dwordx4 store is a VALU write to one of its data registers, lanes 12-15 of every row of 16
+// store the NEW value (measured: buffer stores need 1 wait state, global stores 2).  The compiler's hazard recogniser covers global /
+// flat stores, and buffer stores only when they have NO register soffset ("this hazard only exists if the instruction is not using
+// a register in the soffset field") - on this part it exists with one, and these stores all have one.  An asm block is the only way
+// to keep the scheduler from moving a VALU instruction into the gap.
+__device__ __forceinline__ void buffer_store_b128(i32x4 d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(d), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
 template <int TW, int TH, int STRIDE>
 struct GeoMx {
     static constexpr int MB = TW * TH / 32;
@@ -532,13 +542,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                             l8[2 * q] = sl[0]; l8[2 * q + 1] = sl[1];
                         }
                     }
-                    // The lo words are parked like the hi and q words and stored in phase 3.  (They used to be stored right here,
-                    // "to free their registers": a buffer store issued while the prefetch DMA of the next image is still queued in
-                    // the memory pipe reads its data registers only when it reaches the head of that queue - the registers had been
-                    // reused by then, and lanes 12-15 / 28-31 of the first data dword arrived stale in the lo plane, differently from
-                    // run to run.  Phase 3 stores are issued behind s_waitcnt vmcnt(0), into an empty queue.  Found when the f16x3
-                    // arithmetic - where every layer writes a lo plane - moved onto this kernel; neither the compiler nor a fixed
-                    // number of wait states covers it.)
+                    // The lo words are parked like the hi and q words and stored in phase 3.  (They used to be stored right here, "to
+                    // free their registers", and the next (mt, nt) iteration's first VALU write could land in a data register of that
+                    // store one instruction behind it: the store-data hazard described at buffer_store_b128() - lanes 12-15 / 28-31
+                    // of one dword arrived stale in the lo plane, differently from run to run.  Found when the f16x3 arithmetic -
+                    // where every layer writes a lo plane - moved onto this kernel.)
                     if (wr_lo) {
 #pragma unroll
                         for (int d = 0; d < 8; ++d) lpark[mt][nt][d] = ld[d];
@@ -572,10 +580,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         const bool cok = cob + 16 * q + 8 * kh < a.c_out;
                         const unsigned vb = (vo[mt] == OOB || !cok) ? OOB : vo[mt];
                         const i32x4 d4 = {__float_as_int(t[4 * q]), __float_as_int(t[4 * q + 1]), __float_as_int(t[4 * q + 2]), __float_as_int(t[4 * q + 3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(d4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q], 0);
+                        buffer_store_b128(d4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q]);
                         if (wr_lo) {
                             const i32x4 l4 = {(int)lpark[mt][nt][4 * q], (int)lpark[mt][nt][4 * q + 1], (int)lpark[mt][nt][4 * q + 2], (int)lpark[mt][nt][4 * q + 3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(l4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u, 0);
+                            buffer_store_b128(l4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u);
                         }
                         if (wr_q) {
                             // q planes: this lane owns bytes 8 kh .. 8 kh + 7 of its pixel's 16-byte half (cb & 16)
