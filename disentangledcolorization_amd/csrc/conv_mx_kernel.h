@@ -1,0 +1,793 @@
+// conv_mx_kernel.h — the kernel and its launchers (conv_mx.hip: host side; conv_mx_ar{0,1,2}.hip: one instantiation set per arithmetic) — 3x3 implicit-GEMM conv for gfx950 whose products are an fp16 main term plus fp8 corrections:
+//
+//     w a  ~=  w_h a_h                                  v_mfma_f32_32x32x16_f16      (w_h = fp16(w), a_h = fp16(a))
+//            + q8(w - w_h) q8(a) + q8(w) q8(a - a_h)    v_mfma_scale_f32_32x32x64_f8f6f4, fp8 e4m3, both terms in ONE K = 64
+//                                                        instruction (K half 0: wl8 x a8, K half 1: w8 x al8)
+//
+// The two correction terms are ~2^-11 of the main term, so their 3 mantissa bits leave a relative error of ~2^-16 per
+// product (measured end to end: profiles/r02_precision_sim.txt), and the fp8 instruction retires 4x the K of the fp16 one
+// per pass: per 32 input channels and tap a 32x32 block costs 2 + 2 = 4 matrix-pipe units instead of the 6 of three fp16
+// products (conv_mfma2.hip), and the fp8 passes draw less power, so the power-managed clock stays higher
+// (profiles/r02_mfma_mix.txt: 54 vs 40 G units/s on random operands).
+//
+// Data formats (common.h, struct Act): fp16 hi plane [N][C/16][H][W][16]; q planes [N][C/32][2][H][W][32] fp8 e4m3 holding
+// a8 = fp8(a 2^sexp) and al8 = fp8((a - a_h) 2^(sexp+11)) with ONE power-of-two scale per tensor (fixed at calibration);
+// weights per output channel co: w8 = fp8(w 2^wexp[co]), wl8 = fp8((w - w_h) 2^(wexp[co]+11)).  The hardware applies
+// 2^-(sexp + wexp[co] + 11) to every fp8 product through the instruction's E8M0 scale operands (uniform for the pixel
+// operand, per lane = per output channel for the weight operand).
+//
+// XQ = true selects a second arithmetic on the same skeleton, for the layers whose output decides discrete results downstream:
+//
+//     w a  ~=  w_h a_h + w_l a_h                        four K = 16 fp16 MFMAs per 32 channels (w_l = fp16(w - w_h): an "L" chunk that
+//                                                        re-reads the hi plane against the residual weights)
+//            + q8(w) q8(a - a_h)                         ONE K = 64 fp8 MFMA per 64 channels (its K halves are two 32-channel blocks)
+//
+// i.e. only the ACTIVATION residual goes through fp8.  The weight residual's rounding error is the same at every pixel and
+// multiplies non-negative activations, so it survives spatial pooling (profiles/r02_precision_sim.txt: it is what moves the
+// anchors under the arithmetic above); the activation residual's is zero-mean per pixel.  5 pipe units per 32 channels and tap
+// (f16x3: 6).  Its sources carry the hi plane and al8-only q planes (Act::q_kind 1); chunk order per 64 channels: H L H L Q.
+//
+// Pipeline (same skeleton as conv_mfma2.hip): a "chunk" is 64 bytes per halo pixel and 64 bytes per (tap, output channel):
+// either the fp16 hi values of 32 channels (H chunk: two 16-channel planes) or their two fp8 planes (Q chunk).  Chunks
+// travel HBM/L2 -> LDS by LDS-DMA through raw buffer descriptors (out-of-range lanes read 0 = zero padding), double
+// buffered, one s_barrier per chunk, the next chunk's DMA issued in ninths between the taps; 16-byte XOR swizzle on pixel
+// bit 3 (bank-conflict-free ds_read_b128 fragments); persistent workgroups walking over the images of the batch;
+// v_permlane32_swap epilogue with 16-byte stores.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+#include "common.h"
+
+#ifndef MX_ABL
+#define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk
+#endif
+
+namespace disco {
+
+namespace {
+
+constexpr int WBLK = 1024;
+constexpr int W_NB = 9 * 2 * WBLK;          // bytes of one chunk of one 32-cout block: 9 taps x 2 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// buffer_store_dwordx4 with two wait states glued behind it.  gfx950 hazard (tools/store_hazard_repro.hip, profiles/r02_store_hazard.txt):
+// when the instruction right behind a dwordx4 store is a VALU write to one of its data registers, lanes 12-15 of every row of 16
+// store the NEW value (measured: buffer stores need 1 wait state, global stores 2).  The compiler's hazard recogniser covers global /
+// flat stores, and buffer stores only when they have NO register soffset ("this hazard only exists if the instruction is not using
+// a register in the soffset field") - on this part it exists with one, and these stores all have one.  An asm block is the only way
+// to keep the scheduler from moving a VALU instruction into the gap.
+__device__ __forceinline__ void buffer_store_b128(i32x4 d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(d), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+// four floats -> four fp8 e4m3 bytes of (x / scale), scale a power of two: ONE v_cvt_scalef32_pk_fp8_f32 per pair does the scaling
+// and the round-to-nearest-even (tools/cvt_scale_probe.hip, profiles/r03_cvt_scale_probe.txt: the instruction DIVIDES by its scale
+// operand and is bit-identical to v_mul + v_cvt_pk_fp8_f32 on every code boundary, tie and 100 000 random values).  It does NOT
+// saturate: |x / scale| > 464 yields the NaN code 0x7f - callers check the range themselves.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// one v_max_f32.  fmaxf() (and v_med3 written as a builtin: it is folded back) makes the compiler quiet possible signalling NaNs with
+// a v_max(x, x) in front of every maximum whose operand comes through a phi - twice the instructions in the conv epilogue
+__device__ __forceinline__ float vmax_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned fp8x4_scaled(f32x2 a, f32x2 b, float scale) {
+    s16x2 r = __builtin_bit_cast(s16x2, a[0]);        // any defined register will do (the untouched half is overwritten by the second
+                                                      // conversion); a source that dies here saves the v_mov of a fresh zero
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a[0], a[1], scale, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, b[0], b[1], scale, true);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+template <int TW, int TH, int STRIDE>
+struct GeoMx {
+    static constexpr int MB = TW * TH / 32;
+    static constexpr int TWI = (TW - 1) * STRIDE + 3;
+    static constexpr int THI = (TH - 1) * STRIDE + 3;
+    static constexpr int HALF = (TWI + 1) / 2;
+    static constexpr int PITCH = STRIDE == 1 ? TWI : 2 * HALF;
+    static constexpr int NPIX = THI * PITCH;
+    static constexpr int ROWS_PER_MB = 32 / TW;
+    static_assert(32 % TW == 0, "an M block covers whole tile rows");
+};
+
+// NSRC2: the layer concatenates two sources on read (the descriptor and offsets of the second source exist only then).
+// AR: 0 = f16 + fp8x2, 1 = f16x2 + fp8 (x2q), 2 = f16x3 (below)
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
+    constexpr bool XQ = AR == 1, X3 = AR == 2;
+    static_assert(!(XQ && NSRC2), "the f16x2+fp8 arithmetic takes one source");
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = GeoMx<TW, TH, STRIDE>;
+    constexpr int NWAVE = WM * WN;
+    constexpr int MT = G::MB / WM;
+    constexpr int NTW = NT / WN;
+    static_assert(G::MB % WM == 0 && NT % WN == 0, "tile split");
+    constexpr int PLANE_B = G::NPIX * 32;
+    constexpr int A_UNITS = 2 * G::NPIX * 2;
+    constexpr int A_PIECES = (A_UNITS + 63) / 64;
+    constexpr int A_BYTES = A_PIECES * 1024;
+    constexpr int W_PIECES = NT * 18;
+    constexpr int BUF_BYTES = A_BYTES + W_PIECES * 1024;
+    constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;
+    constexpr int WPW = (W_PIECES + NWAVE - 1) / NWAVE;
+    constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;
+    constexpr int PAR_OFF = 2 * BUF_BYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+    const int nchunks = XQ ? (a.c_in >> 6) * 5 : a.c_in >> 4;    // two chunks (H, Q) per 32 input channels; XQ: H L H L Q per 64; X3: one per 16
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int by = bid / tiles_y;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    const int img_step = gridDim.y;
+    int n = blockIdx.y;
+    if (n >= a.n) return;
+
+    unsigned tmask = 0x1ffu;
+    if (MASKED && a.tapmask) {
+        tmask = 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) tmask |= a.tapmask[by * NT + j];
+        tmask = __builtin_amdgcn_readfirstlane(tmask);
+    }
+
+    float* s_par = reinterpret_cast<float*>(smem + PAR_OFF);
+    for (int i = tid; i < 3 * 32 * NT; i += NWAVE * 64) {
+        const int which = i / (32 * NT), c = i - which * (32 * NT);
+        const int co = by * NT * 32 + c;
+        const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;
+        const float* src = which == 0 ? a.bias : (which == 1 ? a.bn_scale : a.bn_shift);
+        s_par[i] = (src && co < a.c_out) ? src[cpar] : (which == 1 ? 1.f : 0.f);
+    }
+
+    // E8M0 scale operands of the fp8 products: weight side per lane (= per output channel row), pixel side uniform per source
+    int wsc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wsc[j] = X3 ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];
+    const int asc0 = 127 - a.src[0].sexp, asc1 = 127 - a.src[NSRC2 ? 1 : 0].sexp;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[0].p, 0, a.src_bytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[NSRC2 ? 1 : 0].p, 0, a.src_bytes[NSRC2 ? 1 : 0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    constexpr int NS = NSRC2 ? 2 : 1;
+    unsigned voff[NS][APW];           // per source: byte offset (plane included) of this lane's 16 bytes inside a chunk, or OOB
+    {
+        const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
+#pragma unroll
+        for (int si = 0; si < NS; ++si) {
+            const MxSrc& sp = a.src[si];
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const int u = (i * NWAVE + wave) * 64 + lane;
+                const int plane = u / (G::NPIX * 2);
+                const int rem = u - plane * (G::NPIX * 2);
+                const int p = rem >> 1, j = rem & 1;
+                const int py = p / G::PITCH, q = p - py * G::PITCH;
+                const int kh = j ^ ((q >> 3) & 1);          // 16-byte XOR swizzle on bit 3 of the COLUMN position (see the fragment reads)
+                int px;
+                bool slot_ok = u < A_UNITS;
+                if (STRIDE == 1) px = q;
+                else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok && px < G::TWI; }
+                const int gy = iy0 + py, gx = ix0 + px;
+                const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
+                // both chunk kinds keep their second plane h*w*32 bytes after the first (the next 16-channel block of the hi
+                // plane / the al8 plane of the q block), so one offset serves both
+                // (X3: the second plane is the tensor's lo plane, q_off bytes after the hi plane)
+                if (X3) voff[si][i] = in ? (unsigned)plane * sp.q_off + (unsigned)((gy >> sp.up) * sp.w + (gx >> sp.up)) * 32u + kh * 16u : OOB;
+                else voff[si][i] = in ? (unsigned)((plane * sp.h + (gy >> sp.up)) * sp.w + (gx >> sp.up)) * 32u + kh * 16u : OOB;
+            }
+        }
+    }
+    const int c_src0 = a.src[0].c;
+    const unsigned img_b0 = (unsigned)(a.src[0].c * a.src[0].h * a.src[0].w) * 2u, blk_b0 = (unsigned)(a.src[0].h * a.src[0].w) * 32u;
+    const unsigned img_b1 = (unsigned)(a.src[NS - 1].c * a.src[NS - 1].h * a.src[NS - 1].w) * 2u, blk_b1 = (unsigned)(a.src[NS - 1].h * a.src[NS - 1].w) * 32u;
+    const unsigned qo0 = a.src[0].q_off, qo1 = a.src[NS - 1].q_off;
+    const unsigned w_tile_b = (unsigned)(by * NT) * (unsigned)nchunks * W_NB, w_nt_b = (unsigned)nchunks * W_NB;
+
+    // one ninth (part 0..8) of the DMA of chunk `ck` of image `img` into LDS buffer `buf`; part < 0: all of it
+    auto issue = [&](int img, int ck, int buf, int part) {
+        int c0 = (ck >> 1) << 5;                       // first channel of the chunk's 32-channel group
+        bool isq = ck & 1;
+        if (X3) { c0 = ck << 4; isq = false; }         // one chunk per 16 channels: planes = hi / lo
+        if (XQ) {                                      // chunk 5 g64 + i: i = 0, 1: H, L of channels 64 g64 ..; 2, 3: of 64 g64 + 32 ..; 4: Q of all 64
+            const int g64 = ck / 5, i = ck - 5 * g64;
+            isq = i == 4;
+            c0 = (g64 << 6) + (isq ? 0 : (i >> 1) << 5);
+        }
+        const bool s1 = NSRC2 && c0 >= c_src0;
+        // hi plane: image stride C*H*W*2 bytes, 16-channel block stride H*W*32; q planes: the same image stride (2 x 1 byte
+        // per element) and 2 x H*W*32 per 32-channel block - the SAME offsets, shifted by q_off.  XQ: al8-only planes, one byte
+        // per element: half the image stride, H*W*32 per 32-channel block.
+        unsigned soff = s1 ? (unsigned)img * img_b1 + (unsigned)((c0 - c_src0) >> 4) * blk_b1 + (isq ? qo1 : 0u)
+                           : (unsigned)img * img_b0 + (unsigned)(c0 >> 4) * blk_b0 + (isq ? qo0 : 0u);
+        if (XQ && isq) soff = (unsigned)img * (img_b0 >> 1) + (unsigned)(c0 >> 5) * blk_b0 + qo0;
+        char* dA = smem + buf * BUF_BYTES;
+        char* dW = dA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            if (part >= 0 && i / APT != part) continue;
+            const int piece = i * NWAVE + wave;
+            if ((i + 1) * NWAVE <= A_PIECES || piece < A_PIECES) {      // only the last round of pieces needs the run-time test
+                if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(dA + piece * 1024), 16, voff[NS - 1][i], soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(dA + piece * 1024), 16, voff[0][i], soff, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            if (part >= 0 && i / WPT != part) continue;
+            const int piece = i * NWAVE + wave;
+            const int nt = piece / 18, q = piece - nt * 18;
+            if (((i + 1) * NWAVE <= W_PIECES || piece < W_PIECES) && (!MASKED || ((tmask >> (q >> 1)) & 1u)))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(dW + piece * 1024), 16, lane * 16,
+                                                         w_tile_b + (unsigned)nt * w_nt_b + (unsigned)ck * W_NB + q * 1024, 0, 0);
+        }
+    };
+
+    // ---- per-lane fragment addressing ----------------------------------------------------------------------------------------
+    // LDS pixel (row, column q) of a plane lives at (row PITCH + q) 32 + (logical half ^ bit 3 of q) 16: the swizzle depends on
+    // the column only, so a tap (ky, kx) adds a CONSTANT row offset (an instruction immediate) to one of three per-lane column
+    // addresses - no address arithmetic inside the tap loop.  (A 16-lane group of a ds_read_b128 covers 16 consecutive
+    // columns of one row on the 32-wide tiles: bank-conflict free.)
+    const int r = lane & 31, kh = lane >> 5;
+    const int lox = r % TW, loy = r / TW;
+    const int w_off = lane * 16 + wn * NTW * W_NB;
+    int colH[3], colQ[3];             // byte address (within an LDS buffer) of this lane's 16 bytes for kx = 0, 1, 2; row 0 of its M block 0
+    {
+        const int rowb = ((wm * MT * G::ROWS_PER_MB + loy) * STRIDE) * G::PITCH * 32;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int q = lox + (STRIDE == 1 ? kx : (kx & 1) * G::HALF + (kx >> 1));
+            const int sw = (q >> 3) & 1;
+            colH[kx] = rowb + q * 32 + ((sw ^ kh) << 4);                   // H chunk: logical half kh of plane 0 (plane 1: + PLANE_B)
+            colQ[kx] = rowb + q * 32 + (sw << 4) + kh * PLANE_B;          // Q chunk: logical half 0 of plane kh (half 1: ^ 16)
+        }
+    }
+
+    issue(n, 0, 0, -1);
+    int buf = 0;
+    bool dma_waited = false;
+
+    for (;;) {
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int next_n = n + img_step;
+    // one chunk: wait for its DMA, barrier, then 9 taps with the next chunk's DMA issued in ninths between them.
+    // ISQ = false: H chunk, planes = channels 0-15 / 16-31 (fp16); a lane feeds k = 8 kh .. 8 kh + 7 of both planes to two
+    //              K = 16 MFMAs.  ISQ = true: Q chunk, planes = a8 / al8; lane half kh reads all 32 bytes of plane kh
+    //              (K half kh of one K = 64 MFMA: a8 meets wl8, al8 meets w8).
+    // The H and Q chunks of a 32-channel group run back to back in one loop iteration (no branch between the two bodies:
+    // a branch made the register allocator keep the accumulators in two places).
+    // KIND 2 (X3): the f16x3 arithmetic of conv_mfma2.hip on this skeleton - planes = hi / lo of 16 channels, weight tile = w_hi / w_lo
+    //              fragments (conv3x3_pack_host's image), three K = 16 MFMAs per tap in conv_mfma2's order (w_lo a_hi, w_hi a_lo,
+    //              w_hi a_hi), so results are bit-identical to that kernel's
+    auto chunk = [&](auto kind_tag, int ck) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool ISQ = KIND == 1;
+        if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = ck + 1 < nchunks;
+        const int dma_img = more ? n : (next_n < a.n ? next_n : n), dma_ck = more ? ck + 1 : 0;
+        const char* sA = smem + buf * BUF_BYTES;
+        const char* sW = sA + A_BYTES;
+        buf ^= 1;
+        // the tap ORDER is a property of the tile width alone (never of how the tile is split over waves): every instantiation
+        // that can serve a given layer shape accumulates in the same order, so a result does not depend on the batch size
+        constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
+        constexpr bool ROWREUSE = COLMAJOR && MT == 2;
+        const int asc = (NSRC2 && !X3 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
+        // this chunk's three column addresses inside the current buffer (the only per-chunk address arithmetic)
+        const int bufoff = (int)(sA - smem);
+        int ca0[3], ca1[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            ca0[kx] = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
+            ca1[kx] = ISQ ? (ca0[kx] ^ 16) : ca0[kx] + PLANE_B;           // all other address terms are multiples of 32
+        }
+        int wo = w_off;
+        asm volatile("" : "+v"(wo));
+        i32x4 ra[MT][2];
+        i32x4 rb[NTW][2];
+#pragma unroll
+        for (int slot = 0; slot < 9; ++slot) {
+            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
+            const int tap = ky * 3 + kx;
+#if !(MX_ABL & 1)
+            issue(dma_img, dma_ck, buf, slot);
+#endif
+            const bool live = !MASKED || ((tmask >> tap) & 1u);
+            if (!ROWREUSE && !live) continue;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (ROWREUSE && ky > 0 && mt == 0) { ra[0][0] = ra[1][0]; ra[0][1] = ra[1][1]; continue; }
+#if MX_ABL & 2
+                if (slot > 0) continue;
+#endif
+                constexpr int RB = G::PITCH * 32;                           // bytes per tile row
+                const int rowc = (mt * G::ROWS_PER_MB * STRIDE + ky) * RB;   // compile-time constant: the ds_read's immediate offset
+                ra[mt][0] = *reinterpret_cast<const i32x4*>(smem + ca0[kx] + rowc);
+                ra[mt][1] = *reinterpret_cast<const i32x4*>(smem + ca1[kx] + rowc);
+            }
+            if (ROWREUSE && !live) continue;
+#if MX_ABL & 2
+            static_assert(true, "");
+#endif
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+#if MX_ABL & 2
+                if (slot > 0) continue;
+#endif
+                const int off = wo + nt * W_NB + tap * 2 * WBLK;
+                rb[nt][0] = *reinterpret_cast<const i32x4*>(sW + off);
+                rb[nt][1] = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
+            }
+            if ((slot + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if (ISQ) {
+                        const i32x8 bw = {rb[nt][0][0], rb[nt][0][1], rb[nt][0][2], rb[nt][0][3], rb[nt][1][0], rb[nt][1][1], rb[nt][1][2], rb[nt][1][3]};
+                        const i32x8 ap = {ra[mt][0][0], ra[mt][0][1], ra[mt][0][2], ra[mt][0][3], ra[mt][1][0], ra[mt][1][1], ra[mt][1][2], ra[mt][1][3]};
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], 0, 0, 0, wsc[nt], 0, asc);
+                    } else if (KIND == 2) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
+                    } else {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            // pin this tap's MFMAs here: without a use of the accumulators the optimiser sinks the whole (pure) MFMA chain of a
+            // chunk below its last tap, which hoists all 9 taps of fragment reads above it (~200 VGPRs, spills)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    float pin = acc[mt][nt][0];
+                    asm volatile("" : "+v"(pin));
+                    acc[mt][nt][0] = pin;
+                }
+        }
+    };
+    using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>;
+    if constexpr (X3) {
+        for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck);
+    } else if constexpr (XQ) {
+        for (int ck = 0; ck < nchunks; ck += 5) {
+#pragma unroll 1
+            for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h);     // H, L, H, L: the same code, other weights
+            chunk(KQ{}, ck + 4);
+        }
+    } else {
+        for (int ck = 0; ck < nchunks; ck += 2) {
+            chunk(KH{}, ck);
+            chunk(KQ{}, ck + 1);
+        }
+    }
+
+    // ---- epilogue: bias (+res) -> activation -> BN affine -> split into the output planes -> store ------------------------
+    // All stores go through ONE buffer descriptor over the output tensor (hi [+ lo] [+ q] planes are one allocation): the
+    // per-lane part of an address is a 32-bit pixel offset per M block, everything that depends on the channel group, the
+    // image and the plane is a scalar offset, and out-of-tile pixels get an out-of-range offset (the hardware drops the
+    // store) - no 64-bit address arithmetic, no predication.
+    {
+    int by_e = by, oy0_e = oy0, ox0_e = ox0;
+    typedef const __attribute__((address_space(3))) float lds_cfloat;
+    lds_cfloat* par_e = (lds_cfloat*)s_par;            // LDS address space: ds_read, not flat loads
+    // the epilogue reads its parameters from the kernel-argument segment when it runs (a laundered pointer: the loads
+    // cannot be hoisted), so they do not occupy SGPRs - or spill into VGPR lanes - during the tap loop
+    // (constant address space: the loads are scalar and everything derived from them stays wave-uniform)
+    typedef const __attribute__((address_space(4))) ConvMxArgs KArgs;
+    KArgs* ep = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(by_e), "+s"(oy0_e), "+s"(ox0_e), "+v"(par_e), "+s"(ep));
+    KArgs& a = *ep;                   // shadows the by-value argument inside the epilogue
+    const int act = a.act;
+    const float slope = a.slope;
+    const bool has_bn = a.bn_scale != nullptr;
+    auto epilogue = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;      // 0: channel-blocked act, 1: depth-to-space act, 2: fp32 NCHW
+        const int oc = MODE == 1 ? a.d2s_c : a.c_out_pad;
+        const int oh = MODE == 1 ? 2 * a.h_out : a.h_out, ow = MODE == 1 ? 2 * a.w_out : a.w_out;
+        const unsigned ohw = (unsigned)(oh * ow);
+        const bool wr_lo = MODE != 2 && a.out_plane != 0, wr_q = MODE != 2 && a.out_q_off != 0;
+        const bool ql_only = a.out_q_kind != 0;              // al8-only q planes: one byte per element, no a8 plane
+        const float qs = __builtin_ldexpf(1.f, a.out_sexp), qls = __builtin_ldexpf(1.f, a.out_sexp + MX_LO_SHIFT);
+        const __amdgpu_buffer_rsrc_t ro = MODE == 2 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.out_f32, 0, a.out_bytes, 0x00020000)
+                                                    : __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+        // scalar byte offsets per channel group (nt, q): hi plane (the lo plane is out_plane*2 further), a8 plane (al8 is
+        // ohw*32 further); depth-to-space: virtual channel cv -> phase ph = cv / d2s_c, channel cv % d2s_c, pixel (2y+ph/2, 2x+ph%2)
+        unsigned so_hi[NTW][2], so_q[NTW][2];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cv = (by_e * NT + wn * NTW + nt) * 32 + 16 * q;
+                int cb = cv; unsigned php = 0;
+                if (MODE == 1) { const int ph = cv / a.d2s_c; cb = cv - ph * a.d2s_c; php = (unsigned)((ph >> 1) * ow + (ph & 1)) * 32u; }
+                so_hi[nt][q] = ((unsigned)(n * oc) + (unsigned)cb) * ohw * 2u + php;
+                so_q[nt][q] = (unsigned)a.out_q_off + ((unsigned)(n * oc) + (unsigned)(cb & ~31)) * ohw * (ql_only ? 1u : 2u) + (unsigned)(cb & 16) + php;
+            }
+        // per-lane pixel offset (bytes, 32 per pixel) of M block mt, or OOB
+        unsigned vo[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int px = r % TW, py = (wm * MT + mt) * G::ROWS_PER_MB + r / TW;
+            const int oy = oy0_e + py, ox = ox0_e + px;
+            const bool pok = oy < a.h_out && ox < a.w_out;
+            const unsigned pi = MODE == 1 ? (unsigned)(2 * oy * ow + 2 * ox) : (unsigned)(oy * ow + ox);
+            vo[mt] = pok ? (MODE == 2 ? pi * 4u : pi * 32u) : OOB;
+        }
+        // ---- phase 1: math ----
+        // Everything the hot (activation-tensor) modes do per element is branch-free and packed where the ISA has a packed form:
+        // v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32 for bias, slope, BN and the hi/lo split, v_cvt_scalef32_pk_fp8_f32 (scale + RNE +
+        // saturation in one instruction, two elements each) for the fp8 planes; run-time layer properties (residual, BN, lo / q planes)
+        // are tested once per 32x32 block, not per element group.  Round 2's epilogue spent ~15 VALU instructions and 5 scalar
+        // branches per element / 4-element group here, with the matrix pipe idle behind the chunk barrier
+        // (profiles/r02_conv_pmc.txt: 4.1 VALU per MFMA on the f16+fp8x2 instantiation against 0.23 inside its tap loop).
+        // Results are bit-identical to that code (tools/cvt_scale_probe.hip pins the scaled conversion against mul + v_med3 + cvt on
+        // everything that rounds into the finite range; beyond it the instruction yields the NaN code, hence the slow path below).
+        unsigned lpark[MT][NTW][8];                          // lo words of the tile (live only when the output has a lo AND q planes)
+        // activation as x = max(x, x slope + 0): ReLU = slope 0 (the "+ 0" turns -0 into +0, as fmaxf(x, 0) does), none = slope 1
+        const float slope_e = act == DISCO_ACT_RELU ? 0.f : (act == DISCO_ACT_LRELU ? slope : 1.f);
+        const f32x2 slope2 = {slope_e, slope_e}, zero2 = {0.f, 0.f};
+        // the scaled conversions divide by their scale operand: 2^-sexp and 2^-(sexp + 11)
+        const float qinv = __builtin_ldexpf(1.f, -a.out_sexp), qlinv = __builtin_ldexpf(1.f, -(a.out_sexp + MX_LO_SHIFT));
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (MODE != 2) {
+                    f32x2 x[8];                              // pair p = elements 2p, 2p+1; 4-channel group g4 = p >> 1 (c = 8 g4 + 4 kh + 0..3)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
+                        const float4 b4 = *(const __attribute__((address_space(3))) float4*)(par_e + cl);
+                        x[2 * g4] = f32x2{acc[mt][nt][4 * g4], acc[mt][nt][4 * g4 + 1]} + f32x2{b4.x, b4.y};
+                        x[2 * g4 + 1] = f32x2{acc[mt][nt][4 * g4 + 2], acc[mt][nt][4 * g4 + 3]} + f32x2{b4.z, b4.w};
+                    }
+                    if (a.res) {
+                        // residual (same shape and hi-plane layout as the output, its own allocation), plus its lo plane if any
+                        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res_bytes, 0x00020000);
+                        const bool res_lo = X3 || a.res_plane != 0;
+                        f16x4 rh[4], rl[4];
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const unsigned so = so_hi[nt][g4 >> 1];
+                            const unsigned vof = vo[mt] == OOB ? OOB : vo[mt] + 16u * (g4 & 1) + 8u * kh;
+                            rh[g4] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, vof, so, 0));
+                            rl[g4] = res_lo ? __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rr, vof, so + (unsigned)a.res_plane * 2u, 0)) : f16x4{0, 0, 0, 0};
+                        }
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                const f32x2 h2 = {(float)rh[g4][2 * d], (float)rh[g4][2 * d + 1]}, l2 = {(float)rl[g4][2 * d], (float)rl[g4][2 * d + 1]};
+                                if (X3) x[2 * g4 + d] += h2 + l2;                          // conv_mfma2's form: x + (hi + lo)
+                                else { x[2 * g4 + d] += h2; x[2 * g4 + d] += l2; }       // (no lo plane: l2 = 0)
+                            }
+                    }
+#ifndef MX_DEV_MODE
+                    if (act == DISCO_ACT_TANH) {
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) x[p] = f32x2{tanhf(x[p][0]), tanhf(x[p][1])};
+                    } else
+#endif
+                    {
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) {
+                            const f32x2 t = __builtin_elementwise_fma(x[p], slope2, zero2);
+                            x[p] = f32x2{vmax_f32(x[p][0], t[0]), vmax_f32(x[p][1], t[1])};
+                        }
+                    }
+                    if (has_bn) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
+                            const float4 s4 = *(const __attribute__((address_space(3))) float4*)(par_e + 32 * NT + cl);
+                            const float4 h4 = *(const __attribute__((address_space(3))) float4*)(par_e + 64 * NT + cl);
+                            x[2 * g4] = __builtin_elementwise_fma(x[2 * g4], f32x2{s4.x, s4.y}, f32x2{h4.x, h4.y});
+                            x[2 * g4 + 1] = __builtin_elementwise_fma(x[2 * g4 + 1], f32x2{s4.z, s4.w}, f32x2{h4.z, h4.w});
+                        }
+                    }
+                    // fp16 hi (+ lo) in pairs; fp8 a8 / al8 in quads: dword g of the fp8 planes = channels 8 g + 4 kh + 0..3
+                    unsigned hd[8], ld[8], a8[4], l8[4];
+                    f32x2 lf[8];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const f16x2 h2 = __builtin_convertvector(x[p], f16x2);
+                        lf[p] = x[p] - __builtin_convertvector(h2, f32x2);
+                        hd[p] = __builtin_bit_cast(unsigned, h2);
+                    }
+                    if (X3 || wr_lo) {
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) ld[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(lf[p], f16x2));
+                    }
+                    if (!X3 && wr_q) {
+                        float bmax = 0.f;                    // max |x| of this lane's 16 values
+#pragma unroll
+                        for (int p = 0; p < 8; p += 2) {
+                            bmax = fmaxf(fmaxf(bmax, fabsf(x[p][0])), fabsf(x[p][1]));
+                            bmax = fmaxf(fmaxf(bmax, fabsf(x[p + 1][0])), fabsf(x[p + 1][1]));
+                        }
+                        // The conversion does not saturate (a value that rounds above 448 becomes the NaN code 0x7f), and calibration
+                        // leaves 14x headroom: only when a value of this block is beyond the range (|al8| <= |a8| by construction, so
+                        // max |x| decides; wave-uniform test) its operands are clamped first - in place, and counted
+                        if (__builtin_expect(__ballot(!(bmax * qs <= 448.f)) != 0ull, 0)) {
+                            const float lim = 448.f * qinv, liml = 448.f * qlinv;
+                            unsigned cnt = 0;
+#pragma unroll
+                            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const float xc = __builtin_amdgcn_fmed3f(x[p][e], -lim, lim), lc = __builtin_amdgcn_fmed3f(lf[p][e], -liml, liml);
+                                    cnt += (ql_only ? 0 : (xc != x[p][e])) + (lc != lf[p][e]);      // al8-only tensors have no a8 plane to clamp
+                                    x[p][e] = xc; lf[p][e] = lc;
+                                }
+                            if (a.sat && cnt) atomicAdd(a.sat, cnt);
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            a8[g] = fp8x4_scaled(x[2 * g], x[2 * g + 1], qinv);
+                            l8[g] = fp8x4_scaled(lf[2 * g], lf[2 * g + 1], qlinv);
+                        }
+                    }
+                    // v_permlane32_swap: lower.(group 1) <-> upper.(group 0), lower.(group 3) <-> upper.(group 2): the lower
+                    // half-wave then holds channels 0-7 and 16-23 of its pixel, the upper half 8-15 and 24-31
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            auto sh = __builtin_amdgcn_permlane32_swap(hd[4 * q + d], hd[4 * q + 2 + d], false, false);
+                            hd[4 * q + d] = sh[0]; hd[4 * q + 2 + d] = sh[1];
+                        }
+                    if (X3 || wr_lo) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                auto sl = __builtin_amdgcn_permlane32_swap(ld[4 * q + d], ld[4 * q + 2 + d], false, false);
+                                ld[4 * q + d] = sl[0]; ld[4 * q + 2 + d] = sl[1];
+                            }
+                    }
+                    if (!X3 && wr_q) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            auto sa = __builtin_amdgcn_permlane32_swap(a8[2 * q], a8[2 * q + 1], false, false);
+                            a8[2 * q] = sa[0]; a8[2 * q + 1] = sa[1];
+                            auto sl = __builtin_amdgcn_permlane32_swap(l8[2 * q], l8[2 * q + 1], false, false);
+                            l8[2 * q] = sl[0]; l8[2 * q + 1] = sl[1];
+                        }
+                    }
+                    // All output words are parked in the accumulator registers and stored in phase 3: hi in 0-7; f16x3: lo in 8-15;
+                    // otherwise a8 in 8-11, al8 in 12-15 and the lo words (residual-chain tensors only) in lpark.  (The lo words used to be
+                    // stored right here, "to free their registers", and the next (mt, nt) iteration's first VALU write could land in a
+                    // data register of that store one instruction behind it: the store-data hazard described at buffer_store_b128() -
+                    // lanes 12-15 / 28-31 of one dword arrived stale in the lo plane, differently from run to run.  Found when the f16x3
+                    // arithmetic - where every layer writes a lo plane - moved onto this kernel.)
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) acc[mt][nt][d] = __builtin_bit_cast(float, hd[d]);
+                    if constexpr (X3) {
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) acc[mt][nt][8 + d] = __builtin_bit_cast(float, ld[d]);
+                    } else {
+                        if (wr_lo) {
+#pragma unroll
+                            for (int d = 0; d < 8; ++d) lpark[mt][nt][d] = ld[d];
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            acc[mt][nt][8 + g] = __builtin_bit_cast(float, a8[g]);
+                            acc[mt][nt][12 + g] = __builtin_bit_cast(float, l8[g]);
+                        }
+                    }
+                } else {
+                float v[16];
+                // fp32 NCHW outputs (pred_mask0 + softmax, outConv + tanh: two launches per forward): per group of 4 channels
+                // (c = 8 g4 + 4 kh + 0..3) parameters from LDS, bias -> activation -> BN affine
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
+                    const float4 b4 = *(const __attribute__((address_space(3))) float4*)(par_e + cl);
+                    float x[4] = {acc[mt][nt][4 * g4] + b4.x, acc[mt][nt][4 * g4 + 1] + b4.y, acc[mt][nt][4 * g4 + 2] + b4.z, acc[mt][nt][4 * g4 + 3] + b4.w};
+                    if (act == DISCO_ACT_RELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);
+                    } else if (act == DISCO_ACT_LRELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], x[j] * slope);
+                    } else if (act == DISCO_ACT_TANH) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[j] = tanhf(x[j]);
+                    }
+                    if (has_bn) {
+                        const float4 s4 = *(const __attribute__((address_space(3))) float4*)(par_e + 32 * NT + cl);
+                        const float4 h4 = *(const __attribute__((address_space(3))) float4*)(par_e + 64 * NT + cl);
+                        x[0] = x[0] * s4.x + h4.x; x[1] = x[1] * s4.y + h4.y; x[2] = x[2] * s4.z + h4.z; x[3] = x[3] * s4.w + h4.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[4 * g4 + j] = x[j];
+                }
+                if (a.softmax) {
+                    const int cob = (by_e * NT + wn * NTW + nt) * 32;
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (cob + (e & 3) + 8 * (e >> 2) + 4 * kh < a.c_out) mx = fmaxf(mx, v[e]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float sm = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        v[e] = cob + (e & 3) + 8 * (e >> 2) + 4 * kh < a.c_out ? expf(v[e] - mx) : 0.f;
+                        sm += v[e];
+                    }
+                    sm += __shfl_xor(sm, 32);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = v[e] / sm;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = v[e];
+                }
+            }
+        }
+        // ---- phase 2: the next image's first chunk has landed ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- phase 3: stores ----
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int cob = (by_e * NT + wn * NTW + nt) * 32;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                // (elements are read by value: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+                const f32x16& t = acc[mt][nt];
+                if (MODE != 2) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const bool cok = cob + 16 * q + 8 * kh < a.c_out;
+                        const unsigned vb = (vo[mt] == OOB || !cok) ? OOB : vo[mt];
+                        const i32x4 d4 = {__float_as_int(t[4 * q]), __float_as_int(t[4 * q + 1]), __float_as_int(t[4 * q + 2]), __float_as_int(t[4 * q + 3])};
+                        buffer_store_b128(d4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q]);
+                        if (wr_lo) {
+                            const i32x4 l4 = X3 ? i32x4{__float_as_int(t[8 + 4 * q]), __float_as_int(t[9 + 4 * q]), __float_as_int(t[10 + 4 * q]), __float_as_int(t[11 + 4 * q])}
+                                                : i32x4{(int)lpark[mt][nt][4 * q], (int)lpark[mt][nt][4 * q + 1], (int)lpark[mt][nt][4 * q + 2], (int)lpark[mt][nt][4 * q + 3]};
+                            buffer_store_b128(l4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u);
+                        }
+                        if (wr_q) {
+                            // q planes: this lane owns bytes 8 kh .. 8 kh + 7 of its pixel's 16-byte half (cb & 16)
+                            const i32x2 q0 = {__float_as_int(t[8 + 2 * q]), __float_as_int(t[9 + 2 * q])};
+                            const i32x2 q1 = {__float_as_int(t[12 + 2 * q]), __float_as_int(t[13 + 2 * q])};
+                            if (!ql_only) __builtin_amdgcn_raw_buffer_store_b64(q0, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q], 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(q1, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q] + (ql_only ? 0u : ohw * 32u), 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;        // differs between the half-waves: per-lane offset
+                        const unsigned vof = (vo[mt] == OOB || co >= a.c_out) ? OOB : vo[mt] + (unsigned)(n * a.c_out + co) * ohw * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[e]), ro, vof, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+#ifdef MX_DEV_MODE       // ISA inspection builds: one epilogue mode only
+    epilogue(std::integral_constant<int, MX_DEV_MODE>{});
+#else
+    if (a.out_f32) epilogue(std::integral_constant<int, 2>{});
+    else if (a.d2s_c > 0) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 0>{});
+#endif
+    }
+    dma_waited = true;
+
+    n = next_n;
+    if (n >= a.n) break;
+    }
+#endif
+}
+
+inline int num_cus_mx() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0>
+int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
+    using G = GeoMx<TW, TH, STRIDE>;
+    constexpr int A_BYTES = ((2 * G::NPIX * 2 + 63) / 64) * 1024;
+    constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR>;
+    // function attributes are per device and per kernel instantiation (this static lives in the instantiation)
+    static std::once_flag attr_once[DISCO_MAX_DEVICES];
+    hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once[current_device()], [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    });
+    DISCO_HIP_CHECK(attr_err);
+    const int combos = cdiv(a.w_out, TW) * cdiv(a.h_out, TH) * cdiv(a.c_out, 32 * NT);
+    int groups = a.n;
+    {
+        const long cus = num_cus_mx();
+        long best_cost = -1;
+        for (int g = 1; g <= a.n; ++g) {
+            const long cost = (long)cdiv((long)combos * g, cus) * cdiv(a.n, g);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; groups = g; }
+        }
+    }
+    dim3 grid(combos, groups);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, a);
+    DISCO_LAUNCH_CHECK("conv3x3_mx_kernel");
+    return DISCO_OK;
+}
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, int AR>
+int launch_mx2(const ConvMxArgs& a, hipStream_t s) {
+    if constexpr (AR == 1) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, 1>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, 1>(a, s);
+    else {
+        if (a.nsrc > 1) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, true, AR>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, true, AR>(a, s);
+        return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, AR>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, AR>(a, s);
+    }
+}
+
+}  // namespace
+
+// One translation unit per arithmetic instantiates this (conv_mx_ar0/1/2.hip): the three compile in parallel.
+template <int AR>
+int dispatch_mx_ar(const ConvMxArgs& a, hipStream_t s) {
+    const bool wide = a.w_out > 16;
+    const bool nt2 = a.c_out > 32;
+    if (a.stride == 1) {
+        struct Cand { int tw, th, nt; };
+        static const Cand order[6] = {{32, 16, 2}, {32, 16, 1}, {32, 8, 2}, {16, 16, 2}, {32, 8, 1}, {16, 16, 1}};
+        const long fill = (long)num_cus_mx() * 3 / 4;
+        int pick = -1; long best = -1;
+        for (int i = 0; i < 6; ++i) {
+            const Cand& c = order[i];
+            if ((c.nt == 2 && !nt2) || (c.tw == 32 && !wide) || (c.tw == 32 && c.th == 16 && a.h_out <= 8)) continue;
+            const long w = (long)cdiv(a.w_out, c.tw) * cdiv(a.h_out, c.th) * cdiv(a.c_out, 32 * c.nt) * a.n;
+            if (w >= fill) { pick = i; break; }
+            if (w > best) { best = w; pick = i; }
+        }
+        switch (pick) {
+            case 0: return launch_mx2<32, 16, 2, 1, 8, 1, AR>(a, s);
+            case 1: return launch_mx2<32, 16, 1, 1, 8, 1, AR>(a, s);
+            case 2: return launch_mx2<32, 8, 2, 1, 4, 2, AR>(a, s);
+            case 3: return launch_mx2<16, 16, 2, 1, 4, 2, AR>(a, s);
+            case 4: return launch_mx2<32, 8, 1, 1, 8, 1, AR>(a, s);
+            default: return launch_mx2<16, 16, 1, 1, 8, 1, AR>(a, s);
+        }
+    }
+    if (wide) return nt2 ? launch_mx2<32, 4, 2, 2, 4, 2, AR>(a, s) : launch_mx2<32, 4, 1, 2, 4, 1, AR>(a, s);
+    return nt2 ? launch_mx2<16, 8, 2, 2, 4, 2, AR>(a, s) : launch_mx2<16, 8, 1, 2, 4, 1, AR>(a, s);
+}
+
+}  // namespace disco
