@@ -36,7 +36,7 @@ sys.path.insert(0, REPO)
 GFLOP_PER_IMAGE = 255.470          # algorithmic work of one 256x256 image
 FP16_MFMA_PEAK = 2.5e15            # dense, MI355X_MICROARCH.md
 FP32_MFMA_PEAK = 157.3e12
-CONV_SOURCES = ["conv_mfma2.hip", "conv_mx.hip", "common.h", "api.cpp"]
+CONV_SOURCES = ["conv_mx_kernel.h", "conv_mx.hip", "common.h", "api.cpp"]
 
 
 def cpu_baseline(sd, seconds_budget=30.0, all_cores=False):
@@ -87,7 +87,7 @@ def pmc_traffic():
     + WRITE_SIZE).  PMC counters cannot be read from inside a timed run, so the file carries the hash of the kernel sources it
     was measured on; a stale file is reported as null rather than as a number."""
     try:
-        with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")) as f:
             d = json.load(f)
         return d["hbm_bytes_per_launch"] if d.get("source_hash") == source_hash() else None
     except Exception:
@@ -138,12 +138,14 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="fix the TOTAL batch instead (tests; ragged shards allowed)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default=None, choices=["mx8", "x2q", "mx8all", "f16x3", "f16x1"],
+    ap.add_argument("--precision", default=None, choices=["mx8", "x2q", "mx8all", "f16x3"],
                     help="conv arithmetic per stack (disentangledcolorization_amd/model.py); default: the package default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing of the opt-in precision mode (x2q) that a default N=1 run reports next to `value`")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with one thread per host core (minutes on a 256-core box)")
-    ap.add_argument("--micro", type=int, default=1, help="micro-batches per GPU, each on its own HIP stream (2: +1.7%%, 1749 vs 1720 img/s, but concurrent streams blur the per-launch conv timings the roofline is computed from, so the default stays 1)")
+    ap.add_argument("--micro", type=int, default=2, help="micro-batches per GPU, each on its own HIP stream: the token path / k-means of one (a few CUs busy) "
+                    "overlaps with the conv stacks of the other (+1.7%% over 1).  The per-launch profile behind `roofline` is taken on ONE stream after the timed loop")
+    ap.add_argument("--profile-steps", type=int, default=3, help="single-stream, event-bracketed forwards after the timed loop (roofline / stage table)")
     args = ap.parse_args()
     if args.precision is None:
         from disentangledcolorization_amd.model import default_precision
@@ -190,8 +192,10 @@ def main():
                                 enhanced=True, precision=args.precision, init_weights=False)
         model.load_state_dict(sd)
         model = model.cuda().eval()
-        model.set_profiling(2)                    # hipEvent pairs around every MFMA conv launch (and stage marks)
-        runner = ShardedColorizer.from_model(model, micro_batches=args.micro, exact_fallback=False)   # no host sync while timing
+        model.set_profiling(0)                    # the timed loop is the product: no event pairs around the launches
+        # DISCO_FORCE_GATHER=1 (tests/test_gpu_dist.py): run the collectives at world size 1 too
+        force = os.environ.get("DISCO_FORCE_GATHER") == "1"
+        runner = ShardedColorizer.from_model(model, micro_batches=args.micro, exact_fallback=False, force_gather=force)   # no host sync while timing
 
     def seed():
         np.random.seed(130); torch.manual_seed(130)
@@ -217,7 +221,7 @@ def main():
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
-        last = step()   # asynchronous: no host sync inside the timed region; every conv launch is event-bracketed
+        last = step()   # asynchronous: no host sync and no instrumentation inside the timed region
     runner.wait()       # the outstanding all-gathers (N > 1)
     if use_dist:
         dist.barrier()
@@ -227,13 +231,6 @@ def main():
     conv_ms = conv_fl = conv_bytes = 0.0
     conv_launches = 0
     stage_ms = {}
-    if model is not None:
-        # per-launch hipEvent timings of the LAST timed step (the context keeps the events of its latest forward)
-        nl, ms, fl = model.conv_profile()
-        conv_bytes = model.conv_profile_bytes() / max(nl, 1)
-        conv_launches, conv_ms, conv_fl = nl * args.steps, ms * args.steps, fl * args.steps
-        for name, sms, _ in model.profile():
-            stage_ms[name] = sms * args.steps
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -244,7 +241,7 @@ def main():
     # stream, as the timed loop does, changes nothing) and no fp8 activation may have been clamped.
     events = sat = 0
     if model is not None:
-        exact = ShardedColorizer.from_model(model, exact_fallback=True)
+        exact = ShardedColorizer.from_model(model, exact_fallback=True, force_gather=force)
         seed()
         p_exact, m_exact = exact.colorize(gray, ab, n_global, 0, gather=True)
         sync()
@@ -259,6 +256,28 @@ def main():
             raise SystemExit("bench: the timed (unsynchronised) forward is not the reference-exact one: kmeans_events=%d, "
                              "identical to the synchronised forward: %s" % (events, same))
 
+    # ---- the per-launch profile, separately from the timed loop: `--profile-steps` forwards of the same batch on ONE stream with a
+    # hipEvent pair around every MFMA conv launch (recorded on the stream the kernels run on) and the stage marks
+    prof_steps = max(1, args.profile_steps)
+    if model is not None:
+        model.set_profiling(2)
+        single = ShardedColorizer.from_model(model, micro_batches=1, exact_fallback=False)
+        for it in range(1 + prof_steps):           # the first one settles the clocks after the synchronised check above
+            seed()
+            p_prof, m_prof = single.colorize(gray, ab, n_global, 0, gather=False)
+            sync()
+            if it == 0:
+                continue
+            nl, ms, fl = model.conv_profile()
+            conv_bytes = model.conv_profile_bytes() / max(nl, 1)
+            conv_launches += nl; conv_ms += ms; conv_fl += fl
+            for name, sms, _ in model.profile():
+                stage_ms[name] = stage_ms.get(name, 0.0) + sms
+        model.set_profiling(0)
+        lo_r, hi_r = shard_bounds(n_global, world, rank)
+        if not (torch.equal(p_prof, last[0][lo_r:hi_r]) and torch.equal(m_prof, last[1][lo_r:hi_r])):
+            raise SystemExit("bench: the profiled single-stream forward differs from the timed one")
+
     if rank == 0:
         ips = n_global * args.steps / elapsed
         out = {
@@ -271,7 +290,7 @@ def main():
                       "x2q": "f16x3 for SpixelNet; f16x2+fp8 (w_h a_h + w_l a_h in fp16, fp8(w) fp8(a_l) in one K=64 MFMA per 64 channels) for "
                              "ColorProbNet; f16+fp8x2 for HourGlass2; fp32 accumulate",
                       "mx8all": "f16+fp8x2 (fp16 main product + two fp8 e4m3 correction products), fp32 accumulate - not anchor-safe",
-                      "f16x3": "f16x3 (fp16 hi/lo split operands, fp32 accumulate)", "f16x1": "f16"}[args.precision],
+                      "f16x3": "f16x3 (fp16 hi/lo split operands, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE config 2: batch=64/GPU synthetic 256x256 L-channel, K=8 clustering anchors, "
                                    "forward only, synthetic checkpoint of the DISCO layout", "images_per_gpu": args.batch,
@@ -285,16 +304,16 @@ def main():
                 "bound": "mfma", "kernel": "conv3x3_mx_kernel (all instantiations: the f16x3, f16+fp8x2 and f16x2+fp8 arithmetics share one skeleton)",
                 "achieved": round(achieved / 1e12, 2), "peak": FP16_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic(),
-                "launches_per_step": conv_launches // max(args.steps, 1),
+                "launches_per_step": conv_launches // prof_steps,
+                "measured": "hipEvent pairs around every conv launch of %d single-stream forwards of the same batch, after the timed loop "
+                            "(the timed loop itself runs un-instrumented on %d streams)" % (prof_steps, args.micro),
                 "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_fl / max(conv_launches, 1) / 1e9, 3),
                 "algorithmic_hbm_bytes_per_launch": int(conv_bytes),
                 "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK, 4),
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
-                "power_limited_mfma_ceilings_tflops_algorithmic": {"f16x3": 439, "f16+fp8x2": 891, "f16x2+fp8": 640,
-                                                                   "source": "profiles/r02_mfma_mix.txt (registers-only loops, random operands)"},
             }
-            out["stage_ms_per_step"] = {k: round(v / args.steps, 3) for k, v in stage_ms.items()}
+            out["stage_ms_per_step"] = {k: round(v / prof_steps, 3) for k, v in stage_ms.items()}        # of the profiled single-stream forwards
             if world == 1 and not args.no_alt and args.precision == "mx8":
                 # the opt-in arithmetic on the same inputs, timed the same way (NOT `value`: DESIGN.md section 2 says why it is opt-in)
                 out["opt_in_precision"] = measure_alt("x2q", sd, gray, ab, n_global, args, sync)

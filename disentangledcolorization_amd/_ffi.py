@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DISCO_HIP_LIB") or os.path.join(_HERE, "libdisco_hip.
 
 OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
-PREC_F16X3, PREC_F16X1, PREC_MX8, PREC_MX8_ALL, PREC_X2Q = 0, 1, 2, 3, 4
+PREC_F16X3, PREC_MX8, PREC_MX8_ALL, PREC_X2Q = 0, 2, 3, 4
 PLANE_LO, PLANE_Q, PLANE_QL = 1, 2, 4
 
 
@@ -43,15 +43,14 @@ class ForwardArgs(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c_in0", C.c_int32),
                 ("c_in1", C.c_int32), ("up0", C.c_int32), ("up1", C.c_int32), ("c_out", C.c_int32),
-                ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("precision", C.c_int32),
-                ("s2d_weights", C.c_int32)]
+                ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("precision", C.c_int32)]
 
 
 class ConvMxDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c_in0", C.c_int32), ("c_in1", C.c_int32),
                 ("up0", C.c_int32), ("up1", C.c_int32), ("sexp0", C.c_int32), ("sexp1", C.c_int32), ("c_out", C.c_int32),
                 ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("out_planes", C.c_int32),
-                ("out_sexp", C.c_int32), ("out_f32", C.c_int32), ("res_planes", C.c_int32), ("x2q", C.c_int32)]
+                ("out_sexp", C.c_int32), ("out_f32", C.c_int32), ("res_planes", C.c_int32), ("x2q", C.c_int32), ("d2s", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/disco_hip.h declares
@@ -82,15 +81,14 @@ SIGNATURES = {
     "disco_profile_conv_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "disco_op_nchw_to_act": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_act_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "disco_op_conv3x3_pack_s2": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_conv3x3_pack": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_conv3x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "disco_op_conv3x3_set_probe": (_I, [_P]),
     "disco_op_act_bytes": (_I, [_I, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "disco_op_nchw_to_act_mx": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "disco_op_act_mx_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "disco_op_conv3x3_mx_pack": (_I, [_P, _I, _I, _I, _P, _P, C.POINTER(_SZ)]),
-    "disco_op_conv3x3_mx": (_I, [C.POINTER(ConvMxDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "disco_op_conv3x3_mx": (_I, [C.POINTER(ConvMxDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "disco_op_conv3x3_tapmask": (_I, [_P, _I, _I, _P]),
     "disco_diag_mfma_rate": (_I, [_I, _I, C.POINTER(C.c_double)]),
     "disco_op_deconv4x4_pack": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_deconv4x4": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),

@@ -149,12 +149,13 @@ def mark_color_hints(input_grays, target_ABs, gate_maps, kernel_size=3, base_ABs
     return out
 
 
-def fetch_data_from_rgb8(rgb_img, org_size=False, device="cuda", psize=256, return_resized=False):
-    """`fetch_data` (main/colorizer/inference.py:23-42) minus the file decode: uint8 RGB (H,W,3) array or tensor ->
-    (gray (1,1,Hp,Wp), ab (1,2,Hp,Wp), rgb (1,3,Hp,Wp), (H,W)) on the device.
-    org_size=False (the reference's default, inference.py:32-33): cv2.resize to psize x psize, INTER_LINEAR - the published
-    8-bit algorithm of opencv-python 4.6 (fixed-point coefficients; the area path for exact 2x downscales), fused with
-    /255 + RGB->Lab + split in one kernel; (H,W) is then (psize,psize).
+def fetch_data_from_rgb8(rgb_img, org_size=True, device="cuda", psize=256, return_resized=False):
+    """`fetch_data` (main/colorizer/inference.py:23-42; same default: org_size=True) minus the file decode: uint8 RGB (H,W,3) array
+    or tensor -> (gray (1,1,Hp,Wp), ab (1,2,Hp,Wp), rgb (1,3,Hp,Wp), (H,W)) on the device; (H,W) is the ORIGINAL size in both
+    branches, as in the reference (whose batch_depadding, :138-139, ignores it unless --no_resize).
+    org_size=False (what inference.py's CLI passes unless --no_resize, :32-33, :101): cv2.resize to psize x psize (the reference
+    hard-codes 256), INTER_LINEAR - the published 8-bit algorithm of opencv-python 4.6 (fixed-point coefficients; the area path
+    for exact 2x downscales), fused with /255 + RGB->Lab + split in one kernel.
     org_size=True (--no_resize, :28-31): the reference's pad-to-16 quirk (both dims get `16 - dim % 16` when either is not
     a multiple of 16), one kernel: pad + /255 + RGB->Lab + split."""
     src = torch.as_tensor(rgb_img)
@@ -172,7 +173,7 @@ def fetch_data_from_rgb8(rgb_img, org_size=False, device="cuda", psize=256, retu
             rs = torch.empty(P, P, 3, device=src.device, dtype=torch.uint8) if return_resized else None
             _ffi.check(_ffi.lib().disco_op_rgb8_resize_to_lab(_ffi.ptr(src), _ffi.ptr(rs), _ffi.ptr(gray), _ffi.ptr(ab), _ffi.ptr(rgb), 1, H, W,
                                                              P, P, _stream()))
-        return (gray, ab, rgb, (P, P), rs) if return_resized else (gray, ab, rgb, (P, P))
+        return (gray, ab, rgb, (H, W), rs) if return_resized else (gray, ab, rgb, (H, W))
     Hp, Wp = (H + 16 - H % 16, W + 16 - W % 16) if (H % 16 or W % 16) else (H, W)
     with torch.cuda.device(src.device):
         gray = torch.empty(1, 1, Hp, Wp, device=src.device)

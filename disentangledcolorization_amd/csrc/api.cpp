@@ -115,7 +115,6 @@ const int GAMUT_RUNS[20][3] = {{-90, 50, 90}, {-80, 20, 90}, {-70, 0, 90}, {-60,
 struct ConvLayer {
     int c_in = 0, c_in_pad = 0, c_out = 0;
     int kind = 0;                 // 0 plain 3x3, 1 ConvTranspose 4x4 s2 as 4-phase conv, 2 upsample+3x3 as 4-phase conv
-    bool s2d = false;             // stride-2 layer: weights packed for the space-to-depth view of the input
     bool mx = false;              // packed for conv3x3_mx_kernel (fp16 main product + fp8 corrections)
     int x2q = 0;                  // mx: packed for the kernel's f16x2 + fp8 arithmetic (sources with al8-only q planes)
     int c_out_k = 0;              // mx: output channels the kernel computes (c_out padded with zero weights so that act
@@ -234,15 +233,8 @@ int staged_h2d(disco_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipSt
     return DISCO_OK;
 }
 
-// f16x3 layers run on conv3x3_mx_kernel's skeleton (AR = 2: same arithmetic and accumulation order as conv_mfma2.hip, i.e. the
-// same bits, without that kernel's 95 spilled SGPRs); conv_mfma2.hip keeps the hi-only mode, the space-to-depth packing and the
-// timing probe.  DISCO_X3_OLD=1 routes everything through it again (A/B).
-int run_conv(const ConvArgs& ca, hipStream_t s) {
-    static const bool old_kernel = [] { const char* e = getenv("DISCO_X3_OLD"); return e && atoi(e) != 0; }();
-    if (!old_kernel && ca.precision == DISCO_PREC_F16X3 && !ca.s2d && !ca.dbg) return launch_conv3x3_x3(ca, s);
-    return launch_conv3x3_v2(ca, s);
-}
-unsigned long long* g_conv_probe = nullptr;   // timing probe buffer for disco_op_conv3x3 (tools/conv_timeline.py)
+// f16x3 layers run on conv3x3_mx_kernel (AR = 2)
+int run_conv(const ConvArgs& ca, hipStream_t s) { return launch_conv3x3_x3(ca, s); }
 
 // effective conv weight (c_out, c_in, 3, 3): plain `.weight`, or spectral-norm weight_orig / (u . (W v))
 std::vector<float> eff_weight(disco_ctx* c, const std::string& key) {
@@ -352,23 +344,11 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
         return DISCO_OK;
     }
     L.c_in_pad = c_in_pad_override ? c_in_pad_override : round_up(ci, 16);
-    std::vector<char> packed;
-    // Measured on MI355X (profiles/r01_conv_s2d_timeline.txt): the space-to-depth path has the stride-1 LDS footprint and
-    // MFMA/LDS ratio, but each phase chunk uses half of every 128-byte line it fetches, and the stride-2 layers are bound
-    // by L2->LDS line traffic (input re-read per N tile), not by LDS reads: 0.66 vs 0.65 ms on 64->128@256^2, 0.56 vs
-    // 0.53 ms on 256->512@64^2.  The forward therefore keeps the plain stride-2 tiles; the packing stays available
-    // through disco_op_conv3x3_pack_s2.
-    static const bool kUseS2D = [] { const char* e = getenv("DISCO_S2D"); return e && atoi(e) != 0; }();
-    if (kUseS2D && stride2 && !ci_map) {     // every stride-2 layer of the path sees even input sizes (H, W multiples of 16)
-        L.s2d = true;
-        std::vector<float> w4((size_t)co * 4 * L.c_in_pad * 9);
-        conv3x3_s2d_weights_host(w.data(), co, ci, L.c_in_pad, w4.data());
-        packed.resize(conv3x3_packed_bytes(co, 4 * L.c_in_pad));
-        conv3x3_pack_host(w4.data(), co, 4 * L.c_in_pad, nullptr, 4 * L.c_in_pad, packed.data());
-    } else {
-        packed.resize(conv3x3_packed_bytes(co, L.c_in_pad));
-        conv3x3_pack_host(w.data(), co, ci, ci_map ? ci_map->data() : nullptr, L.c_in_pad, packed.data());
-    }
+    // (Stride-2 layers keep the plain stride-2 tiles: a space-to-depth packing was measured in round 1 - same LDS footprint and MFMA/LDS
+    // ratio as stride 1, but each phase chunk uses half of every 128-byte line it fetches and these layers are bound by L2->LDS line
+    // traffic: 0.66 vs 0.65 ms on 64->128@256^2, profiles/r01_conv_s2d_timeline.txt - and removed in round 3.)
+    std::vector<char> packed(conv3x3_packed_bytes(co, L.c_in_pad));
+    conv3x3_pack_host(w.data(), co, ci, ci_map ? ci_map->data() : nullptr, L.c_in_pad, packed.data());
     rc = upload(c, packed.data(), packed.size(), (void**)&L.d_w);
     if (rc) return rc;
     if ((rc = upload_vec(c, bias, &L.d_bias))) return rc;
@@ -632,17 +612,13 @@ struct Plan {
             ca.nsrc = 1;
             if (in1) { ca.src[1] = {in1->p, (long)in1->plane, in1->c, in1->h, in1->w, up1}; ca.nsrc = 2; }
             ca.n = in0.n; ca.h_in = hin; ca.w_in = win; ca.c_in = L.c_in_pad;
-            if (L.s2d) {
-                if (stride != 2 || in1 || up0 || (hin & 1) || (win & 1)) { set_error("conv %s: packed for stride 2 on an even-sized plain source", key.c_str()); rc = DISCO_ESHAPE; return out; }
-                ca.s2d = 1; ca.c_in = 4 * L.c_in_pad;
-            }
             ca.h_out = ho; ca.w_out = wo; ca.stride = stride;
             ca.w = L.d_w; ca.tapmask = L.d_tapmask; ca.c_out = L.c_out; ca.c_out_pad = L.c_out;
             ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
             ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
             ca.out = out.p; ca.out_plane = (long)out.plane;
             ca.out_f32 = out_f32; ca.d2s_c = d2s ? L.c_out / 4 : 0; ca.softmax = softmax ? 1 : 0;
-            ca.act = actc; ca.slope = slope; ca.precision = c->opt.precision == DISCO_PREC_F16X1 ? DISCO_PREC_F16X1 : DISCO_PREC_F16X3;
+            ca.act = actc; ca.slope = slope; ca.precision = DISCO_PREC_F16X3;
             rc = run_conv(ca, s);
             if (!out_f32) calibrate(key, out, [] {});     // calibration pass: records max |x| (fp16 range guard) for f16x3 layers too
         }
@@ -657,7 +633,7 @@ struct Plan {
             double bytes = (L.x2q ? 3.0 : 4.0) * in0.n * ((double)in0.c * in0.h * in0.w + (in1 ? (double)in1->c * in1->h * in1->w : 0.0));
             bytes += bpe_out * in0.n * (double)(out_f32 ? L.c_real : co_t) * ho * wo;
             if (res) bytes += 4.0 * in0.n * (double)co_t * ho * wo;
-            bytes += L.mx ? (double)conv_mx_packed_bytes(co_t, L.c_in_pad, L.x2q) : (double)conv3x3_packed_bytes(L.c_out, L.s2d ? 4 * L.c_in_pad : L.c_in_pad);
+            bytes += L.mx ? (double)conv_mx_packed_bytes(co_t, L.c_in_pad, L.x2q) : (double)conv3x3_packed_bytes(L.c_out, L.c_in_pad);
             c->conv_prof.push_back({e0, e1, 2.0 * taps * L.c_in * (double)ho * wo * in0.n, key, bytes});
         }
         return out;
@@ -997,7 +973,7 @@ int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (!opt || !out) { set_error("null argument"); return DISCO_EINVAL; }
     if (opt->sp_size != 16) { set_error("sp_size %d unsupported (16 only, inference.py:146)", opt->sp_size); return DISCO_EUNSUPPORTED; }
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
-    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_F16X1 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL && opt->precision != DISCO_PREC_X2Q) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
+    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL && opt->precision != DISCO_PREC_X2Q) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
     if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }
     if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("segnet_only context takes no colorizer flags"); return DISCO_EINVAL; }
     int ndev = 0;
@@ -1287,20 +1263,6 @@ int disco_op_conv3x3_pack(const float* h_w, int c_out, int c_in, void* d_packed,
     return DISCO_OK;
 }
 
-int disco_op_conv3x3_pack_s2(const float* h_w, int c_out, int c_in, void* d_packed, size_t* bytes) {
-    if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }
-    const int cpad = round_up(c_in, 16);
-    *bytes = conv3x3_packed_bytes(c_out, 4 * cpad);
-    if (!d_packed) return DISCO_OK;
-    if (!h_w) { set_error("null weight"); return DISCO_EINVAL; }
-    std::vector<float> w4((size_t)c_out * 4 * cpad * 9);
-    conv3x3_s2d_weights_host(h_w, c_out, c_in, cpad, w4.data());
-    std::vector<char> packed(*bytes);
-    conv3x3_pack_host(w4.data(), c_out, 4 * cpad, nullptr, 4 * cpad, packed.data());
-    DISCO_HIP_CHECK(hipMemcpy(d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice));
-    return DISCO_OK;
-}
-
 int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d_src1, const void* d_packed_w,
                      const float* d_bias, const float* d_bn_scale, const float* d_bn_shift, const void* d_res, void* d_out,
                      void* stream) {
@@ -1324,8 +1286,7 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
     ca.out = (f16*)d_out; ca.out_plane = (long)d->n * ca.h_out * ca.w_out * d->c_out;
     ca.res = (const f16*)d_res; ca.res_plane = ca.out_plane;
     ca.act = d->act; ca.slope = d->slope; ca.precision = d->precision;
-    if (d->s2d_weights) { ca.s2d = 1; ca.c_in = 4 * d->c_in0; }
-    ca.dbg = g_conv_probe;
+    if (d->precision != DISCO_PREC_F16X3) { set_error("conv3x3 op: precision %d (the f16x3 arithmetic only; the fp16+fp8 ones go through disco_op_conv3x3_mx)", d->precision); return DISCO_EINVAL; }
     return run_conv(ca, (hipStream_t)stream);
 }
 
@@ -1378,7 +1339,7 @@ int disco_op_conv3x3_mx_pack(const float* h_w, int c_out, int c_in, int x2q, voi
 
 int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const void* d_src1, const void* d_packed_w, const int32_t* d_wexp,
                         const float* d_bias, const float* d_bn_scale, const float* d_bn_shift, const void* d_res, void* d_out,
-                        uint32_t* d_sat, void* stream) {
+                        uint32_t* d_sat, const uint32_t* d_tapmask, void* stream) {
     if (!d || !d_src0 || !d_packed_w || !d_wexp || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
     if (!positive("conv3x3_mx", {d->n, d->h_in, d->w_in, d->c_in0, d->c_out}) || d->c_in1 < 0) { if (d->c_in1 < 0) set_error("conv3x3_mx: c_in1 %d", d->c_in1); return DISCO_ESHAPE; }
     ConvMxArgs ca{};
@@ -1400,20 +1361,32 @@ int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const v
     ca.stride = d->stride; ca.h_out = (d->h_in - 1) / d->stride + 1; ca.w_out = (d->w_in - 1) / d->stride + 1;
     ca.w = d_packed_w; ca.wexp = d_wexp; ca.c_out = d->c_out; ca.c_out_pad = d->c_out;
     ca.bias = d_bias; ca.bn_scale = d_bn_scale; ca.bn_shift = d_bn_shift;
+    if (d->d2s && (d->out_f32 || d->stride != 1 || d->c_out % 128)) { set_error("conv3x3_mx op: depth-to-space needs an activation output, stride 1, c_out = 4 C with C a multiple of 32"); return DISCO_ESHAPE; }
     if (d->out_f32) ca.out_f32 = (float*)d_out;
     else {
-        const Act o = flat_act(d_out, d->n, d->c_out, ca.h_out, ca.w_out, d->out_planes, d->out_sexp);
+        const Act o = d->d2s ? flat_act(d_out, d->n, d->c_out / 4, 2 * ca.h_out, 2 * ca.w_out, d->out_planes, d->out_sexp)
+                             : flat_act(d_out, d->n, d->c_out, ca.h_out, ca.w_out, d->out_planes, d->out_sexp);
+        if (d->d2s) ca.d2s_c = d->c_out / 4;
         ca.out = o.p; ca.out_plane = (long)o.plane; ca.out_q_off = o.q_off; ca.out_sexp = d->out_sexp; ca.out_q_kind = o.q_kind;
     }
+    ca.tapmask = d_tapmask;
     if (d_res) {
-        const Act rr = flat_act(d_res, d->n, d->c_out, ca.h_out, ca.w_out, d->res_planes, 0);
+        const Act rr = d->d2s ? flat_act(d_res, d->n, d->c_out / 4, 2 * ca.h_out, 2 * ca.w_out, d->res_planes, 0)
+                              : flat_act(d_res, d->n, d->c_out, ca.h_out, ca.w_out, d->res_planes, 0);
         ca.res = rr.p; ca.res_plane = (long)rr.plane;
     }
     ca.act = d->act; ca.slope = d->slope; ca.sat = d_sat; ca.x2q = d->x2q ? 1 : 0;
     return launch_conv3x3_mx(ca, (hipStream_t)stream);
 }
 
-int disco_op_conv3x3_set_probe(void* d_buf) { g_conv_probe = (unsigned long long*)d_buf; return DISCO_OK; }
+
+int disco_op_conv3x3_tapmask(const float* h_w, int c_out, int c_in, uint32_t* d_mask) {
+    if (!h_w || !d_mask || c_out <= 0 || c_in <= 0) { set_error("conv3x3_tapmask: bad argument"); return DISCO_EINVAL; }
+    std::vector<uint32_t> mask(cdiv(c_out, 32));
+    conv3x3_tapmask_host(h_w, c_out, c_in, mask.data());
+    DISCO_HIP_CHECK(hipMemcpy(d_mask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    return DISCO_OK;
+}
 
 int disco_diag_mfma_rate(int mode, int iters, double* tflops) { return diag_mfma_rate(mode, iters, tflops); }
 
@@ -1442,7 +1415,8 @@ int disco_op_deconv4x4(const void* d_src, const void* d_packed_w, const float* d
     ca.w = (const f16*)d_packed_w; ca.c_out = 4 * c_out; ca.c_out_pad = 4 * c_out; ca.bias = d_bias;
     ca.out = (f16*)d_out; ca.out_plane = (long)n * 4 * h_in * w_in * c_out; ca.d2s_c = c_out;
     ca.act = DISCO_ACT_LRELU; ca.slope = slope; ca.precision = precision;
-    return launch_conv3x3_v2(ca, (hipStream_t)stream);
+    if (precision != DISCO_PREC_F16X3) { set_error("deconv4x4 op: precision %d", precision); return DISCO_EINVAL; }
+    return run_conv(ca, (hipStream_t)stream);      // the forward's own path: conv3x3_mx_kernel AR = 2 with the depth-to-space epilogue
 }
 
 int disco_op_poolfeat(const float* d_feat, const float* d_prob, float* d_pooled, float* d_conf, float* d_sizes, int n, int ch,

@@ -97,21 +97,26 @@ __global__ void rgb8_to_lab_kernel(const unsigned char* __restrict__ src, float*
 // uint8 image, then /255 and RGB->Lab.  cv2 is a third-party dependency (opencv-python==4.6.0.66, environment.yaml:89) that is
 // not available offline; this restates its published algorithm for 8-bit images (modules/imgproc/src/resize.cpp):
 //   * exact 2x downscale in both directions: INTER_LINEAR is replaced by the area path, dst = (a + b + c + d + 2) >> 2;
-//   * otherwise, per axis: f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s, clamped to the image (f = 0 at the borders);
+//   * otherwise, per axis: f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s; x: clamped to the image (f = 0 at the borders);
+//     y: f is kept and the two ROW indices are clipped instead (the invoker's clip(sy + k, 0, ssize.height)): at the top / bottom border
+//     both rows are the same row, still weighted b0 and b1 - one LSB less than a single weight of 2048 in places (vertical upscales);
 //     coefficients (1-f, f) are rounded to 11-bit fixed point (x 2048, round half to even); the horizontal pass keeps
 //     S[s] a0 + S[s+1] a1 as a 32-bit integer; the vertical pass is
 //     dst = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2        (VResizeLinear<uchar,...>, bit-exact integer math)
 // with scale = 1 / (dst / src) in double precision.  One thread per destination pixel; the Lab conversion is fused in.
 struct ResizeAxis { int s0, s1; int c0, c1; };
+template <bool CLAMP_F>
 __device__ inline ResizeAxis resize_axis(int d, int n_src, int n_dst) {
     const double scale = 1.0 / ((double)n_dst / (double)n_src);
     float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
-    if (s < 0) { f = 0.f; s = 0; }
-    if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    if (CLAMP_F) {          // the x loop of cv::resize
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    }
     ResizeAxis a;
-    a.s0 = s; a.s1 = s + 1 < n_src ? s + 1 : n_src - 1;
+    a.s0 = min(max(s, 0), n_src - 1); a.s1 = min(max(s + 1, 0), n_src - 1);
     a.c0 = __float2int_rn((1.f - f) * 2048.f);
     a.c1 = __float2int_rn(f * 2048.f);
     return a;
@@ -132,7 +137,7 @@ __global__ void rgb8_resize_to_lab_kernel(const unsigned char* __restrict__ src,
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[k] = (q[k] + q[3 + k] + q[(long)W * 3 + k] + q[(long)W * 3 + 3 + k] + 2) >> 2;
         } else {
-            const ResizeAxis ax = resize_axis(x, W, Wo), ay = resize_axis(y, H, Ho);
+            const ResizeAxis ax = resize_axis<true>(x, W, Wo), ay = resize_axis<false>(y, H, Ho);
             const unsigned char* r0 = im + (long)ay.s0 * W * 3;
             const unsigned char* r1 = im + (long)ay.s1 * W * 3;
 #pragma unroll

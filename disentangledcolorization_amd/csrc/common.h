@@ -146,8 +146,6 @@ struct ConvArgs {
     uint32_t src_bytes[2];  // filled by the launcher: bytes addressable through each source's buffer descriptor
     uint32_t w_bytes;       // ... and through the packed-weight descriptor
     int softmax;        // fp32 NCHW output only: softmax over the c_out (<= 32) channels after the epilogue
-    int s2d;            // stride-2 layer whose weights were packed for the space-to-depth view (conv3x3_s2d_weights_host)
-    unsigned long long* dbg;  // timing probe (tools/conv_timeline.py): per-chunk s_memtime stamps of workgroup 0, or null
 };
 
 // ---- conv3x3, fp16 main product + two fp8 (e4m3, K = 64) correction products (conv_mx.hip) ----------------------------
@@ -194,7 +192,7 @@ size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int x2q = 0);
 // h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map as in conv3x3_pack_host; c_in_pad multiple of 32 (x2q: 64); h_wexp: cdiv(c_out,32)*32 ints
 void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int x2q = 0);
 int launch_conv3x3_mx(const ConvMxArgs& a, hipStream_t s);
-// the f16x3 layer described by a ConvArgs (no s2d, no probe) on conv3x3_mx_kernel's skeleton; results bit-identical to launch_conv3x3_v2
+// the f16x3 layer described by a ConvArgs on conv3x3_mx_kernel (AR = 2)
 int launch_conv3x3_x3(const ConvArgs& a, hipStream_t s);
 unsigned char fp8_e4m3_from_float(float x);      // round to nearest even, saturating to +-448
 float fp8_e4m3_to_float(unsigned char v);
@@ -210,16 +208,12 @@ constexpr int DISCO_MAX_DEVICES = 64;
 // ordinal of the calling thread's current HIP device, clamped into [0, DISCO_MAX_DEVICES) (per-device one-time setup tables)
 inline int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0; return d % DISCO_MAX_DEVICES; }
 int diag_mfma_rate(int mode, int iters, double* tflops);   // diag.hip
-int launch_conv3x3_v2(const ConvArgs& a, hipStream_t s);   // conv_mfma2.hip: LDS-DMA double-buffered pipeline
 // ConvTranspose2d(4,s2,p1) weight (c_in,c_out,4,4) -> equivalent 3x3 conv weight (4*c_out, c_in, 3, 3), phase-major
 void deconv_as_conv3x3_host(const float* h_w_iohw, int c_in, int c_out, float* h_w_oihw);
 // nearest-x2-upsample followed by a 3x3 conv (c_out,c_in,3,3) -> 4-phase 3x3 conv on the low-res input
 // (4*c_out, c_in, 3, 3), phase-major, taps pre-summed (sub-pixel decomposition; 4 non-zero taps per phase)
 void upconv_as_conv3x3_host(const float* h_w_oihw, int c_in, int c_out, float* h_w4_oihw);
 // bit t of mask[nb] set iff any weight of tap t is non-zero in 32-cout block nb
-// stride-2 3x3 weights (c_out,c_in,3,3) -> the equivalent stride-1 weights (c_out, 4*c_in_pad, 3, 3) over the space-to-depth
-// view of the input: channel (cb*4 + py*2+px)*16 + j = channel cb*16+j of sub-pixel phase (py,px); c_in_pad multiple of 16
-void conv3x3_s2d_weights_host(const float* h_w, int c_out, int c_in, int c_in_pad, float* out);
 void conv3x3_tapmask_host(const float* h_w, int c_out, int c_in, uint32_t* mask /* cdiv(c_out,32) */);
 
 // ---- direct (VALU) convs ------------------------------------------------------------------------

@@ -247,7 +247,7 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
 
 int launch_conv3x3_x3(const ConvArgs& c, hipStream_t s) {
     ConvMxArgs a{};
-    if (c.nsrc < 1 || c.nsrc > 2 || c.s2d) { set_error("conv3x3_x3: %d sources / s2d %d", c.nsrc, c.s2d); return DISCO_EINVAL; }
+    if (c.nsrc < 1 || c.nsrc > 2) { set_error("conv3x3_x3: %d sources", c.nsrc); return DISCO_EINVAL; }
     int csum = 0;
     for (int i = 0; i < c.nsrc; ++i) {
         const ConvSrc& sp = c.src[i];

@@ -65,7 +65,12 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 // a register in the soffset field") - on this part it exists with one, and these stores all have one.  An asm block is the only way
 // to keep the scheduler from moving a VALU instruction into the gap.
 __device__ __forceinline__ void buffer_store_b128(i32x4 d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(d), "v"(voff), "s"(r), "s"(soff) : "memory");
+    // ... and five wait states in FRONT of it: a VMEM instruction that reads an SGPR (descriptor, soffset) written by a VALU instruction
+    // needs 5 wait states, the compiler's hazard recogniser does not look into an asm block, and in the instantiations that spill SGPRs
+    // the descriptor / offset are reloaded with v_readlane_b32 right in front of the store.  Found in round 3 (tools/conv_determinism_probe.py):
+    // the masked depth-to-space instantiation of the f16x2+fp8 arithmetic (116 spilled SGPRs) wrote its hi plane through stale offsets,
+    // differently from run to run.
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(d), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 
 // four floats -> four fp8 e4m3 bytes of (x / scale), scale a power of two: ONE v_cvt_scalef32_pk_fp8_f32 per pair does the scaling

@@ -33,9 +33,9 @@ MAX_ACT_BYTES = (1 << 32) - (1 << 20)
 
 
 # conv arithmetic per stack (include/disco_hip.h DISCO_PREC_*): "mx8" = f16x3 on SpixelNet + ColorProbNet (the anchor-deciding
-# stacks), f16+fp8x2 on HourGlass2; "x2q" = additionally the ColorProbNet on f16x2+fp8; "f16x3" everywhere; "mx8all" / "f16x1":
+# stacks), f16+fp8x2 on HourGlass2; "x2q" = additionally the ColorProbNet on f16x2+fp8; "f16x3" everywhere; "mx8all":
 # measurements only
-_PRECISIONS = {"f16x3": _ffi.PREC_F16X3, "f16x1": _ffi.PREC_F16X1, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}
+_PRECISIONS = {"f16x3": _ffi.PREC_F16X3, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}
 DEFAULT_PRECISION = "mx8"
 
 

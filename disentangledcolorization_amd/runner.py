@@ -59,7 +59,7 @@ class ShardedColorizer:
     as long as no empty-cluster event occurs (bench.py checks that after its timed loop)."""
 
     def __init__(self, forward_fn, n_clusters=8, random_hint=False, sp_size=16, group=None, micro_batches=1,
-                 exact_fallback=True, max_fallback=None):
+                 exact_fallback=True, max_fallback=None, force_gather=False):
         self.forward_fn = forward_fn
         self.k, self.random_hint, self.sp = n_clusters, random_hint, sp_size
         self.group = group
@@ -68,20 +68,25 @@ class ShardedColorizer:
         self.micro = max(1, int(micro_batches))
         self.exact_fallback = bool(exact_fallback)
         self.max_fallback = int(max_fallback) if max_fallback else 20 * n_clusters
+        # force_gather: run the collectives even at world size 1 when a process group exists (the only way to exercise the RCCL
+        # path - packed send buffer, async work handle, result views - on a single-GPU box: tests/test_gpu_dist.py via bench.py)
+        self.force_gather = bool(force_gather)
         self._streams = None
         self._pending = []          # outstanding asynchronous all-gathers (async_gather=True): (work, finish callback)
         self.last_events = None     # per-image empty-cluster draws of the GLOBAL batch of the latest exact forward
 
     @classmethod
-    def from_model(cls, model, group=None, micro_batches=1, exact_fallback=None):
+    def from_model(cls, model, group=None, micro_batches=1, exact_fallback=None, force_gather=False):
         fn = lambda g, a, T, idx, pos, fs, fb, want: model.forward_once(g, a, True, T, idx, pos, fs, fb, want)
         exact = model.sync_kmeans_events if exact_fallback is None else exact_fallback
-        return cls(fn, model.hint_num, model.random_hint, model.sp_size, group, micro_batches, exact, model.max_fallback())
+        return cls(fn, model.hint_num, model.random_hint, model.sp_size, group, micro_batches, exact, model.max_fallback(), force_gather)
 
     # ---- local forward (optionally as micro-batches on separate streams) ----------------------------------------
     def _forward_local(self, gray, ab, sampled_T, idx, pos, fstream, fbases, want):
         n = gray.shape[0]
-        m = min(self.micro, n)
+        # a forward that reports its empty-cluster events synchronises the host before it returns, so micro-batches would
+        # run one after the other anyway: the exact mode issues the shard as one batch
+        m = 1 if want else min(self.micro, n)
         if m <= 1 or not gray.is_cuda:
             return self.forward_fn(gray, ab, sampled_T, idx, pos, fstream, fbases, want)
         if self._streams is None or len(self._streams) < m:
@@ -110,7 +115,7 @@ class ShardedColorizer:
 
     def _exchange_events(self, ev_local, n_global, world, rank, checksum, device):
         """Per-image event counts of the global batch on every rank (+ a check that all ranks made the same draws)."""
-        if world == 1 and not (os.environ.get("DISCO_FORCE_GATHER") == "1" and dist.is_available() and dist.is_initialized()):
+        if world == 1 and not (self.force_gather and dist.is_available() and dist.is_initialized()):
             return ev_local.astype(np.int64)
         counts = [shard_bounds(n_global, world, r)[1] - shard_bounds(n_global, world, r)[0] for r in range(world)]
         mx = max(counts)
@@ -159,22 +164,38 @@ class ShardedColorizer:
             stream = peek_randint(l, 2 * MF)
             check = zlib.crc32(idx.tobytes()) ^ zlib.crc32(stream[:MF].tobytes())
             bases = np.zeros(n_global, np.int64)
+            out, ev = run(stream, bases[lo:hi], True)
             for _ in range(n_global + 1):
-                while len(stream) < int(bases.max()) + MF:
-                    stream = peek_randint(l, 2 * len(stream))
-                out, ev = run(stream, bases[lo:hi], True)
                 events = self._exchange_events(ev, n_global, world, rank, check, gray_local.device)
                 new_bases = np.concatenate(([0], np.cumsum(events)[:-1])).astype(np.int64)
-                if not np.any((events > 0) & (new_bases != bases)):
+                redo = (events > 0) & (new_bases != bases)      # images that drew fallback rows from the wrong offset of the stream
+                if not np.any(redo):
                     break
                 bases = new_bases
+                while len(stream) < int(bases.max()) + MF:
+                    stream = peek_randint(l, 2 * len(stream))
+                # only those images run again (an image's result does not depend on the batch it is part of); every rank takes
+                # part in the next exchange, whether it had anything to redo or not
+                sel = np.nonzero(redo[lo:hi])[0]
+                if len(sel):
+                    ts = torch.as_tensor(sel, device=gray_local.device)
+                    o2, e2 = self._forward_local(gray_local[ts], ab_local[ts], sampled_T, idx[lo:hi][sel], None, stream, bases[lo:hi][sel], True)
+                    rows = (ts[:, None] * rep + torch.arange(rep, device=ts.device)[None, :]).reshape(-1)
+                    fixed = []
+                    for k in range(6):      # outputs 1, 2, 4 carry n*rep rows (image-major); 0 has n rows; 3, 5 may be expanded views
+                        t = out[k]
+                        if t is None or o2[k] is None:
+                            fixed.append(t); continue
+                        t = t.clone() if t._base is not None or not t.is_contiguous() else t
+                        t[rows if t.shape[0] == n_loc * rep else ts] = o2[k]
+                        fixed.append(t)
+                    out = tuple(fixed)
+                    ev = ev.copy(); ev[sel] = e2
             for _ in range(int(events.sum())):      # every rank consumes what the reference's single process would have
                 torch.randint(l, (1,))
             self.last_events = events
         pred, mask = out[2], out[5]
-        # world size 1 normally skips the collective; DISCO_FORCE_GATHER=1 runs it anyway when a process group exists (the only
-        # way to exercise the RCCL path - packed send buffer, async work handle, unpack - on a single-GPU box: tests/test_gpu_dist.py)
-        force = os.environ.get("DISCO_FORCE_GATHER") == "1" and dist.is_available() and dist.is_initialized()
+        force = self.force_gather and dist.is_available() and dist.is_initialized()    # world size 1 normally skips the collective
         if not gather or (world == 1 and not force):
             return pred, mask
         return self._all_gather_packed(pred, mask, n_global, world, rank, rep, async_gather)
@@ -188,32 +209,76 @@ class ShardedColorizer:
         self._pending = []
 
     def _all_gather_packed(self, pred, mask, n_global, world, rank, rep, async_op=False):
-        """One collective for both results: per output row [pred (2HW) | hint_mask (hw)], shards padded to the largest."""
+        """One collective for both results: per output row [pred (2HW) | hint_mask (hw)].  Equal shards (the bench, any batch
+        that divides by the world size): the collective gathers straight into the result - pred_colors and hint_mask are
+        returned as strided VIEWS of the receive buffer (row stride 2HW + hw), no unpack pass; call .contiguous() where a
+        dense tensor is needed.  Ragged shards are padded to the largest and unpacked."""
         counts = [(shard_bounds(n_global, world, r)[1] - shard_bounds(n_global, world, r)[0]) * rep for r in range(world)]
         mx = max(counts)
         ps, ms = tuple(pred.shape[1:]), tuple(mask.shape[1:])
         np_, nm = int(np.prod(ps)), int(np.prod(ms))
-        send = pred.new_zeros((mx, np_ + nm))
         rows = pred.shape[0]
+        equal = min(counts) == mx
+        send = pred.new_empty((mx, np_ + nm)) if equal else pred.new_zeros((mx, np_ + nm))
         if rows:
             send[:rows, :np_] = pred.reshape(rows, np_)
             send[:rows, np_:] = mask.reshape(rows, nm)
         recv = pred.new_empty((world * mx, np_ + nm))
         total = sum(counts)
-        pred_g = pred.new_empty((total,) + ps)
-        mask_g = mask.new_empty((total,) + ms)
+        if equal:
+            pred_g = recv[:, :np_].unflatten(1, ps)
+            mask_g = recv[:, np_:].unflatten(1, ms)
+            finish = None
+        else:
+            pred_g = pred.new_empty((total,) + ps)
+            mask_g = mask.new_empty((total,) + ms)
 
-        def finish():
-            o = 0
-            for r in range(world):
-                blk = recv[r * mx: r * mx + counts[r]]
-                pred_g[o: o + counts[r]] = blk[:, :np_].reshape((counts[r],) + ps)
-                mask_g[o: o + counts[r]] = blk[:, np_:].reshape((counts[r],) + ms)
-                o += counts[r]
+            def finish():
+                o = 0
+                for r in range(world):
+                    blk = recv[r * mx: r * mx + counts[r]]
+                    pred_g[o: o + counts[r]] = blk[:, :np_].reshape((counts[r],) + ps)
+                    mask_g[o: o + counts[r]] = blk[:, np_:].reshape((counts[r],) + ms)
+                    o += counts[r]
 
         work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=async_op)
         if async_op:
             self._pending.append((work, finish))
-        else:
+        elif finish is not None:
             finish()
         return pred_g, mask_g
+
+
+def colorize_mixed(model, grays, abs_=None, sampled_T=0, max_batch=64):
+    """BASELINE config 4 (`--no_resize`, mixed 512x512 / 768x512 ...): a LIST of (1,1,H,W) / (1,H,W) gray images of different
+    sizes (H, W multiples of 16: fetch_data pads, inference.py:27-31) -> list of the model's 6-tuples, one per image, in input
+    order.  The reference loops over files one at a time (inference.py:93-109); here images of equal shape run as one batch
+    (at most `max_batch` at a time).  Host-side draws follow the reference's order: the k-means rows of image i are drawn i-th
+    from NumPy's global state, so the result equals the per-file loop's as long as no empty-cluster fallback draw occurs
+    (those come from torch's global stream in file order; the grouped batches consume them in group order)."""
+    n = len(grays)
+    g4 = [g.reshape(1, 1, g.shape[-2], g.shape[-1]) for g in grays]
+    a4 = [None if abs_ is None else abs_[i].reshape(1, 2, g4[i].shape[2], g4[i].shape[3]) for i in range(n)]
+    sp, K = model.sp_size, model.hint_num
+    # draws in input order, exactly as the per-file loop would make them
+    idx, pos = [], []
+    for g in g4:
+        l = (g.shape[2] // sp) * (g.shape[3] // sp)
+        i1, p1 = global_draws(1, l, K, model.random_hint)
+        idx.append(i1); pos.append(p1)
+    groups = {}
+    for i, g in enumerate(g4):
+        groups.setdefault((g.shape[2], g.shape[3]), []).append(i)
+    results = [None] * n
+    rep = 3 if sampled_T > 0 else 1
+    for (H, W), members in groups.items():
+        for c0 in range(0, len(members), max_batch):
+            sel = members[c0: c0 + max_batch]
+            gray = torch.cat([g4[i] for i in sel], 0)
+            ab = torch.zeros(len(sel), 2, H, W, device=gray.device) if abs_ is None else torch.cat([a4[i] for i in sel], 0)
+            out = model.forward_with_draws(gray, ab, True, sampled_T,
+                                           None if model.random_hint else np.concatenate([idx[i] for i in sel]),
+                                           np.concatenate([pos[i] for i in sel]) if model.random_hint else None)
+            for j, i in enumerate(sel):
+                results[i] = tuple(None if t is None else (t[j * rep:(j + 1) * rep] if t.shape[0] == len(sel) * rep else t[j:j + 1]) for t in out)
+    return results

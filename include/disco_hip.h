@@ -24,8 +24,7 @@
  *     disco_last_error() gives a thread-local message for the last failing call.
  *   - threading: launchers are asynchronous on the given hipStream_t (passed as void*) and re-entrant across
  *     streams/devices; the only process-global state is one-time per-device setup (function attributes, the
- *     op-level gamut table: std::call_once / mutex) and the diagnostic probe pointer of
- *     disco_op_conv3x3_set_probe (a debugging aid: set it from one thread, before launching).  One context per device.
+ *     op-level gamut table: std::call_once / mutex).  One context per device.
  *     No hidden host synchronisation except in disco_forward's k-means fallback bookkeeping
  *     (documented there) and disco_sync.
  *   - host-side randomness (k-means initial rows, empty-cluster fallback rows, random hints) is
@@ -41,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 5
+#define DISCO_ABI_VERSION 6
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -61,7 +60,8 @@ typedef struct disco_ctx disco_ctx;
 
 /* conv precision modes */
 #define DISCO_PREC_F16X3 0 /* fp16 hi/lo split operands, 3 MFMA products, fp32 accumulate */
-#define DISCO_PREC_F16X1 1 /* fp16 hi operands only */
+/* (1 was DISCO_PREC_F16X1, "fp16 hi operands only", a measurement mode of rounds 1-2 that ran on round 1's conv kernel; removed
+ *  with that kernel in ABI version 6: disco_create rejects it) */
 #define DISCO_PREC_MX8 2   /* the default: the enhanceNet (HourGlass2, everything downstream of the anchors) computes
                               w a ~= w_h a_h + fp8(w - w_h) fp8(a) + fp8(w) fp8(a - a_h): an fp16 main product plus two fp8
                               (e4m3) correction products in one K=64 MFMA (csrc/conv_mx.hip).  Its activations carry an fp16
@@ -192,18 +192,12 @@ typedef struct disco_conv_desc {
     int32_t c_out, stride;     /* 3x3, pad 1, stride 1 or 2 */
     int32_t act;               /* DISCO_ACT_* applied after bias (+residual) */
     float slope;
-    int32_t precision;         /* DISCO_PREC_* */
-    int32_t s2d_weights;       /* 1: d_packed_w came from disco_op_conv3x3_pack_s2 (stride 2, one plain source, even sizes) */
+    int32_t precision;         /* DISCO_PREC_F16X3 (this entry point runs the f16x3 arithmetic; the others: disco_op_conv3x3_mx) */
 } disco_conv_desc;
 
 /* Pack an effective fp32 OIHW 3x3 weight (host) for the MFMA kernel; returns bytes needed when
  * d_packed == NULL.  c_in = c_in0 + c_in1 (each a multiple of 16, or c_in0 arbitrary when c_in1 = 0). */
 int disco_op_conv3x3_pack(const float *h_w_oihw, int c_out, int c_in, void *d_packed, size_t *bytes);
-/* The same for a STRIDE-2 layer run over the space-to-depth view of its input (the fast path for stride 2: the four
- * sub-pixel phases of the input become 4x the channels of a stride-1 conv with 1/2/2/4 live taps, so the LDS halo
- * tile has the stride-1 footprint); 4x the bytes of disco_op_conv3x3_pack.  Use with disco_conv_desc.s2d_weights. */
-int disco_op_conv3x3_pack_s2(const float *h_w_oihw, int c_out, int c_in, void *d_packed, size_t *bytes);
-
 /* out = bn(act(conv3x3(cat(src0,src1)) + bias [+ res]));  bias/bn_scale/bn_shift: device fp32 (c_out) or NULL */
 int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d_src1, const void *d_packed_w,
                      const float *d_bias, const float *d_bn_scale, const float *d_bn_shift, const void *d_res,
@@ -236,18 +230,19 @@ typedef struct disco_conv_mx_desc {
     int32_t res_planes;        /* DISCO_PLANE_* bits of the residual buffer (its lo plane is used when present) */
     int32_t x2q;               /* 1: the f16x2 + fp8 arithmetic: one source with DISCO_PLANE_QL planes, c_in0 a multiple of 64,
                                   weights packed with x2q = 1 */
+    int32_t d2s;               /* 1: depth-to-space epilogue (the sub-pixel up-convs / transposed convs of the forward): c_out = 4 C
+                                  phase-major output channels, channel ph*C + c of input pixel (y, x) goes to channel c of pixel
+                                  (2y + ph/2, 2x + ph%2) of an (n, C, 2h, 2w) activation buffer; C a multiple of 32; stride 1 */
 } disco_conv_mx_desc;
 /* d_packed == NULL: only *bytes.  d_wexp: device int32 [round_up(c_out, 32)], the per-output-channel weight scale exponents */
 int disco_op_conv3x3_mx_pack(const float *h_w_oihw, int c_out, int c_in, int x2q, void *d_packed, int32_t *d_wexp,
                              size_t *bytes);
 int disco_op_conv3x3_mx(const disco_conv_mx_desc *d, const void *d_src0, const void *d_src1, const void *d_packed_w,
                         const int32_t *d_wexp, const float *d_bias, const float *d_bn_scale, const float *d_bn_shift,
-                        const void *d_res, void *d_out, uint32_t *d_sat, void *stream);
-
-/* Timing probe for disco_op_conv3x3 (tools/conv_timeline.py): d_buf = device buffer of 16*64*4 uint64 that workgroup 0
- * fills with s_memtime stamps per wave and chunk {before DMA wait, after it, after the barrier, after the last MFMA};
- * NULL switches it off. */
-int disco_op_conv3x3_set_probe(void *d_buf);
+                        const void *d_res, void *d_out, uint32_t *d_sat, const uint32_t *d_tapmask, void *stream);
+/* d_tapmask (optional, what the forward uses for its sub-pixel up-convs / transposed convs): per 32-output-channel block a 9-bit mask
+ * of the taps that carry any non-zero weight; masked-out taps are neither fetched nor multiplied.  Device uint32 [ceil(c_out / 32)]: */
+int disco_op_conv3x3_tapmask(const float *h_w_oihw, int c_out, int c_in, uint32_t *d_mask);
 
 /* Diagnostic: sustained v_mfma_f32_32x32x16_f16 rate of the current device on a registers-only loop (no LDS, no
  * memory), 2 waves per SIMD on every CU, operands: mode 0 = zeros, 1 = N(0,1) fp16, 2 = the f16x3 product mix

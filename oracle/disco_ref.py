@@ -488,8 +488,11 @@ def cv2_resize_linear_u8(img: np.ndarray, dst_h: int, dst_w: int) -> np.ndarray:
       * cv::resize: an exact 2x downscale in both directions is redirected to the area path (resizeAreaFast_, 8U:
         (a + b + c + d + 2) >> 2);
       * otherwise resizeGeneric_ with HResizeLinear / VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>:
-        per axis f = (float)((d + 0.5) * scale - 0.5), s = cvFloor(f), f -= s, (s < 0 -> f = 0, s = 0; s >= n-1 -> f = 0, s = n-1),
-        coefficients saturate_cast<short>((1-f, f) * 2048) (round half to even), scale = 1 / (dst / src) in double;
+        per axis f = (float)((d + 0.5) * scale - 0.5), s = cvFloor(f), f -= s, coefficients saturate_cast<short>((1-f, f) * 2048)
+        (round half to even), scale = 1 / (dst / src) in double.  The two axes treat the image border differently: the x loop of
+        cv::resize clamps (s < 0 -> f = 0, s = 0; s >= n-1 -> f = 0, s = n-1); the y loop keeps f and the invoker clips the two ROW
+        indices to [0, n-1] instead (clip(sy + k, 0, ssize.height)), so at the top / bottom border both rows are the same row,
+        still weighted b0 and b1 - and ((b0 r) >> 16) + ((b1 r) >> 16) can be one less than (2048 r) >> 16 (vertical upscales);
         rows: D = S[s] a0 + S[s+1] a1 (int32); columns: dst = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2.
     Pinned by hand-computed vectors and a <= 1 LSB cross-check against F.interpolate(bilinear, align_corners=False) in
     tests/test_oracle_golden.py (cv2's own output cannot be generated here: "parity unpinned" against the binary)."""
@@ -498,21 +501,22 @@ def cv2_resize_linear_u8(img: np.ndarray, dst_h: int, dst_w: int) -> np.ndarray:
     if H == 2 * dst_h and W == 2 * dst_w:
         return ((src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2).astype(np.uint8)
 
-    def axis(n_src, n_dst):
+    def axis(n_src, n_dst, clamp_f):
         scale = 1.0 / (float(n_dst) / float(n_src))
         f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
         s = np.floor(f).astype(np.int64)
         f = (f - s.astype(np.float32)).astype(np.float32)
-        lo = s < 0
-        f[lo] = 0; s[lo] = 0
-        hi = s >= n_src - 1
-        f[hi] = 0; s[hi] = n_src - 1
+        if clamp_f:             # the x loop of cv::resize
+            lo = s < 0
+            f[lo] = 0; s[lo] = 0
+            hi = s >= n_src - 1
+            f[hi] = 0; s[hi] = n_src - 1
         c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
         c1 = np.rint(f * np.float32(2048)).astype(np.int64)
-        return s, np.minimum(s + 1, n_src - 1), c0, c1
+        return np.clip(s, 0, n_src - 1), np.clip(s + 1, 0, n_src - 1), c0, c1
 
-    x0, x1, a0, a1 = axis(W, dst_w)
-    y0, y1, b0, b1 = axis(H, dst_h)
+    x0, x1, a0, a1 = axis(W, dst_w, True)
+    y0, y1, b0, b1 = axis(H, dst_h, False)
     rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]          # (H, dst_w, C) int
     out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
     return out.astype(np.uint8)
@@ -520,15 +524,14 @@ def cv2_resize_linear_u8(img: np.ndarray, dst_h: int, dst_w: int) -> np.ndarray:
 
 def fetch_from_rgb8(rgb8: np.ndarray, org_size: bool = True, psize: int = 256):
     """main/colorizer/inference.py:23-42 after cv2.imread/cvtColor, for one uint8 RGB image (H,W,3).
-    org_size=False (the reference's default, :32-33): cv2.resize to psize x psize, INTER_LINEAR (cv2_resize_linear_u8).
+    org_size=False (what inference.py's CLI passes unless --no_resize, :32-33, :101): cv2.resize to psize x psize, INTER_LINEAR (cv2_resize_linear_u8).
     org_size=True (--no_resize, :28-31): the pad-to-16 quirk (BOTH dims get `16 - dim % 16` rows/columns, i.e. a full 16
     when only the other one is off).  Then /255 in float64 -> float32, RGB->Lab (the reference's torch rgb2lab stands in
     for cv2's float COLOR_RGB2LAB, see color.hip), gray = (L-50)/50, ab/110, rgb*2-1.
     Returns (gray (1,1,Hp,Wp), ab (1,2,Hp,Wp), rgb (1,3,Hp,Wp), (H,W))."""
-    H, W = rgb8.shape[:2]
+    H, W = rgb8.shape[:2]           # the ORIGINAL size in both branches (inference.py:26,42); batch_depadding (:138-139) ignores it when resized
     if not org_size:
         rgb8 = cv2_resize_linear_u8(rgb8, psize, psize)
-        H, W = psize, psize
     elif H % 16 != 0 or W % 16 != 0:
         rgb8 = np.pad(rgb8, ((0, 16 - H % 16), (0, 16 - W % 16), (0, 0)), mode="edge")
     rgb = np.array(rgb8 / 255.0, np.float32)

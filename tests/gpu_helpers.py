@@ -33,12 +33,12 @@ def from_act(a, c=None):
     return out
 
 
-def pack_conv(w, s2d=False):
-    """(Cout,Cin,3,3) fp32 cpu -> packed device buffer (s2d: the space-to-depth packing of a stride-2 layer)."""
+def pack_conv(w):
+    """(Cout,Cin,3,3) fp32 cpu -> packed device buffer."""
     w = w.detach().cpu().float().contiguous()
     co, ci = w.shape[:2]
     nbytes = C.c_size_t()
-    pack = _ffi.lib().disco_op_conv3x3_pack_s2 if s2d else _ffi.lib().disco_op_conv3x3_pack
+    pack = _ffi.lib().disco_op_conv3x3_pack
     _ffi.check(pack(None, co, ci, None, C.byref(nbytes)))
     buf = torch.empty(nbytes.value, device=DEV, dtype=torch.uint8)
     _ffi.check(pack(_ffi.ptr(w), co, ci, _ffi.ptr(buf), C.byref(nbytes)))
@@ -46,7 +46,7 @@ def pack_conv(w, s2d=False):
 
 
 def conv3x3(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, act=_ffi.ACT_NONE, slope=0.0,
-            bn_scale=None, bn_shift=None, res=None, precision=_ffi.PREC_F16X3, s2d=False):
+            bn_scale=None, bn_shift=None, res=None, precision=_ffi.PREC_F16X3):
     """HIP conv on act tensors; returns the act output.  src*: (2,N,h,w,C) fp16."""
     n = src0.shape[1]
     h_in = src0.shape[2] * (2 if up0 else 1)
@@ -54,8 +54,8 @@ def conv3x3(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, ac
     c0 = src0.shape[4]
     c1 = src1.shape[4] if src1 is not None else 0
     co = w.shape[0]
-    packed = pack_conv(w, s2d)
-    d = _ffi.ConvDesc(n, h_in, w_in, c0, c1, int(up0), int(up1), co, stride, act, slope, precision, int(s2d))
+    packed = pack_conv(w)
+    d = _ffi.ConvDesc(n, h_in, w_in, c0, c1, int(up0), int(up1), co, stride, act, slope, precision)
     ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
     out = torch.empty(2, n, ho, wo, co, device=DEV, dtype=torch.float16)
     dv = lambda t: None if t is None else t.to(DEV).float().contiguous()
@@ -116,7 +116,7 @@ def pack_conv_mx(w, x2q=False):
 
 
 def conv3x3_mx(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, act=_ffi.ACT_NONE, slope=0.0, bn_scale=None,
-               bn_shift=None, res=None, out_planes=_ffi.PLANE_LO, out_sexp=0, out_f32=False, packed=None, x2q=False):
+               bn_shift=None, res=None, out_planes=_ffi.PLANE_LO, out_sexp=0, out_f32=False, packed=None, x2q=False, d2s=False, tapmask=False):
     """src*: MxAct with q planes (x2q: one source with al8-only planes, PLANE_QL); res: MxAct (hi [+ lo]).
     Returns (MxAct | fp32 NCHW tensor, saturation count)."""
     h_in, w_in = src0.h * (2 if up0 else 1), src0.w * (2 if up0 else 1)
@@ -125,15 +125,20 @@ def conv3x3_mx(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1,
     ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
     d = _ffi.ConvMxDesc(src0.n, h_in, w_in, src0.c_pad, src1.c_pad if src1 is not None else 0, int(up0), int(up1), src0.sexp,
                         src1.sexp if src1 is not None else 0, co, stride, act, slope, out_planes, out_sexp, int(out_f32),
-                        res.planes if res is not None else 0, int(x2q))
-    out = torch.empty(src0.n, co, ho, wo, device=DEV, dtype=torch.float32) if out_f32 else MxAct(src0.n, co, ho, wo, out_planes, out_sexp)
+                        res.planes if res is not None else 0, int(x2q), int(d2s))
+    out = torch.empty(src0.n, co, ho, wo, device=DEV, dtype=torch.float32) if out_f32 else (
+        MxAct(src0.n, co // 4, 2 * ho, 2 * wo, out_planes, out_sexp) if d2s else MxAct(src0.n, co, ho, wo, out_planes, out_sexp))
     sat = torch.zeros(1, device=DEV, dtype=torch.int32)
+    mask = None
+    if tapmask:         # the forward's masked instantiations: taps without any non-zero weight are skipped per 32-cout block
+        mask = torch.zeros((co + 31) // 32, device=DEV, dtype=torch.int32)
+        _ffi.check(_ffi.lib().disco_op_conv3x3_tapmask(_ffi.ptr(w.detach().cpu().float().contiguous()), co, w.shape[1], _ffi.ptr(mask)))
     dv = lambda t: None if t is None else t.to(DEV).float().contiguous()
     bias, bn_scale, bn_shift = dv(bias), dv(bn_scale), dv(bn_shift)
     _ffi.check(_ffi.lib().disco_op_conv3x3_mx(C.byref(d), _ffi.ptr(src0.buf), _ffi.ptr(src1.buf) if src1 is not None else None,
                                              _ffi.ptr(buf), _ffi.ptr(wexp), _ffi.ptr(bias), _ffi.ptr(bn_scale), _ffi.ptr(bn_shift),
                                              _ffi.ptr(res.buf) if res is not None else None,
-                                             _ffi.ptr(out) if out_f32 else _ffi.ptr(out.buf), _ffi.ptr(sat), stream()))
+                                             _ffi.ptr(out) if out_f32 else _ffi.ptr(out.buf), _ffi.ptr(sat), _ffi.ptr(mask), stream()))
     torch.cuda.synchronize()
     return out, int(sat.item())
 

@@ -94,7 +94,7 @@ def test_forward_matches_oracle_batch(synth_sd, q_to_ab):
     assert _err(got[2], want[2]) <= AB_TOL
 
 
-def test_batch_invariance_at_bench_size(synth_sd):
+def test_batch_invariance_at_bench_size(synth_sd, q_to_ab):
     """Full BASELINE config-2 size (N=64 @256x256): images are independent, so any image of the big batch must
     equal the same image run alone (same k-means init rows), anchors included; K anchors per image."""
     n, k = 64, 8
@@ -113,6 +113,14 @@ def test_batch_invariance_at_bench_size(synth_sd):
         one = m(gray[i:i + 1].cuda(), ab[i:i + 1].cuda(), True, 0)
         torch.cuda.synchronize()
         assert torch.equal(one[5][0], mask[i]) and torch.equal(one[2][0], pred[i])
+        # ... and the timed batch against the ORACLE: these three images of bench.py's seed-5 batch, same k-means rows
+        # (closes the chain "timed batch == tested path == oracle": anchors exact, ab within the 1e-3 bar)
+        _seed(130)
+        for _ in range(i):
+            np.random.choice(256, k, replace=False)
+        want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=k).forward(gray[i:i + 1], ab[i:i + 1])
+        assert torch.equal(mask[i].cpu(), want[5][0]), "anchors of bench image %d differ from the oracle" % i
+        assert _err(pred[i], want[2][0]) <= AB_TOL and _err(pal[i], want[0][0]) < LOGIT_TOL
 
 
 def test_diverse_batch_equals_per_image_runs(synth_sd):
@@ -315,16 +323,15 @@ def test_random_hint_with_host_positions(synth_sd, q_to_ab):
     assert _err(out[0], want[0]) < LOGIT_TOL and _err(out[1], want[1]) < LOGIT_TOL and _err(out[2], want[2]) <= AB_TOL
 
 
-def test_precision_mode_f16x1_runs(synth_sd):
-    """The hi-only mode is a speed option; it must run and stay within fp16-class error of the x3 path."""
-    gray, ab = synth.synth_inputs(1, 128, 128, seed=3)
-    m3 = _model(synth_sd, 8)
-    m1 = AnchorColorProb(n_clusters=8, enhanced=True, precision="f16x1", init_weights=False)
-    m1.load_state_dict(synth_sd); m1 = m1.cuda().eval()
-    _seed(1); a = m3(gray.cuda(), ab.cuda(), True, 0)
-    _seed(1); b = m1(gray.cuda(), ab.cuda(), True, 0)
-    torch.cuda.synchronize()
-    assert _err(a[3], b[3]) < 2e-2
+def test_removed_precision_mode_is_rejected(synth_sd):
+    """The hi-only mode ("f16x1", ABI value 1) ran on round 1's conv kernel and went with it (ABI 6): ctor keyword and C ABI reject it."""
+    import ctypes as C
+    from disentangledcolorization_amd import _ffi
+    with pytest.raises(KeyError):
+        AnchorColorProb(n_clusters=8, enhanced=True, precision="f16x1", init_weights=False)
+    ctx = C.c_void_p()
+    opt = _ffi.Options(16, 8, 0, 1, 0, 0, 0)
+    assert _ffi.lib().disco_create(0, C.byref(opt), C.byref(ctx)) != 0
 
 
 def test_precision_mode_x2q_against_oracle(synth_sd, q_to_ab):
@@ -452,3 +459,46 @@ def test_fp8_saturation_counter_and_calibration_record(synth_sd):
     _seed(1)
     after = m(gray.cuda(), ab.cuda(), True, 0)
     assert torch.equal(before[5], after[5]) and _err(before[2], after[2]) < 2e-4 and m.saturation_count() == 0
+
+
+def test_colorize_cli_flow_against_oracle(synth_sd, q_to_ab, tmp_path):
+    """The caller: tools/colorize.py = main/colorizer/inference.py:93-131 (decode -> fetch_data -> forward -> Lab -> uint8 -> PNG) on the
+    repo-local 150x201 test image (SURVEY config 1), default resize-256 path and --no_resize, against
+    fetch_from_rgb8 -> DiscoOracle -> labs_to_rgb8: <= 1 LSB per channel (uint8 truncation of a float that may differ in the last ulp)."""
+    import subprocess
+    import sys
+    from PIL import Image
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    png = os.path.join(repo, "tools", "gradient_150x201.png")
+    rgb8 = np.asarray(Image.open(png).convert("RGB"))
+    for flags, org in (([], False), (["--no_resize"], True)):
+        out = tmp_path / ("o%d" % org)
+        r = subprocess.run([sys.executable, os.path.join(repo, "tools", "colorize.py"), "--out", str(out), "--seed", "130", png] + flags,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = np.asarray(Image.open(out / "gradient_150x201.png").convert("RGB"))
+        gray, ab, _, (H, W) = R.fetch_from_rgb8(rgb8, org_size=org)
+        _seed(130)          # inference.py:58-60; the CLI seeds NumPy the same way before its first forward
+        want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=8).forward(gray, ab)
+        if not org:
+            H, W = gray.shape[2], gray.shape[3]
+        ref8 = R.labs_to_rgb8(torch.cat((gray, want[2]), 1), H, W)[0]
+        assert got.shape == ref8.shape == ((150, 201, 3) if org else (256, 256, 3))
+        assert np.abs(got.astype(int) - ref8.astype(int)).max() <= 1
+
+
+def test_colorize_mixed_shapes_equals_per_file_loop(synth_sd):
+    """BASELINE config 4 (--no_resize: a mixed 512x512 / 768x512 list): runner.colorize_mixed groups equal shapes into batches;
+    every image's result must equal the reference's one-file-at-a-time loop (same draws in file order), bit for bit."""
+    from disentangledcolorization_amd.runner import colorize_mixed
+    m = _model(synth_sd, 8)
+    shapes = [(512, 512), (768, 512), (512, 512), (512, 768), (768, 512)]
+    data = [synth.synth_inputs(1, h, w, seed=40 + i) for i, (h, w) in enumerate(shapes)]
+    _seed(130)
+    loop = [m(g.cuda(), a.cuda(), True, 0) for g, a in data]
+    _seed(130)
+    got = colorize_mixed(m, [g.cuda() for g, _ in data], [a.cuda() for _, a in data])
+    torch.cuda.synchronize()
+    for one, grp in zip(loop, got):
+        for k in (0, 2, 5):
+            assert torch.equal(one[k], grp[k])

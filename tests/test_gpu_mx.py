@@ -172,3 +172,52 @@ def test_conv3x3_mx_rejects_bad_shapes(H):
     x = torch.randn(1, 48, 8, 8)
     with pytest.raises(_ffi.DiscoError):
         H.conv3x3_mx(H.to_act_mx(x, c_pad=64), torch.randn(16, 48, 3, 3), torch.zeros(16), out_planes=Q)   # 16 output channels cannot carry q planes
+
+
+@pytest.mark.parametrize("planes", [Q, LO | Q])
+def test_conv3x3_mx_depth_to_space(H, planes):
+    """The depth-to-space epilogue of the fp16+fp8 arithmetic (HourGlass2's sub-pixel up-convs: `up2.conv1`, `up1.conv1`): 4 C
+    phase-major output channels of the low-resolution conv land in an (n, C, 2h, 2w) activation, hi (+ lo) and q planes."""
+    gen = g(21)
+    n, cin, C, h, w = 2, 64, 32, 13, 19                     # ragged: partial tiles
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(4 * C, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(C, generator=gen) * 0.1                 # the kernel indexes its parameters modulo the phase size
+    y = F.relu(F.conv2d(x.double(), wt.double(), b.double().repeat(4), padding=1))          # (n, 4C, h, w), channel = ph*C + c
+    want = y.reshape(n, 2, 2, C, h, w).permute(0, 3, 4, 1, 5, 2).reshape(n, C, 2 * h, 2 * w)   # pixel (2y + ph/2, 2x + ph%2)
+    out, sat = H.conv3x3_mx(H.to_act_mx(x), wt, b, act=_ffi.ACT_RELU, out_planes=planes, out_sexp=H.sexp_for(want.float()), d2s=True)
+    scale = max(1.0, want.abs().max().item())
+    assert sat == 0 and H.max_err(out.read(0), want) < TOL * scale
+    assert H.max_err(out.read(2), want) < TOL * scale       # hi + dequantised al8 plane: the q planes landed in the right pixels too
+
+
+@pytest.mark.parametrize("x2q", [False, True])
+def test_conv3x3_mx_masked_depth_to_space_is_run_to_run_deterministic(H, x2q):
+    """Regression (round 3): the epilogue's 16-byte stores are asm blocks (store-data hazard, conv_mx_kernel.h), which the compiler's
+    hazard recogniser does not look into - and in the instantiations that spill SGPRs the store's descriptor / offset registers are
+    reloaded with v_readlane right in front of it (VALU-written SGPR -> VMEM read: 5 wait states).  The masked depth-to-space
+    instantiation of the f16x2+fp8 arithmetic (the ColorProbNet's up-convs under precision="x2q") wrote its hi plane through stale
+    offsets, differently from run to run.  Sub-pixel up-conv weights (4 live taps per phase), tap mask on, five repeats, raw buffers
+    byte-identical - and correct."""
+    planes = _ffi.PLANE_QL if x2q else Q
+    gen = g(5)
+    n, cin, C, h, w = 8, 128, 64, 64, 64
+    x = torch.relu(torch.randn(n, cin, h, w, generator=gen))
+    w3 = torch.randn(C, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    wt = torch.zeros(4 * C, cin, 3, 3)
+    for py in range(2):
+        for px in range(2):
+            for ky in range(3):
+                for kx in range(3):          # nearest-x2 upsample + 3x3 == 4 phases of pre-summed 2x2 taps on the low-res grid
+                    wt[(py * 2 + px) * C:(py * 2 + px + 1) * C, :, ((py + ky - 1) >> 1) + 1, ((px + kx - 1) >> 1) + 1] += w3[:, :, ky, kx]
+    b = torch.randn(C, generator=gen) * 0.1
+    want = F.relu(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w3.double(), b.double(), padding=1))
+    src = H.to_act_mx(x, planes)
+    packed = H.pack_conv_mx(wt, x2q)
+    bufs = []
+    for _ in range(5):
+        out, sat = H.conv3x3_mx(src, wt, b, act=_ffi.ACT_RELU, out_planes=planes, out_sexp=H.sexp_for(want.float()), packed=packed, x2q=x2q, d2s=True, tapmask=True)
+        bufs.append(out.buf.clone())
+    for o in bufs[1:]:
+        assert torch.equal(o, bufs[0])
+    assert sat == 0 and H.max_err(out.read(2), want) < TOL * max(1.0, want.abs().max().item())

@@ -109,6 +109,13 @@ def test_cv2_resize_restatement_hand_vectors():
     # 3x1 -> 2x1 (vertical only, scale 1.5): f = 0.25, 1.75 -> (0,.25) (1,.75); rows D = v*2048; b = (1536,512), (512,1536):
     # ((1536*(0>>4))>>16) + ((512*(204800>>4))>>16) + 2 = 0 + 100 + 2 -> 25;  ((512*(204800>>4))>>16) + ((1536*(409600>>4))>>16) + 2 = 100+600+2 -> 175
     assert R.cv2_resize_linear_u8(np.array([[[0]], [[100]], [[200]]], np.uint8), 2, 1).ravel().tolist() == [25, 175]
+    # 2x2 -> 4x3: a VERTICAL UPSCALE with a horizontally interpolated column.  x (clamped f): a = (2048,0) (1024,1024) (2048,0); y (f kept,
+    # rows clipped): dy=0: s=-1, f=.75 -> rows (0,0), b = (512,1536); dy=3: s=1, f=.25 -> rows (1,1), b = (1536,512).  Middle column:
+    # D0 = (10+21)*1024 = 31744, D0>>4 = 1984: top = ((512*1984)>>16) + ((1536*1984)>>16) + 2 = 15 + 46 + 2 -> 63>>2 = 15 (one weight of
+    # 2048 on the same row would give (62+2)>>2 = 16); D1 = (110+121)*1024, D1>>4 = 14784: bottom = 346 + 115 + 2 -> 463>>2 = 115 (not 116);
+    # dy=1: b = (1536,512) on rows (0,1): 46 + 115 + 2 -> 40
+    assert R.cv2_resize_linear_u8(np.array([[[10], [21]], [[110], [121]]], np.uint8), 4, 3)[..., 0].tolist() == \
+        [[10, 15, 21], [35, 40, 46], [85, 90, 96], [110, 115, 121]]
     # exact 2x downscale in both directions: cv::resize switches INTER_LINEAR to the area path, (a+b+c+d+2)>>2
     assert R.cv2_resize_linear_u8(np.array([[[1], [2]], [[3], [5]]], np.uint8), 1, 1).ravel().tolist() == [3]
     rs = np.random.RandomState(0)
@@ -122,7 +129,7 @@ def test_cv2_resize_restatement_hand_vectors():
         if (h, w) == (ho, wo):
             assert np.array_equal(got, img)             # identity resize is exact
     gr, ab, rgb, hw = R.fetch_from_rgb8(rs.randint(0, 256, (100, 75, 3)).astype(np.uint8), org_size=False)
-    assert gr.shape == (1, 1, 256, 256) and ab.shape == (1, 2, 256, 256) and hw == (256, 256)
+    assert gr.shape == (1, 1, 256, 256) and ab.shape == (1, 2, 256, 256) and hw == (100, 75)      # the ORIGINAL size (inference.py:26,42)
 
 
 def test_spixelseg_standalone(golden_dir, synth_sd):

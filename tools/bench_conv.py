@@ -50,7 +50,7 @@ def bench_mx(L, args, name, c0, c1, co, hin, stride, up0):
 
     def run():
         _ffi.check(L.disco_op_conv3x3_mx(C.byref(d), _ffi.ptr(x0.buf), _ffi.ptr(x1.buf) if x1 else None, _ffi.ptr(packed), _ffi.ptr(wexp),
-                                        _ffi.ptr(bias), None, None, None, _ffi.ptr(out.buf), None, H.stream()))
+                                        _ffi.ptr(bias), None, None, None, _ffi.ptr(out.buf), None, None, H.stream()))
     for _ in range(3):
         run()
     torch.cuda.synchronize()

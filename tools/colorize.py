@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--spix_pos", action="store_true")
     ap.add_argument("--anchors", action="store_true", help="also save the anchor overlay")
     ap.add_argument("--no_resize", action="store_true", help="keep the original size (padded to multiples of 16), inference.py:148")
-    ap.add_argument("--psize", type=int, default=256)
+    ap.add_argument("--resize_to", type=int, default=256, help="side of the resized input (the reference hard-codes 256, inference.py:33; its --psize is the superpixel size)")
     ap.add_argument("--seed", type=int, default=130)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -49,7 +49,9 @@ def main():
     model = model.cuda().eval()
     for path in args.images:
         rgb8 = np.asarray(Image.open(path).convert("RGB"))
-        gray, ab, _, (H, W) = basic.fetch_data_from_rgb8(rgb8, org_size=args.no_resize, psize=args.psize)
+        gray, ab, _, (H, W) = basic.fetch_data_from_rgb8(rgb8, org_size=args.no_resize, psize=args.resize_to)
+        if not args.no_resize:
+            H, W = gray.shape[2], gray.shape[3]         # batch_depadding (inference.py:138-139): no crop unless --no_resize
         _, _, pred_ab, affinity, _, hint_mask = model(gray, ab, True, 2 if args.diverse else 0)
         stem = os.path.splitext(os.path.basename(path))[0]
         for i in range(pred_ab.shape[0]):
