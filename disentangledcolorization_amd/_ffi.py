@@ -43,14 +43,16 @@ class ForwardArgs(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c_in0", C.c_int32),
                 ("c_in1", C.c_int32), ("up0", C.c_int32), ("up1", C.c_int32), ("c_out", C.c_int32),
-                ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("precision", C.c_int32)]
+                ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("precision", C.c_int32),
+                ("sexp_in", C.c_int32), ("sexp_out", C.c_int32), ("sexp_res", C.c_int32)]
 
 
 class ConvMxDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c_in0", C.c_int32), ("c_in1", C.c_int32),
                 ("up0", C.c_int32), ("up1", C.c_int32), ("sexp0", C.c_int32), ("sexp1", C.c_int32), ("c_out", C.c_int32),
                 ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("out_planes", C.c_int32),
-                ("out_sexp", C.c_int32), ("out_f32", C.c_int32), ("res_planes", C.c_int32), ("x2q", C.c_int32), ("d2s", C.c_int32)]
+                ("out_sexp", C.c_int32), ("out_f32", C.c_int32), ("res_planes", C.c_int32), ("res_sexp", C.c_int32), ("x2q", C.c_int32),
+                ("d2s", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/disco_hip.h declares

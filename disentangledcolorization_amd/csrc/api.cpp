@@ -527,7 +527,7 @@ struct Plan {
         hipEventRecord(ev, s);
         c->prof.push_back({name, ev, flops});
     }
-    // scale exponent of the q planes of the tensor produced by `key` (fixed by the calibration pass of disco_finalize)
+    // scale exponent of the tensor produced by `key` (fixed by the calibration pass of disco_finalize)
     bool scale_of(const std::string& key, int* sexp) {
         auto it = c->sexp.find(key);
         if (it == c->sexp.end()) {
@@ -537,38 +537,62 @@ struct Plan {
         *sexp = it->second;
         return true;
     }
-    // Calibration (disco_finalize): `produce` has just written tensor `t` with a provisional q scale; measure max |x| of its
-    // hi plane, fix the scale so that the maximum lands in [16, 32) of fp8's +-448 range (2^4 of headroom for other inputs,
-    // 2^-13 of the maximum still representable), and run the producer again with the final scale.
+    // Calibration (disco_finalize / disco_calibrate): `produce` has just written tensor `t` with a provisional exponent (the previous
+    // calibration's, or 0).  Measure max |xs| of its hi plane; if the provisional scale overflowed fp16 or buried the tensor in its
+    // subnormals, move it by 2^10 and produce again; then fix the exponent so that the maximum lands in [16, 32) - 2^11 of fp16
+    // headroom (and 14x of fp8's +-448) for other inputs, values down to 2^-7 of the maximum keep a normal fp16 lo word - and
+    // produce once more with the final exponent.  `tie`: a tensor that is concatenated on read with an earlier one (skip
+    // connections; the conv accumulates both sources in ONE domain) takes the earlier tensor's exponent, which must then leave its
+    // own values inside fp16's comfortable range - otherwise this checkpoint cannot run and the error names the layer.
     template <class F>
-    void calibrate(const std::string& key, Act& t, F&& produce) {
+    void calibrate(const std::string& key, Act& t, F&& produce, const std::string& tie = "") {
         if (!calib || dry || !ok()) return;
-        float* d_amax = (float*)raw(256);
-        float amax = 0.f;
-        if (!ok()) return;
-        if (hipMemsetAsync(d_amax, 0, 4, s) != hipSuccess) { rc = DISCO_EHIP; return; }
-        rc = launch_act_amax(t, d_amax, s);
-        if (ok() && (hipMemcpyAsync(&amax, d_amax, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = hip_fail(hipGetLastError(), "calibration amax");
-        drop(d_amax);
-        if (!ok()) return;
+        float amax_s = 0.f;      // stored maximum
+        for (int attempt = 0; attempt < 12; ++attempt) {
+            float* d_amax = (float*)raw(256);
+            if (!ok()) return;
+            if (hipMemsetAsync(d_amax, 0, 4, s) != hipSuccess) { rc = DISCO_EHIP; return; }
+            rc = launch_act_amax(t, d_amax, s);
+            if (ok() && (hipMemcpyAsync(&amax_s, d_amax, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = hip_fail(hipGetLastError(), "calibration amax");
+            drop(d_amax);
+            if (!ok()) return;
+            const bool too_big = !(amax_s <= 16384.f);                      // also inf / NaN
+            const bool too_small = amax_s > 0.f && amax_s < 1.f / 1024.f;
+            if (!too_big && !too_small) break;
+            if (attempt == 11 || !std::isfinite(std::ldexp(1.f, t.sexp))) {
+                set_error("activation range of %s cannot be brought into fp16 range (stored max |x| = %g at scale 2^%d): not a finite network output", key.c_str(), (double)amax_s, t.sexp);
+                rc = DISCO_EUNSUPPORTED; return;
+            }
+            t.sexp += too_big ? -10 : 10;
+            produce();
+            if (!ok()) return;
+        }
+        float amax = std::ldexp(amax_s, -t.sexp);                           // true maximum
         {   // calibrations accumulate: a later disco_calibrate on other images can only widen a tensor's range
             auto prev = c->amax.find(key);
             if (prev != c->amax.end() && prev->second > amax) amax = prev->second;
         }
         c->amax[key] = amax;
-        if (!(amax <= 16384.f)) {     // also catches NaN
-            set_error("activation range of %s (max |x| = %g) leaves no fp16 headroom: this checkpoint cannot run in fp16 hi/lo arithmetic", key.c_str(), (double)amax);
-            rc = DISCO_EUNSUPPORTED; return;
-        }
         int e = 0;
-        if (amax > 0.f) { std::frexp(amax, &e); e = 5 - e; }        // amax 2^e in [16, 32)
+        if (amax > 0.f) { std::frexp(amax, &e); e = 5 - e; }                // amax 2^e in [16, 32)
+        if (!tie.empty()) {
+            auto it = c->sexp.find(tie);
+            if (it == c->sexp.end()) { set_error("calibration order: %s is tied to %s, which has no exponent yet", key.c_str(), tie.c_str()); rc = DISCO_ESTATE; return; }
+            const float tied = std::ldexp(amax, it->second);
+            if (amax > 0.f && !(tied <= 8192.f && tied >= 1.f / 64.f)) {
+                set_error("%s and %s are concatenated on read and must share one scale, but their ranges differ too much (max |x| %g vs %g): "
+                          "this checkpoint cannot run in fp16 hi/lo arithmetic", key.c_str(), tie.c_str(), (double)amax, (double)c->amax[tie]);
+                rc = DISCO_EUNSUPPORTED; return;
+            }
+            e = it->second;
+        }
         c->sexp[key] = e;
-        if (t.q_off) { t.sexp = e; produce(); }
+        if (t.sexp != e) { t.sexp = e; produce(); }
     }
 
     // MFMA conv: out = bn(act(conv(cat(in0[,in1])) + bias [+ res]));  ofmt: planes of the output tensor (-1: the default)
     Act conv(const std::string& key, const Act& in0, const Act* in1, int up0, int up1, int stride, int actc, float slope,
-             const Act* res = nullptr, float* out_f32 = nullptr, bool d2s = false, bool softmax = false, int ofmt = -1) {
+             const Act* res = nullptr, float* out_f32 = nullptr, bool d2s = false, bool softmax = false, int ofmt = -1, const std::string& tie = "") {
         const ConvLayer& L = c->conv.at(key);
         const int hin = in0.h << up0, win = in0.w << up0;
         const int ho = (hin - 1) / stride + 1, wo = (win - 1) / stride + 1;
@@ -579,7 +603,7 @@ struct Plan {
         else if (!out_f32) out = act(in0.n, ho, wo, co_t, ofmt);
         if (dry || !ok()) return out;
         if (in0.c + (in1 ? in1->c : 0) != L.c_in_pad) { set_error("conv %s: input channels %d != %d", key.c_str(), in0.c + (in1 ? in1->c : 0), L.c_in_pad); rc = DISCO_ESHAPE; return out; }
-        if (!out_f32 && (ofmt & (F_Q | F_QL)) && !scale_of(key, &out.sexp)) return out;
+        if (!out_f32 && !scale_of(key, &out.sexp)) return out;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = c->profiling >= 2 && !calib && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
         if (timed) hipEventRecord(e0, s);
@@ -597,30 +621,33 @@ struct Plan {
                 ca.h_out = ho; ca.w_out = wo; ca.stride = stride;
                 ca.w = L.d_w; ca.wexp = L.d_wexp; ca.tapmask = L.d_tapmask; ca.c_out = co_t; ca.c_out_pad = co_t;
                 ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
-                ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
+                ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0; ca.res_sexp = res ? res->sexp : 0;
                 ca.out = out.p; ca.out_plane = (long)out.plane; ca.out_q_off = out.q_off; ca.out_sexp = out.sexp; ca.out_q_kind = out.q_kind;
                 ca.out_f32 = out_f32; ca.d2s_c = d2s ? co_t / 4 : 0; ca.softmax = softmax ? 1 : 0;
                 ca.act = actc; ca.slope = slope; ca.sat = calib ? nullptr : c->d_sat; ca.x2q = L.x2q;
                 rc = launch_conv3x3_mx(ca, s);
             };
             launch();
-            if (!out_f32) calibrate(key, out, launch);
+            if (!out_f32) calibrate(key, out, launch, tie);
         } else {
+            auto launch = [&]() {
             ConvArgs ca{};
-            if (!in0.plane || (in1 && !in1->plane) || (res && !res->plane) || (!out_f32 && !out.plane)) { set_error("conv %s: the f16x3 kernel needs lo planes", key.c_str()); rc = DISCO_ESHAPE; return out; }
-            ca.src[0] = {in0.p, (long)in0.plane, in0.c, in0.h, in0.w, up0};
+            if (!in0.plane || (in1 && !in1->plane) || (res && !res->plane) || (!out_f32 && !out.plane)) { set_error("conv %s: the f16x3 kernel needs lo planes", key.c_str()); rc = DISCO_ESHAPE; return; }
+            ca.src[0] = {in0.p, (long)in0.plane, in0.c, in0.h, in0.w, up0, in0.sexp};
             ca.nsrc = 1;
-            if (in1) { ca.src[1] = {in1->p, (long)in1->plane, in1->c, in1->h, in1->w, up1}; ca.nsrc = 2; }
+            if (in1) { ca.src[1] = {in1->p, (long)in1->plane, in1->c, in1->h, in1->w, up1, in1->sexp}; ca.nsrc = 2; }
             ca.n = in0.n; ca.h_in = hin; ca.w_in = win; ca.c_in = L.c_in_pad;
             ca.h_out = ho; ca.w_out = wo; ca.stride = stride;
             ca.w = L.d_w; ca.tapmask = L.d_tapmask; ca.c_out = L.c_out; ca.c_out_pad = L.c_out;
             ca.bias = L.d_bias; ca.bn_scale = L.d_bn_scale; ca.bn_shift = L.d_bn_shift;
-            ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0;
-            ca.out = out.p; ca.out_plane = (long)out.plane;
+            ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0; ca.res_sexp = res ? res->sexp : 0;
+            ca.out = out.p; ca.out_plane = (long)out.plane; ca.out_sexp = out.sexp;
             ca.out_f32 = out_f32; ca.d2s_c = d2s ? L.c_out / 4 : 0; ca.softmax = softmax ? 1 : 0;
             ca.act = actc; ca.slope = slope; ca.precision = DISCO_PREC_F16X3;
             rc = run_conv(ca, s);
-            if (!out_f32) calibrate(key, out, [] {});     // calibration pass: records max |x| (fp16 range guard) for f16x3 layers too
+            };
+            launch();
+            if (!out_f32) calibrate(key, out, launch, tie);
         }
         if (timed) {
             hipEventRecord(e1, s);
@@ -638,14 +665,14 @@ struct Plan {
         }
         return out;
     }
-    Act deconv(const std::string& key, const Act& in, float slope, int ofmt = -1) {
-        return conv(key, in, nullptr, 0, 0, 1, DISCO_ACT_LRELU, slope, nullptr, nullptr, true, false, ofmt);
+    Act deconv(const std::string& key, const Act& in, float slope, const std::string& tie) {
+        return conv(key, in, nullptr, 0, 0, 1, DISCO_ACT_LRELU, slope, nullptr, nullptr, true, false, -1, tie);
     }
     Act c1(const std::string& key, const float* gray, int n, int h, int w, int actc, float slope) {
         const DirectLayer& L = c->direct.at(key);
         Act out = act(n, h, w, cpad(L.c_out), dfmt());
         if (dry || !ok()) return out;
-        if (out.q_off && !scale_of(key, &out.sexp)) return out;
+        if (!scale_of(key, &out.sexp)) return out;
         auto launch = [&]() { rc = launch_conv_c1(gray, L.d_w, L.d_bias, nullptr, nullptr, out, L.c_out, actc, slope, calib ? nullptr : c->d_sat, s); };
         launch();
         calibrate(key, out, launch);
@@ -671,13 +698,14 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
     Act o4 = P.conv(sg + "conv3b.0", t, nullptr, 0, 0, 1, LRELU, 0.1f); P.drop(t);
     t = P.conv(sg + "conv4a.0", o4, nullptr, 0, 0, 2, LRELU, 0.1f);
     Act o5 = P.conv(sg + "conv4b.0", t, nullptr, 0, 0, 1, LRELU, 0.1f); P.drop(t);
-    Act d = P.deconv(sg + "deconv3.0", o5, 0.1f); P.drop(o5);
+    // the transposed convs' outputs are concatenated on read with the encoder tensors of the same level: one exponent per pair
+    Act d = P.deconv(sg + "deconv3.0", o5, 0.1f, sg + "conv3b.0"); P.drop(o5);
     Act cc = P.conv(sg + "conv3_1.0", o4, &d, 0, 0, 1, LRELU, 0.1f); P.drop(d); P.drop(o4);
-    d = P.deconv(sg + "deconv2.0", cc, 0.1f); P.drop(cc);
+    d = P.deconv(sg + "deconv2.0", cc, 0.1f, sg + "conv2b.0"); P.drop(cc);
     cc = P.conv(sg + "conv2_1.0", o3, &d, 0, 0, 1, LRELU, 0.1f); P.drop(d); P.drop(o3);
-    d = P.deconv(sg + "deconv1.0", cc, 0.1f); P.drop(cc);
+    d = P.deconv(sg + "deconv1.0", cc, 0.1f, sg + "conv1b.0"); P.drop(cc);
     cc = P.conv(sg + "conv1_1.0", o2, &d, 0, 0, 1, LRELU, 0.1f); P.drop(d); P.drop(o2);
-    d = P.deconv(sg + "deconv0.0", cc, 0.1f); P.drop(cc);
+    d = P.deconv(sg + "deconv0.0", cc, 0.1f, sg + "conv0b.0"); P.drop(cc);
     cc = P.conv(sg + "conv0_1.0", o1, &d, 0, 0, 1, LRELU, 0.1f); P.drop(d); P.drop(o1);
     // pred_mask0 (16 -> 9, bias) + softmax over the 9 slots, fp32 NCHW out (network.py:311-312)
     P.conv(sg + "pred_mask0", cc, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, dry ? (float*)16 : d_affinity, false, true);
@@ -687,7 +715,7 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
 int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, size_t* peak, bool calib = false) {
     Plan P(c, a, cap, dry);
     P.calib = calib;
-    if (!dry && !calib && any_mx(c) && !c->calibrated) { set_error("mx context used before its calibration pass"); return DISCO_ESTATE; }
+    if (!dry && !calib && !c->calibrated) { set_error("context used before its calibration pass"); return DISCO_ESTATE; }
     const int n = a->n, H = a->h, W = a->w, sp = c->opt.sp_size, K = c->opt.n_clusters;
     const int hs = H / sp, ws = W / sp, L = hs * ws;
     const bool test = a->test_mode != 0, h2r = c->opt.hint2regress != 0, spos = c->opt.spix_pos != 0;
@@ -744,7 +772,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     if (!dry && P.ok()) P.rc = spos ? get_pos(c, H, W, &pos) : get_pos(c, hs, ws, &pos);
     if (!dry && P.ok()) {
         PoolArgs pa{};
-        pa.feat_act = feats.p; pa.feat_plane = (long)feats.plane; pa.c_act = 64;
+        pa.feat_act = feats.p; pa.feat_plane = (long)feats.plane; pa.c_act = 64; pa.feat_mul = std::ldexp(1.f, -feats.sexp);
         pa.feat_nchw = a->d_ab; pa.c_nchw = 2; pa.prob = a->d_affinity;
         if (spos) { pa.feat_bc = pos; pa.c_bc = 64; pa.bc_out = pos_img; }
         pa.partial = (float*)pool_ws; pa.cnt = (float*)pool_ws + (size_t)n * L * 9 * (cpool + 1);
@@ -817,13 +845,13 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     P.stage_arith = arith_of(c, "enhanceNet.");
     Act full = P.act(n2, H, W, 64, P.dfmt());
     Act g16 = P.act(n2, H, W, P.cpad(16), P.dfmt());
-    if (!dry && P.ok() && full.q_off && P.scale_of("upfeat", &full.sexp) && P.scale_of("gray16", &g16.sexp)) {}
+    if (!dry && P.ok() && P.scale_of("upfeat", &full.sexp) && P.scale_of("gray16", &g16.sexp)) {}
     {
         unsigned int* sat = calib ? nullptr : c->d_sat;
         auto up = [&]() { P.rc = launch_upfeat(dec, 1, a->d_affinity, rep, &full, nullptr, n2, 64, hs, ws, sp, sat, s); };
         auto gr = [&]() { P.rc = launch_gray16(a->d_gray, rep, g16, sat, s); };
         if (!dry && P.ok()) { up(); P.calibrate("upfeat", full, up); }
-        if (!dry && P.ok()) { gr(); P.calibrate("gray16", g16, gr); }
+        if (!dry && P.ok()) { gr(); P.calibrate("gray16", g16, gr, "upfeat"); }        // concatenated on read with the up-sampled features
     }
     P.drop(dec);
     P.mark("upfeat");
@@ -842,11 +870,11 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
         Act y = P.conv(k + "3", t2, nullptr, 0, 0, 1, RELU, 0.f, &x, nullptr, false, false, rfmt); P.drop(t2); P.drop(x);
         x = y;
     }
-    t = P.conv(en + "up2.conv1", x, nullptr, 0, 0, 1, NOACT, 0.f); P.drop(x);
+    t = P.conv(en + "up2.conv1", x, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, -1, en + "down1.conv.2"); P.drop(x);      // concatenated with e2
     Act u = P.conv(en + "up2.combine", t, &e2, 1, 0, 1, RELU, 0.f); P.drop(t); P.drop(e2);
     t = P.conv(en + "up2.conv2.0", u, nullptr, 0, 0, 1, RELU, 0.f); P.drop(u);
     u = P.conv(en + "up2.conv2.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
-    t = P.conv(en + "up1.conv1", u, nullptr, 0, 0, 1, NOACT, 0.f); P.drop(u);
+    t = P.conv(en + "up1.conv1", u, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, -1, en + "inConv.conv.0"); P.drop(u);     // concatenated with e1
     u = P.conv(en + "up1.combine", t, &e1, 1, 0, 1, RELU, 0.f); P.drop(t); P.drop(e1);
     t = P.conv(en + "up1.conv2.0", u, nullptr, 0, 0, 1, RELU, 0.f); P.drop(u);
     u = P.conv(en + "up1.conv2.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
@@ -868,13 +896,12 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
 
 void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int W, float* d_affinity);
 
-// The calibration pass of an mx context (end of disco_finalize): one forward over two synthetic 256x256 images - uniform noise
-// and a smooth low-frequency pattern - in which every producer of an fp8-carrying tensor runs twice: once to measure the
+// The calibration pass of a context (end of disco_finalize): one forward over two synthetic 256x256 images - uniform noise
+// and a smooth low-frequency pattern - in which every producer of an activation tensor runs (at least) twice: once to measure the
 // tensor's max |x|, once more with the power-of-two scale that measurement fixes (Plan::calibrate).  The scales are
 // properties of the checkpoint from then on (deterministic: the inputs are generated here); q-plane clamping at run time is
 // counted (disco_saturation_count) so that inputs far outside the calibrated range are noticed.
 int calibrate_ctx(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, int uh = 0, int uw = 0) {
-    if (!any_mx(c) || (c->opt.segnet_only && c->opt.precision != DISCO_PREC_MX8_ALL)) { c->calibrated = true; return DISCO_OK; }
     const int n = d_user_gray ? un : 2, H = d_user_gray ? uh : 256, W = d_user_gray ? uw : 256, K = c->opt.n_clusters, L = (H / 16) * (W / 16);
     std::vector<float> g(d_user_gray ? 0 : (size_t)n * H * W);
     if (!d_user_gray) {
@@ -1271,12 +1298,12 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
     if (d->c_in0 % 16 || d->c_in1 % 16) { set_error("conv3x3 op: source channels must be multiples of 16"); return DISCO_ESHAPE; }
     ConvArgs ca{};
     const int h0 = d->up0 ? d->h_in / 2 : d->h_in, w0 = d->up0 ? d->w_in / 2 : d->w_in;
-    ca.src[0] = {(const f16*)d_src0, (long)d->n * h0 * w0 * d->c_in0, d->c_in0, h0, w0, d->up0};
+    ca.src[0] = {(const f16*)d_src0, (long)d->n * h0 * w0 * d->c_in0, d->c_in0, h0, w0, d->up0, d->sexp_in};
     ca.nsrc = 1;
     if (d->c_in1) {
         if (!d_src1) { set_error("null second source"); return DISCO_EINVAL; }
         const int h1 = d->up1 ? d->h_in / 2 : d->h_in, w1 = d->up1 ? d->w_in / 2 : d->w_in;
-        ca.src[1] = {(const f16*)d_src1, (long)d->n * h1 * w1 * d->c_in1, d->c_in1, h1, w1, d->up1};
+        ca.src[1] = {(const f16*)d_src1, (long)d->n * h1 * w1 * d->c_in1, d->c_in1, h1, w1, d->up1, d->sexp_in};
         ca.nsrc = 2;
     }
     ca.n = d->n; ca.h_in = d->h_in; ca.w_in = d->w_in; ca.c_in = d->c_in0 + d->c_in1;
@@ -1284,7 +1311,7 @@ int disco_op_conv3x3(const disco_conv_desc* d, const void* d_src0, const void* d
     ca.w = (const f16*)d_packed_w; ca.c_out = d->c_out; ca.c_out_pad = d->c_out;
     ca.bias = d_bias; ca.bn_scale = d_bn_scale; ca.bn_shift = d_bn_shift;
     ca.out = (f16*)d_out; ca.out_plane = (long)d->n * ca.h_out * ca.w_out * d->c_out;
-    ca.res = (const f16*)d_res; ca.res_plane = ca.out_plane;
+    ca.res = (const f16*)d_res; ca.res_plane = ca.out_plane; ca.res_sexp = d->sexp_res; ca.out_sexp = d->sexp_out;
     ca.act = d->act; ca.slope = d->slope; ca.precision = d->precision;
     if (d->precision != DISCO_PREC_F16X3) { set_error("conv3x3 op: precision %d (the f16x3 arithmetic only; the fp16+fp8 ones go through disco_op_conv3x3_mx)", d->precision); return DISCO_EINVAL; }
     return run_conv(ca, (hipStream_t)stream);
@@ -1317,7 +1344,7 @@ int disco_op_act_mx_to_nchw(const void* d_src, float* d_dst, int n, int ch, int 
     const Act t = flat_act(d_src, n, c_pad, h, w, planes, sexp);
     if (which == 0) {
         if (!t.plane) { set_error("act_mx_to_nchw: which = 0 needs the lo plane"); return DISCO_EINVAL; }
-        return launch_act_to_nchw(t.p, (long)t.plane, d_dst, n, ch, h, w, c_pad, (hipStream_t)stream);
+        return launch_act_to_nchw(t.p, (long)t.plane, d_dst, n, ch, h, w, c_pad, (hipStream_t)stream, sexp);
     }
     if (!t.q_off || which < 1 || which > 2) { set_error("act_mx_to_nchw: which %d / planes %d", which, planes); return DISCO_EINVAL; }
     return launch_act_q_to_nchw(t, d_dst, ch, which - 1, (hipStream_t)stream);
@@ -1373,7 +1400,7 @@ int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const v
     if (d_res) {
         const Act rr = d->d2s ? flat_act(d_res, d->n, d->c_out / 4, 2 * ca.h_out, 2 * ca.w_out, d->res_planes, 0)
                               : flat_act(d_res, d->n, d->c_out, ca.h_out, ca.w_out, d->res_planes, 0);
-        ca.res = rr.p; ca.res_plane = (long)rr.plane;
+        ca.res = rr.p; ca.res_plane = (long)rr.plane; ca.res_sexp = d->res_sexp;
     }
     ca.act = d->act; ca.slope = d->slope; ca.sat = d_sat; ca.x2q = d->x2q ? 1 : 0;
     return launch_conv3x3_mx(ca, (hipStream_t)stream);
@@ -1410,7 +1437,7 @@ int disco_op_deconv4x4(const void* d_src, const void* d_packed_w, const float* d
     if (!d_src || !d_packed_w || !d_bias || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
     if (c_in % 16 || (4 * c_out) % 64) { set_error("deconv4x4: c_in %% 16 and c_out %% 16 required"); return DISCO_ESHAPE; }
     ConvArgs ca{};
-    ca.src[0] = {(const f16*)d_src, (long)n * h_in * w_in * c_in, c_in, h_in, w_in, 0};
+    ca.src[0] = {(const f16*)d_src, (long)n * h_in * w_in * c_in, c_in, h_in, w_in, 0, 0};
     ca.nsrc = 1; ca.n = n; ca.h_in = h_in; ca.w_in = w_in; ca.c_in = c_in; ca.stride = 1; ca.h_out = h_in; ca.w_out = w_in;
     ca.w = (const f16*)d_packed_w; ca.c_out = 4 * c_out; ca.c_out_pad = 4 * c_out; ca.bias = d_bias;
     ca.out = (f16*)d_out; ca.out_plane = (long)n * 4 * h_in * w_in * c_out; ca.d2s_c = c_out;

@@ -35,12 +35,16 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
 // ---- activation tensor ----------------------------------------------------------------------------
-// hi plane: channel-blocked [N][C/16][H][W][16] fp16 = fp16(x), always present.
-// lo plane (optional, `plane` != 0): same layout, fp16(x - hi), at p + plane   (the f16x3 kernel's second operand plane,
+// ONE power-of-two exponent per tensor, `sexp`, fixed at calibration time: every plane stores xs = x * 2^sexp (the largest |xs| of
+// the calibration images lands in [16, 32): 2^11 of fp16 headroom above, and values down to 2^-7 of the maximum keep a NORMAL fp16
+// lo word).  Rounds 1-2 stored x itself in the fp16 planes: a checkpoint whose activations are not O(1) overflowed fp16 (a hard
+// failure above 16 384) or pushed the lo plane into fp16 subnormals.  A consumer undoes the scale with exact power-of-two
+// multiplications folded into its epilogue parameters (conv: launch_conv3x3_mx) or applied to the fp32 sum (pooling).
+// hi plane: channel-blocked [N][C/16][H][W][16] fp16 = fp16(xs), always present.
+// lo plane (optional, `plane` != 0): same layout, fp16(xs - hi), at p + plane   (the f16x3 kernel's second operand plane,
 //   residual inputs, the pooling kernel).
 // q planes (optional, `q_off` != 0): fp8 e4m3 [N][C/32][2][H][W][32] at (char*)p + q_off: for every 32-channel block the
-//   plane a8 = fp8(x * 2^sexp) followed by the plane al8 = fp8((x - hi) * 2^(sexp + 11))   (the correction operands of
-//   conv3x3_mx_kernel).  sexp is a per-tensor power of two fixed at calibration time.
+//   plane a8 = fp8(xs) followed by the plane al8 = fp8((xs - hi) * 2^11)   (the correction operands of conv3x3_mx_kernel).
 //   q_kind 1: ONLY the al8 planes, [N][C/32][H][W][32] (1 byte per element): the operand of the f16x2+fp8 arithmetic, which
 //   keeps both fp16 products of the hi plane and sends just the activation residual through fp8.
 struct Act {
@@ -85,18 +89,20 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
     return a - b;
 }
 
-// 8 consecutive channels (the half `half` of a 16-channel block `blk`) of pixel `pix` of image `img` -> the planes of an act
+// 8 consecutive channels (the half `half` of a 16-channel block `blk`) of pixel `pix` of image `img` -> the planes of an act;
+// v: TRUE values, stored scaled by 2^sexp
 __device__ __forceinline__ void store_act8(f16* hi_p, long plane, long q_off, int sexp, long img, int blk, int half, long pix, long hw,
-                                            int nblk, const float* v, unsigned* sat = nullptr, int q_kind = 0) {
+                                            int nblk, const float* v_true, unsigned* sat = nullptr, int q_kind = 0) {
     f16x8 h, l;
-    float lo[8];
+    float v[8], lo[8];
+    const float sc = ldexpf(1.f, sexp);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { h[j] = (f16)v[j]; lo[j] = v[j] - (float)h[j]; l[j] = (f16)lo[j]; }
+    for (int j = 0; j < 8; ++j) { v[j] = v_true[j] * sc; h[j] = (f16)v[j]; lo[j] = v[j] - (float)h[j]; l[j] = (f16)lo[j]; }
     f16* o = hi_p + (((long)img * nblk + blk) * hw + pix) * 16 + half * 8;
     *reinterpret_cast<f16x8*>(o) = h;
     if (plane) *reinterpret_cast<f16x8*>(o + plane) = l;
     if (q_off) {
-        const float qs = ldexpf(1.f, sexp), qls = ldexpf(1.f, sexp + MX_LO_SHIFT);
+        const float qs = 1.f, qls = ldexpf(1.f, MX_LO_SHIFT);
         unsigned char* q = reinterpret_cast<unsigned char*>(hi_p) + q_off + (((long)img * (nblk >> 1) + (blk >> 1)) * (q_kind ? 1 : 2)) * hw * 32 + pix * 32 + (blk & 1) * 16 + half * 8;
         uint2 a, b;
         b.x = pack_fp8x4(lo[0] * qls, lo[1] * qls, lo[2] * qls, lo[3] * qls, sat); b.y = pack_fp8x4(lo[4] * qls, lo[5] * qls, lo[6] * qls, lo[7] * qls, sat);
@@ -118,6 +124,7 @@ struct ConvSrc {
     int c;           // channels of this source (multiple of 16)
     int h, w;        // stored size (half of logical when up)
     int up;          // nearest x2 upsample on read
+    int sexp;        // scale exponent of the tensor (both sources of a layer carry the same one)
 };
 
 struct ConvArgs {
@@ -135,6 +142,8 @@ struct ConvArgs {
     const float* bn_shift;
     const f16* res;     // residual (same layout as out) or null
     long res_plane;
+    int res_sexp;       // scale exponents of the residual and of the output tensor (0 for fp32 NCHW outputs)
+    int out_sexp;
     f16* out;
     long out_plane;
     float* out_f32;     // if set: fp32 NCHW output (n, c_out, h_out, w_out) instead of act planes
@@ -153,7 +162,7 @@ struct MxSrc {
     const f16* p;        // hi plane
     uint32_t q_off;      // bytes from p to the q planes
     int c, h, w, up;     // channels (multiple of 32), stored size, nearest x2 upsample on read
-    int sexp;            // scale exponent of the q planes
+    int sexp;            // scale exponent of the tensor
 };
 struct ConvMxArgs {
     MxSrc src[2];
@@ -170,10 +179,17 @@ struct ConvMxArgs {
     const float* bn_shift;
     const f16* res;           // residual: hi plane, lo plane at res + res_plane (res_plane 0: hi only)
     long res_plane;
+    int res_sexp;             // scale exponent of the residual tensor
+    // filled by the launcher from the exponents (exact powers of two): the epilogue computes
+    //     x = acc * acc_mul + bias * bias_mul [+ res * res_mul];  x = act(x);  x = x * (bn_scale * bns_mul) + bn_shift * bnh_mul
+    // in the domain 2^e_pre (e_pre = the sources' exponent with a BN, the output's without: activations are positively homogeneous;
+    // tanh / fp32 outputs: 0) and leaves x * 2^out_sexp; force_bn: run the affine with the defaults (1, 0) although the layer has no BN
+    float acc_mul, bias_mul, res_mul, bns_mul, bnh_mul;
+    int force_bn;
     f16* out;                 // hi plane
     long out_plane;           // != 0: also write the lo plane at out + out_plane
-    size_t out_q_off;         // != 0: also write the q planes at (char*)out + out_q_off with scale exponent out_sexp
-    int out_sexp;
+    size_t out_q_off;         // != 0: also write the q planes at (char*)out + out_q_off
+    int out_sexp;             // scale exponent of the output tensor (all planes; 0 for fp32 NCHW outputs)
     float* out_f32;
     int d2s_c;
     int act;
@@ -223,13 +239,14 @@ int launch_conv_c1(const float* d_gray, const float* d_w /*(cout,9)*/, const flo
                    const float* d_bn_shift, const Act& out, int c_out, int act, float slope, unsigned int* sat, hipStream_t s);
 
 // ---- layout conversion --------------------------------------------------------------------------
-int launch_nchw_to_act(const float* src, f16* dst, long plane, int n, int c, int h, int w, int c_pad, hipStream_t s);
-int launch_act_to_nchw(const f16* src, long plane, float* dst, int n, int c, int h, int w, int c_pad, hipStream_t s);
+int launch_nchw_to_act(const float* src, f16* dst, long plane, int n, int c, int h, int w, int c_pad, hipStream_t s, int sexp = 0);
+int launch_act_to_nchw(const f16* src, long plane, float* dst, int n, int c, int h, int w, int c_pad, hipStream_t s, int sexp = 0);
 
 // ---- superpixel ops -----------------------------------------------------------------------------
 // feature source for pooling: either act planes (c_act channels) and/or extra fp32 NCHW channels
 struct PoolArgs {
     const f16* feat_act; long feat_plane; int c_act;   // NHWC act features, channels [0,c_act)   (may be null)
+    float feat_mul;                                     // 2^-sexp of feat_act: hi + lo is multiplied by it (exact)
     const float* feat_nchw; int c_nchw;                 // fp32 NCHW features, channels [c_act, c_act+c_nchw)  (may be null)
     const float* feat_bc; int c_bc;                     // fp32 (H*W, c_bc) pixel-major features shared by every image of
                                                         // the batch (the per-pixel position encoding of --spix_pos); last

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
 
 // ---- layout converters -----------------------------------------------------------------------------
 __global__ void nchw_to_act_kernel(const float* __restrict__ src, f16* dst, long plane, int n, int c, int h, int w,
-                                   int c_pad) {
+                                   int c_pad, float sc) {
     const long total = (long)n * h * w * c_pad;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         // t enumerates the channel-blocked destination: ((img*C/16 + blk)*hw + p)*16 + lane16
@@ -82,7 +82,7 @@ __global__ void nchw_to_act_kernel(const float* __restrict__ src, f16* dst, long
         const int blk = (int)((q / hw) % (c_pad >> 4));
         const long img = q / (hw * (c_pad >> 4));
         const int ch = blk * 16 + l16;
-        const float v = ch < c ? src[(img * c + ch) * hw + p] : 0.f;
+        const float v = (ch < c ? src[(img * c + ch) * hw + p] : 0.f) * sc;
         const f16 hi = (f16)v;
         dst[t] = hi;
         dst[t + plane] = (f16)(v - (float)hi);
@@ -90,7 +90,7 @@ __global__ void nchw_to_act_kernel(const float* __restrict__ src, f16* dst, long
 }
 
 __global__ void act_to_nchw_kernel(const f16* __restrict__ src, long plane, float* dst, int n, int c, int h, int w,
-                                   int c_pad) {
+                                   int c_pad, float inv_sc) {
     const long total = (long)n * c * h * w;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const long hw = (long)h * w;
@@ -98,7 +98,7 @@ __global__ void act_to_nchw_kernel(const f16* __restrict__ src, long plane, floa
         const int ch = (int)((t / hw) % c);
         const long img = t / (hw * c);
         const long s = ((img * (c_pad >> 4) + (ch >> 4)) * hw + p) * 16 + (ch & 15);
-        dst[t] = (float)src[s] + (float)src[s + plane];
+        dst[t] = ((float)src[s] + (float)src[s + plane]) * inv_sc;
     }
 }
 
@@ -121,16 +121,16 @@ int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, c
     return DISCO_OK;
 }
 
-int launch_nchw_to_act(const float* src, f16* dst, long plane, int n, int c, int h, int w, int c_pad, hipStream_t s) {
+int launch_nchw_to_act(const float* src, f16* dst, long plane, int n, int c, int h, int w, int c_pad, hipStream_t s, int sexp) {
     const long total = (long)n * h * w * c_pad;
-    hipLaunchKernelGGL(nchw_to_act_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, dst, plane, n, c, h, w, c_pad);
+    hipLaunchKernelGGL(nchw_to_act_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, dst, plane, n, c, h, w, c_pad, ldexpf(1.f, sexp));
     DISCO_LAUNCH_CHECK("nchw_to_act_kernel");
     return DISCO_OK;
 }
 
-int launch_act_to_nchw(const f16* src, long plane, float* dst, int n, int c, int h, int w, int c_pad, hipStream_t s) {
+int launch_act_to_nchw(const f16* src, long plane, float* dst, int n, int c, int h, int w, int c_pad, hipStream_t s, int sexp) {
     const long total = (long)n * c * h * w;
-    hipLaunchKernelGGL(act_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, plane, dst, n, c, h, w, c_pad);
+    hipLaunchKernelGGL(act_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, plane, dst, n, c, h, w, c_pad, ldexpf(1.f, -sexp));
     DISCO_LAUNCH_CHECK("act_to_nchw_kernel");
     return DISCO_OK;
 }

@@ -24,17 +24,17 @@ __global__ void nchw_to_act_mx_kernel(const float* __restrict__ src, f16* __rest
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * nblk * hw) return;
     const long pix = idx % hw; const long t = idx / hw; const int blk = (int)(t % nblk); const int img = (int)(t / nblk);
-    const float qs = ldexpf(1.f, sexp), qls = ldexpf(1.f, sexp + MX_LO_SHIFT);
+    const float sc = ldexpf(1.f, sexp), qls = ldexpf(1.f, MX_LO_SHIFT);      // every plane stores x 2^sexp
     f16 hi[16], lo[16];
     unsigned char a8[16], l8[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int ch = blk * 16 + j;
-        const float v = ch < c ? src[((long)img * c + ch) * hw + pix] : 0.f;
+        const float v = (ch < c ? src[((long)img * c + ch) * hw + pix] : 0.f) * sc;
         hi[j] = (f16)v;
         const float l = v - (float)hi[j];
         lo[j] = (f16)l;
-        const float x = __builtin_amdgcn_fmed3f(v * qs, -448.f, 448.f), y = __builtin_amdgcn_fmed3f(l * qls, -448.f, 448.f);
+        const float x = __builtin_amdgcn_fmed3f(v, -448.f, 448.f), y = __builtin_amdgcn_fmed3f(l * qls, -448.f, 448.f);
         a8[j] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xff);
         l8[j] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(y, 0.f, 0, false) & 0xff);
     }
@@ -65,7 +65,7 @@ __global__ void act_amax_kernel(const f16* __restrict__ p, long elems, float* __
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));   // non-negative floats order like uints
 }
 
-// test helper: dequantised views of an act's q planes as fp32 NCHW: which = 0: a8 2^-sexp; 1: hi + al8 2^-(sexp+11)
+// test helper: dequantised views of an act's q planes as fp32 NCHW (true values): which = 0: a8 2^-sexp; 1: (hi + al8 2^-11) 2^-sexp
 __global__ void act_q_to_nchw_kernel(const f16* __restrict__ src, long q_off, int sexp, float* __restrict__ dst, int n, int c, int h, int w,
                                      int c_pad, int which, int q_kind) {
     const long hw = (long)h * w;
@@ -79,7 +79,7 @@ __global__ void act_q_to_nchw_kernel(const f16* __restrict__ src, long q_off, in
         return sg ? -f : f;
     };
     if (which == 0) dst[idx] = q_kind ? 0.f : ldexpf(dq(q[0]), -sexp);        // al8-only planes have no a8 view
-    else dst[idx] = (float)src[((long)img * (c_pad / 16) + (ch >> 4)) * hw * 16 + pix * 16 + (ch & 15)] + ldexpf(dq(q[q_kind ? 0 : hw * 32]), -(sexp + MX_LO_SHIFT));
+    else dst[idx] = ldexpf((float)src[((long)img * (c_pad / 16) + (ch >> 4)) * hw * 16 + pix * 16 + (ch & 15)] + ldexpf(dq(q[q_kind ? 0 : hw * 32]), -MX_LO_SHIFT), -sexp);
 }
 
 }  // namespace
@@ -203,6 +203,25 @@ void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map,
                 }
 }
 
+// The exact power-of-two factors that carry the accumulators (domain 2^sexp_in of the sources), the parameters and the residual
+// (2^res_sexp) into the domain the epilogue works in, and its result into the output's (2^out_sexp); see ConvMxArgs.
+static int fold_scales(ConvMxArgs& a, int sexp_in) {
+    const bool f32 = a.out_f32 != nullptr;
+    if (f32) a.out_sexp = 0;
+    for (int e : {sexp_in, a.out_sexp, a.res ? a.res_sexp : 0})
+        if (e < -60 || e > 60) { set_error("conv3x3: scale exponent %d outside [-60, 60]", e); return DISCO_EINVAL; }
+    const bool bn = a.bn_scale != nullptr;
+    const bool true_dom = f32 || a.act == DISCO_ACT_TANH;            // tanh and the fused softmax work on true values
+    a.force_bn = (!bn && true_dom && a.out_sexp != 0) ? 1 : 0;       // tanh into a scaled tensor: the affine (1, 0) carries the scale
+    const int e_pre = true_dom ? 0 : (bn ? sexp_in : a.out_sexp);    // ReLU / LeakyReLU / none are positively homogeneous
+    a.acc_mul = std::ldexp(1.f, e_pre - sexp_in);
+    a.bias_mul = std::ldexp(1.f, e_pre);
+    a.res_mul = std::ldexp(1.f, e_pre - (a.res ? a.res_sexp : 0));
+    a.bns_mul = std::ldexp(1.f, a.out_sexp - e_pre);
+    a.bnh_mul = std::ldexp(1.f, a.out_sexp);
+    return DISCO_OK;
+}
+
 int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
     ConvMxArgs a = a_in;
     if (a.nsrc < 1 || a.nsrc > 2) { set_error("conv3x3_mx: %d sources", a.nsrc); return DISCO_EINVAL; }
@@ -215,7 +234,7 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
         if (bytes >= ((size_t)1 << 32) || sp.q_off < per) { set_error("conv3x3_mx: activation tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", bytes); return DISCO_ESHAPE; }
         a.src_bytes[i] = (uint32_t)bytes;
         if ((size_t)sp.h * sp.w * 32 >= (1u << 30)) { set_error("conv3x3_mx: image too large for 30-bit in-image offsets"); return DISCO_ESHAPE; }
-        if (sp.sexp < -100 || sp.sexp > 100) { set_error("conv3x3_mx: scale exponent %d", sp.sexp); return DISCO_EINVAL; }
+        if (sp.sexp != a.src[0].sexp) { set_error("conv3x3_mx: the sources carry different scale exponents (%d, %d): tensors that are concatenated on read must share one", a.src[0].sexp, sp.sexp); return DISCO_ESTATE; }
         csum += sp.c;
     }
     if (csum != a.c_in) { set_error("conv3x3_mx: sources carry %d channels, layer takes %d", csum, a.c_in); return DISCO_ESHAPE; }
@@ -241,7 +260,7 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
     if (a.out_q_off && !a.out_f32 && (a.d2s_c > 0 ? a.d2s_c : a.c_out_pad) % 32) { set_error("conv3x3_mx: q planes need a multiple of 32 output channels"); return DISCO_ESHAPE; }
     if (a.act == DISCO_ACT_LRELU && !(a.slope >= 0.f && a.slope <= 1.f)) { set_error("conv3x3_mx: LeakyReLU slope %g outside [0, 1]", (double)a.slope); return DISCO_ESHAPE; }
     if (a.c_out > 32 && a.c_out % 64) { set_error("conv3x3_mx: c_out %d (>32) must be a multiple of 64", a.c_out); return DISCO_ESHAPE; }
-    if (a.out_sexp < -100 || a.out_sexp > 100) { set_error("conv3x3_mx: output scale exponent %d", a.out_sexp); return DISCO_EINVAL; }
+    if (int rc = fold_scales(a, a.src[0].sexp)) return rc;
     return dispatch_mx(a, s);
 }
 
@@ -256,7 +275,8 @@ int launch_conv3x3_x3(const ConvArgs& c, hipStream_t s) {
         const size_t bytes = (size_t)sp.plane * 2 + per;
         if (bytes >= ((size_t)1 << 32)) { set_error("conv3x3: activation tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", bytes); return DISCO_ESHAPE; }
         if ((size_t)sp.h * sp.w * 32 >= (1u << 30)) { set_error("conv3x3: image too large for 30-bit in-image offsets"); return DISCO_ESHAPE; }
-        a.src[i] = {sp.p, (uint32_t)((size_t)sp.plane * 2), sp.c, sp.h, sp.w, sp.up, 0};
+        if (sp.sexp != c.src[0].sexp) { set_error("conv3x3: the sources carry different scale exponents (%d, %d): tensors that are concatenated on read must share one", c.src[0].sexp, sp.sexp); return DISCO_ESTATE; }
+        a.src[i] = {sp.p, (uint32_t)((size_t)sp.plane * 2), sp.c, sp.h, sp.w, sp.up, sp.sexp};
         a.src_bytes[i] = (uint32_t)bytes;
         csum += sp.c;
     }
@@ -265,7 +285,7 @@ int launch_conv3x3_x3(const ConvArgs& c, hipStream_t s) {
     a.h_out = c.h_out; a.w_out = c.w_out; a.stride = c.stride;
     a.w = c.w; a.wexp = nullptr; a.tapmask = c.tapmask; a.c_out = c.c_out; a.c_out_pad = c.c_out_pad;
     a.bias = c.bias; a.bn_scale = c.bn_scale; a.bn_shift = c.bn_shift;
-    a.res = c.res; a.res_plane = c.res_plane; a.out = c.out; a.out_plane = c.out_plane; a.out_f32 = c.out_f32;
+    a.res = c.res; a.res_plane = c.res_plane; a.res_sexp = c.res_sexp; a.out = c.out; a.out_plane = c.out_plane; a.out_f32 = c.out_f32; a.out_sexp = c.out_sexp;
     a.d2s_c = c.d2s_c; a.act = c.act; a.slope = c.slope; a.softmax = c.softmax; a.x3 = 1;
     {
         const size_t wb = (size_t)cdiv(c.c_out, 32) * (c.c_in / 16) * W_NB;          // = conv3x3_packed_bytes
@@ -286,6 +306,7 @@ int launch_conv3x3_x3(const ConvArgs& c, hipStream_t s) {
     if (c.d2s_c > 0 && (c.d2s_c % 16 || c.out_f32)) { set_error("conv3x3: depth-to-space needs a multiple of 16 channels (got %d) and an activation output", c.d2s_c); return DISCO_ESHAPE; }
     if (c.act == DISCO_ACT_LRELU && !(c.slope >= 0.f && c.slope <= 1.f)) { set_error("conv3x3: LeakyReLU slope %g outside [0, 1]", (double)c.slope); return DISCO_ESHAPE; }
     if (c.c_out > 32 && c.c_out % 64) { set_error("conv3x3: c_out %d (>32) must be a multiple of 64", c.c_out); return DISCO_ESHAPE; }
+    if (int rc = fold_scales(a, c.src[0].sexp)) return rc;
     return dispatch_mx(a, s);
 }
 

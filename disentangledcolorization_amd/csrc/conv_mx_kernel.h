@@ -10,11 +10,12 @@
 // products (conv_mfma2.hip), and the fp8 passes draw less power, so the power-managed clock stays higher
 // (profiles/r02_mfma_mix.txt: 54 vs 40 G units/s on random operands).
 //
-// Data formats (common.h, struct Act): fp16 hi plane [N][C/16][H][W][16]; q planes [N][C/32][2][H][W][32] fp8 e4m3 holding
-// a8 = fp8(a 2^sexp) and al8 = fp8((a - a_h) 2^(sexp+11)) with ONE power-of-two scale per tensor (fixed at calibration);
-// weights per output channel co: w8 = fp8(w 2^wexp[co]), wl8 = fp8((w - w_h) 2^(wexp[co]+11)).  The hardware applies
-// 2^-(sexp + wexp[co] + 11) to every fp8 product through the instruction's E8M0 scale operands (uniform for the pixel
-// operand, per lane = per output channel for the weight operand).
+// Data formats (common.h, struct Act): ONE power-of-two scale 2^sexp per tensor (fixed at calibration), carried by every plane:
+// as = a 2^sexp; fp16 hi plane [N][C/16][H][W][16] = a_h = fp16(as); q planes [N][C/32][2][H][W][32] fp8 e4m3 holding a8 = fp8(as)
+// and al8 = fp8((as - a_h) 2^11); weights per output channel co: w8 = fp8(w 2^wexp[co]), wl8 = fp8((w - w_h) 2^(wexp[co]+11)).  The
+// hardware applies 2^-(wexp[co] + 11) to every fp8 product through the instruction's E8M0 scale operand of the weight side (per lane
+// = per output channel; the pixel side's is 1), so all products of a tile accumulate in the sources' domain 2^sexp; the epilogue
+// moves to the output's with exact power-of-two factors folded into its parameters (ConvMxArgs::acc_mul ...).
 //
 // XQ = true selects a second arithmetic on the same skeleton, for the layers whose output decides discrete results downstream:
 //
@@ -159,14 +160,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         const int co = by * NT * 32 + c;
         const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;
         const float* src = which == 0 ? a.bias : (which == 1 ? a.bn_scale : a.bn_shift);
-        s_par[i] = (src && co < a.c_out) ? src[cpar] : (which == 1 ? 1.f : 0.f);
+        // exact power-of-two factors carry the parameters into the domains the epilogue works in (ConvMxArgs::acc_mul ...)
+        const float pm = which == 0 ? a.bias_mul : (which == 1 ? a.bns_mul : a.bnh_mul);
+        s_par[i] = ((src && co < a.c_out) ? src[cpar] : (which == 1 ? 1.f : 0.f)) * pm;
     }
 
     // E8M0 scale operands of the fp8 products: weight side per lane (= per output channel row), pixel side uniform per source
     int wsc[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) wsc[j] = X3 ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];
-    const int asc0 = 127 - a.src[0].sexp, asc1 = 127 - a.src[NSRC2 ? 1 : 0].sexp;
+    constexpr int asc0 = 127, asc1 = 127;          // pixel-side E8M0 scale: 1 (the tensor's scale stays in the accumulators)
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[0].p, 0, a.src_bytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[NSRC2 ? 1 : 0].p, 0, a.src_bytes[NSRC2 ? 1 : 0], 0x00020000);
@@ -413,7 +416,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     KArgs& a = *ep;                   // shadows the by-value argument inside the epilogue
     const int act = a.act;
     const float slope = a.slope;
-    const bool has_bn = a.bn_scale != nullptr;
+    const bool has_bn = a.bn_scale != nullptr || a.force_bn != 0;
+    const float acc_mul = a.acc_mul, res_mul = a.res_mul;
     auto epilogue = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;      // 0: channel-blocked act, 1: depth-to-space act, 2: fp32 NCHW
         const int oc = MODE == 1 ? a.d2s_c : a.c_out_pad;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         const unsigned ohw = (unsigned)(oh * ow);
         const bool wr_lo = MODE != 2 && a.out_plane != 0, wr_q = MODE != 2 && a.out_q_off != 0;
         const bool ql_only = a.out_q_kind != 0;              // al8-only q planes: one byte per element, no a8 plane
-        const float qs = __builtin_ldexpf(1.f, a.out_sexp), qls = __builtin_ldexpf(1.f, a.out_sexp + MX_LO_SHIFT);
+        constexpr float qs = 1.f;             // the epilogue leaves x 2^out_sexp: the fp8 planes take it as it is
         const __amdgpu_buffer_rsrc_t ro = MODE == 2 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.out_f32, 0, a.out_bytes, 0x00020000)
                                                     : __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
         // scalar byte offsets per channel group (nt, q): hi plane (the lo plane is out_plane*2 further), a8 plane (al8 is
@@ -460,8 +464,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         // activation as x = max(x, x slope + 0): ReLU = slope 0 (the "+ 0" turns -0 into +0, as fmaxf(x, 0) does), none = slope 1
         const float slope_e = act == DISCO_ACT_RELU ? 0.f : (act == DISCO_ACT_LRELU ? slope : 1.f);
         const f32x2 slope2 = {slope_e, slope_e}, zero2 = {0.f, 0.f};
-        // the scaled conversions divide by their scale operand: 2^-sexp and 2^-(sexp + 11)
-        const float qinv = __builtin_ldexpf(1.f, -a.out_sexp), qlinv = __builtin_ldexpf(1.f, -(a.out_sexp + MX_LO_SHIFT));
+        // the scaled conversions divide by their scale operand: 1 and 2^-11
+        const float qinv = 1.f, qlinv = __builtin_ldexpf(1.f, -MX_LO_SHIFT);
+        const f32x2 acc_mul2 = {acc_mul, acc_mul}, res_mul2 = {res_mul, res_mul};
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
@@ -472,8 +477,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
                         const float4 b4 = *(const __attribute__((address_space(3))) float4*)(par_e + cl);
-                        x[2 * g4] = f32x2{acc[mt][nt][4 * g4], acc[mt][nt][4 * g4 + 1]} + f32x2{b4.x, b4.y};
-                        x[2 * g4 + 1] = f32x2{acc[mt][nt][4 * g4 + 2], acc[mt][nt][4 * g4 + 3]} + f32x2{b4.z, b4.w};
+                        x[2 * g4] = __builtin_elementwise_fma(f32x2{acc[mt][nt][4 * g4], acc[mt][nt][4 * g4 + 1]}, acc_mul2, f32x2{b4.x, b4.y});
+                        x[2 * g4 + 1] = __builtin_elementwise_fma(f32x2{acc[mt][nt][4 * g4 + 2], acc[mt][nt][4 * g4 + 3]}, acc_mul2, f32x2{b4.z, b4.w});
                     }
                     if (a.res) {
                         // residual (same shape and hi-plane layout as the output, its own allocation), plus its lo plane if any
@@ -492,8 +497,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #pragma unroll
                             for (int d = 0; d < 2; ++d) {
                                 const f32x2 h2 = {(float)rh[g4][2 * d], (float)rh[g4][2 * d + 1]}, l2 = {(float)rl[g4][2 * d], (float)rl[g4][2 * d + 1]};
-                                if (X3) x[2 * g4 + d] += h2 + l2;                          // conv_mfma2's form: x + (hi + lo)
-                                else { x[2 * g4 + d] += h2; x[2 * g4 + d] += l2; }       // (no lo plane: l2 = 0)
+                                if (X3) x[2 * g4 + d] = __builtin_elementwise_fma(h2 + l2, res_mul2, x[2 * g4 + d]);      // x + (hi + lo) 2^k
+                                else {                                                                                 // (no lo plane: l2 = 0)
+                                    x[2 * g4 + d] = __builtin_elementwise_fma(h2, res_mul2, x[2 * g4 + d]);
+                                    x[2 * g4 + d] = __builtin_elementwise_fma(l2, res_mul2, x[2 * g4 + d]);
+                                }
                             }
                     }
 #ifndef MX_DEV_MODE
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         // leaves 14x headroom: only when a value of this block is beyond the range (|al8| <= |a8| by construction, so
                         // max |x| decides; wave-uniform test) its operands are clamped first - in place, and counted
                         if (__builtin_expect(__ballot(!(bmax * qs <= 448.f)) != 0ull, 0)) {
-                            const float lim = 448.f * qinv, liml = 448.f * qlinv;
+                            const float lim = 448.f, liml = 448.f * qlinv;
                             unsigned cnt = 0;
 #pragma unroll
                             for (int p = 0; p < 8; ++p)
@@ -618,7 +626,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
                     const float4 b4 = *(const __attribute__((address_space(3))) float4*)(par_e + cl);
-                    float x[4] = {acc[mt][nt][4 * g4] + b4.x, acc[mt][nt][4 * g4 + 1] + b4.y, acc[mt][nt][4 * g4 + 2] + b4.z, acc[mt][nt][4 * g4 + 3] + b4.w};
+                    float x[4] = {fmaf(acc[mt][nt][4 * g4], acc_mul, b4.x), fmaf(acc[mt][nt][4 * g4 + 1], acc_mul, b4.y), fmaf(acc[mt][nt][4 * g4 + 2], acc_mul, b4.z),
+                                  fmaf(acc[mt][nt][4 * g4 + 3], acc_mul, b4.w)};
                     if (act == DISCO_ACT_RELU) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);

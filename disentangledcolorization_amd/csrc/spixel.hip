@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
             const f16x8 l = *reinterpret_cast<const f16x8*>(s16 + off + a.feat_plane);
             float f[8], pr[9];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (float)h[j] + (float)l[j];
+            for (int j = 0; j < 8; ++j) f[j] = ((float)h[j] + (float)l[j]) * a.feat_mul;
 #pragma unroll
             for (int c = 0; c < 9; ++c) pr[c] = sp_prob[p * 9 + c];
 #pragma unroll
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
                         if (a.sp == 16) { py = p >> 4; px = p & 15; } else { py = p / a.sp; px = p - py * a.sp; }
                         const int off = py * rowstride + px * pstride;
                         if (ch == C) f[u] = 1.f;
-                        else if (s16) f[u] = (float)s16[off] + (float)s16[off + plane];
+                        else if (s16) f[u] = ((float)s16[off] + (float)s16[off + plane]) * a.feat_mul;
                         else f[u] = s32[off];
                     }
                 }

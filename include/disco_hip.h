@@ -193,6 +193,8 @@ typedef struct disco_conv_desc {
     int32_t act;               /* DISCO_ACT_* applied after bias (+residual) */
     float slope;
     int32_t precision;         /* DISCO_PREC_F16X3 (this entry point runs the f16x3 arithmetic; the others: disco_op_conv3x3_mx) */
+    int32_t sexp_in, sexp_out, sexp_res;   /* scale exponents of the sources (both the same), the output and the residual: every plane
+                                  of an activation buffer stores x 2^sexp (0 = the plain values disco_op_nchw_to_act writes) */
 } disco_conv_desc;
 
 /* Pack an effective fp32 OIHW 3x3 weight (host) for the MFMA kernel; returns bytes needed when
@@ -204,9 +206,10 @@ int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d
                      void *d_out, void *stream);
 
 /* ---- conv3x3 with an fp16 main product and fp8 (e4m3, K = 64 MFMA) correction products (csrc/conv_mx.hip) -----------
- * Activation buffers of this path: the fp16 hi plane [N][C/16][H][W][16], then (planes bit 0) the fp16 lo plane, then
- * (planes bit 1) the fp8 q planes [N][C/32][2][H][W][32]: a8 = fp8(x 2^sexp) and al8 = fp8((x - hi) 2^(sexp+11)), one
- * power-of-two scale per tensor.  C is padded to a multiple of 16 (32 with q planes). */
+ * Activation buffers of this path carry ONE power-of-two scale per tensor, xs = x 2^sexp, in every plane: the fp16 hi plane
+ * [N][C/16][H][W][16] = fp16(xs), then (planes bit 0) the fp16 lo plane fp16(xs - hi), then (planes bit 1) the fp8 q planes
+ * [N][C/32][2][H][W][32]: a8 = fp8(xs) and al8 = fp8((xs - hi) 2^11).  C is padded to a multiple of 16 (32 with q planes).
+ * (sexp puts the tensor's largest |xs| into [16, 32): fp16 keeps 2^11 of headroom, fp8's +-448 a factor 14.) */
 #define DISCO_PLANE_LO 1
 #define DISCO_PLANE_Q 2
 #define DISCO_PLANE_QL 4   /* instead of DISCO_PLANE_Q: only the al8 planes, [N][C/32][H][W][32] (operands of the x2q arithmetic) */
@@ -228,6 +231,7 @@ typedef struct disco_conv_mx_desc {
     int32_t out_sexp;
     int32_t out_f32;           /* 1: d_out is fp32 NCHW */
     int32_t res_planes;        /* DISCO_PLANE_* bits of the residual buffer (its lo plane is used when present) */
+    int32_t res_sexp;          /* scale exponent of the residual buffer */
     int32_t x2q;               /* 1: the f16x2 + fp8 arithmetic: one source with DISCO_PLANE_QL planes, c_in0 a multiple of 64,
                                   weights packed with x2q = 1 */
     int32_t d2s;               /* 1: depth-to-space epilogue (the sub-pixel up-convs / transposed convs of the forward): c_out = 4 C

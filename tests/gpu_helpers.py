@@ -33,6 +33,15 @@ def from_act(a, c=None):
     return out
 
 
+def to_act_scaled(x, sexp):
+    """As to_act, every plane storing x 2^sexp (exact: a power of two)."""
+    return to_act(x.float() * 2.0 ** sexp)
+
+
+def from_act_scaled(a, sexp, c=None):
+    return from_act(a, c) * 2.0 ** -sexp
+
+
 def pack_conv(w):
     """(Cout,Cin,3,3) fp32 cpu -> packed device buffer."""
     w = w.detach().cpu().float().contiguous()
@@ -46,8 +55,9 @@ def pack_conv(w):
 
 
 def conv3x3(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, act=_ffi.ACT_NONE, slope=0.0,
-            bn_scale=None, bn_shift=None, res=None, precision=_ffi.PREC_F16X3):
-    """HIP conv on act tensors; returns the act output.  src*: (2,N,h,w,C) fp16."""
+            bn_scale=None, bn_shift=None, res=None, precision=_ffi.PREC_F16X3, sexp_in=0, sexp_out=0, sexp_res=0):
+    """HIP conv on act tensors; returns the act output.  src*: (2,N,h,w,C) fp16.  sexp_*: the scale exponents the buffers carry
+    (to_act_scaled / from_act_scaled below convert with one)."""
     n = src0.shape[1]
     h_in = src0.shape[2] * (2 if up0 else 1)
     w_in = src0.shape[3] * (2 if up0 else 1)
@@ -55,7 +65,7 @@ def conv3x3(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, ac
     c1 = src1.shape[4] if src1 is not None else 0
     co = w.shape[0]
     packed = pack_conv(w)
-    d = _ffi.ConvDesc(n, h_in, w_in, c0, c1, int(up0), int(up1), co, stride, act, slope, precision)
+    d = _ffi.ConvDesc(n, h_in, w_in, c0, c1, int(up0), int(up1), co, stride, act, slope, precision, sexp_in, sexp_out, sexp_res)
     ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
     out = torch.empty(2, n, ho, wo, co, device=DEV, dtype=torch.float16)
     dv = lambda t: None if t is None else t.to(DEV).float().contiguous()
@@ -125,7 +135,7 @@ def conv3x3_mx(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1,
     ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
     d = _ffi.ConvMxDesc(src0.n, h_in, w_in, src0.c_pad, src1.c_pad if src1 is not None else 0, int(up0), int(up1), src0.sexp,
                         src1.sexp if src1 is not None else 0, co, stride, act, slope, out_planes, out_sexp, int(out_f32),
-                        res.planes if res is not None else 0, int(x2q), int(d2s))
+                        res.planes if res is not None else 0, res.sexp if res is not None else 0, int(x2q), int(d2s))
     out = torch.empty(src0.n, co, ho, wo, device=DEV, dtype=torch.float32) if out_f32 else (
         MxAct(src0.n, co // 4, 2 * ho, 2 * wo, out_planes, out_sexp) if d2s else MxAct(src0.n, co, ho, wo, out_planes, out_sexp))
     sat = torch.zeros(1, device=DEV, dtype=torch.int32)

@@ -345,8 +345,17 @@ def test_precision_mode_x2q_against_oracle(synth_sd, q_to_ab):
     torch.cuda.synchronize()
     assert m.saturation_count() == 0
     _seed(130); want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=8).forward(gray, ab)
-    assert torch.equal(out[5].cpu(), want[5]), "anchors"
-    assert _err(out[0], want[0]) < 5e-5 and _err(out[2], want[2]) <= AB_TOL
+    # the continuous measure first: pal_logit within 5e-5 of the fp32 oracle (measured 1.4e-5).  Anchors are a discrete decision on
+    # k-means near-ties: this opt-in arithmetic disagrees with the fp32 oracle in 0.66 % of images (profiles/r02_anchor_stability.txt;
+    # the fp32 oracle itself with an fp64 evaluation in 0.6 %), so at most one of the four images may differ - those that agree must
+    # meet the ab bar
+    pal_err = _err(out[0], want[0])
+    assert pal_err < 5e-5, pal_err
+    same = [bool(torch.equal(out[5][i].cpu(), want[5][i])) for i in range(n)]
+    assert sum(same) >= n - 1, same
+    for i in range(n):
+        if same[i]:
+            assert _err(out[2][i], want[2][i]) <= AB_TOL
     # a single image of the batch run alone: bit-identical (same accumulation order whatever tile serves the layer)
     _seed(130); np.random.choice(256, 8, replace=False)
     one = m(gray[1:2].cuda(), ab[1:2].cuda(), True, 0)
@@ -426,8 +435,6 @@ def test_fp8_saturation_counter_and_calibration_record(synth_sd):
     import ctypes as C
     from disentangledcolorization_amd import _ffi
     from disentangledcolorization_amd.model import default_precision
-    if default_precision() in ("f16x3", "f16x1"):
-        pytest.skip("no fp8 planes under $DISCO_PRECISION=%s" % default_precision())
     m = _model(synth_sd, 8)
     gray, ab = synth.synth_inputs(2, 128, 128, seed=3)
     _seed(1)
@@ -443,9 +450,13 @@ def test_fp8_saturation_counter_and_calibration_record(synth_sd):
         key, amax, sexp = C.c_char_p(), C.c_float(), C.c_int()
         _ffi.check(L.disco_calibration_entry(m._ctx, i, C.byref(key), C.byref(amax), C.byref(sexp)))
         seen[key.value.decode()] = (amax.value, sexp.value)
-        assert 0 <= amax.value <= 16384
+        assert amax.value >= 0
+        tied = key.value.decode() in ("gray16", "enhanceNet.up2.conv1", "enhanceNet.up1.conv1") or ".deconv" in key.value.decode()
         if amax.value > 0:
-            assert 16 <= amax.value * 2.0 ** sexp.value < 32
+            if tied:      # concatenated on read with an earlier tensor: that one's exponent (Plan::calibrate)
+                assert 1 / 64 <= amax.value * 2.0 ** sexp.value <= 8192
+            else:
+                assert 16 <= amax.value * 2.0 ** sexp.value < 32
     assert "enhanceNet.up1.conv2.2" in seen and "upfeat" in seen and "repnet.conv5_3.4" in seen
     # user calibration on the caller's own images: ranges only widen, results stay within the parity bar and the anchors
     # (decided upstream on f16x3) do not move
@@ -502,3 +513,50 @@ def test_colorize_mixed_shapes_equals_per_file_loop(synth_sd):
     for one, grp in zip(loop, got):
         for k in (0, 2, 5):
             assert torch.equal(one[k], grp[k])
+
+
+def _stress_variant(sd, which):
+    """Checkpoints whose activations are NOT O(1) (the synthetic checkpoint's BN statistics were calibrated to keep them there):
+    a block scaled up / down by 2^8 between two BatchNorms, a spectral-norm layer whose u vector makes sigma 16x too small, and the
+    same in the HourGlass2 with its skip connection.  The downstream BN statistics (or the skip's weights) are adjusted so that the
+    network stays finite; the fp32 oracle evaluates the very same tensors."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    def bn_out(key, f):
+        sd[key + ".weight"] *= f; sd[key + ".bias"] *= f
+    def bn_in(key, f):
+        sd[key + ".running_mean"] *= f; sd[key + ".running_var"] *= f * f
+    if which == "repnet_x256":
+        bn_out("repnet.conv2_3.6", 256.0); bn_in("repnet.conv3_3.6", 256.0)
+    elif which == "repnet_x1_256":
+        bn_out("repnet.conv2_3.6", 1 / 256.0); bn_in("repnet.conv3_3.6", 1 / 256.0)
+    elif which == "sn_sigma_16":
+        sd["repnet.conv4_3.2.weight_u"] /= 16.0                 # sigma = u.(W v) is 16x too small -> effective weights 16x larger
+        bn_in("repnet.conv4_3.6", 16.0)
+    elif which == "enhance_skip_x256":
+        bn_out("enhanceNet.down1.conv.4", 256.0)                # e2: feeds down2 and, through the skip connection, up2.combine
+        bn_in("enhanceNet.down2.conv.4", 256.0)
+        sd["enhanceNet.up2.combine.weight"][:, 128:] /= 256.0  # cat(up(conv1(x)), e2): the e2 half
+    else:
+        raise KeyError(which)
+    return sd
+
+
+@pytest.mark.parametrize("which", ["repnet_x256", "repnet_x1_256", "sn_sigma_16", "enhance_skip_x256"])
+def test_checkpoints_with_activations_far_from_one(synth_sd, q_to_ab, which):
+    """Checkpoint-agnostic numerics (round 3): every activation tensor carries one power-of-two exponent fixed by the calibration
+    forward, so a checkpoint whose activations run at 2^8 or 2^-8 of the synthetic one's goes through the same arithmetic at the
+    same relative precision - rounds 1-2 stored raw values in fp16 and failed above 16 384 / lost the lo plane below.  Against the
+    fp32 oracle at the usual tolerances, anchors exact."""
+    sd = _stress_variant(synth_sd, which)
+    m = AnchorColorProb(n_clusters=8, enhanced=True, init_weights=False)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    n = 2
+    gray, ab = synth.synth_inputs(n, 128, 128, seed=19)
+    _seed(130); out = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    assert m.saturation_count() == 0
+    _seed(130); want = R.DiscoOracle(sd, q_to_ab, n_clusters=8).forward(gray, ab)
+    assert torch.isfinite(want[2]).all() and want[2].abs().max() < 0.999, "the stress checkpoint must stay an informative comparison"
+    assert torch.equal(out[5].cpu(), want[5]), "anchors"
+    assert _err(out[0], want[0]) < LOGIT_TOL * max(1.0, want[0].abs().max().item()) and _err(out[2], want[2]) <= AB_TOL

@@ -98,6 +98,27 @@ def test_conv3x3_is_run_to_run_deterministic_and_lo_exact(H, case):
     assert (outs[0] - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("exps", [(3, 5, 5), (-9, -6, -4), (12, 14, 10), (0, 4, 0)])
+@pytest.mark.parametrize("use_bn", [False, True])
+def test_conv3x3_scale_exponents(H, exps, use_bn):
+    """One power-of-two exponent per activation tensor (common.h, struct Act): sources stored as x 2^sexp_in, residual as
+    r 2^sexp_res, the output leaves as y 2^sexp_out; the epilogue folds the exact factors into its parameters.  Results must equal
+    the unscaled run to fp32 rounding (they are bit-identical unless a plane leaves fp16's normal range), for inputs whose true
+    magnitudes make fp16 storage impossible without the exponent (x ~ 2^-sexp_in)."""
+    e_in, e_out, e_res = exps
+    gen = g(77 + e_in)
+    cin, cout, h, w = 64, 64, 20, 36
+    x = torch.randn(2, cin, h, w, generator=gen) * 2.0 ** -e_in           # e.g. |x| ~ 4000 for e_in = -12: beyond fp16 for sums
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1 * 2.0 ** -e_in
+    res = torch.randn(2, cout, h, w, generator=gen) * 2.0 ** -e_res
+    bn = (torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.1 * 2.0 ** -e_in) if use_bn else None
+    want = _ref_conv(x.double(), wt.double(), b.double(), 1, _ffi.ACT_LRELU, 0.2, (bn[0].double(), bn[1].double()) if bn else None, res.double())
+    got = H.from_act_scaled(H.conv3x3(H.to_act_scaled(x, e_in), wt, b, act=_ffi.ACT_LRELU, slope=0.2, bn_scale=bn[0] if bn else None,
+                                      bn_shift=bn[1] if bn else None, res=H.to_act_scaled(res, e_res), sexp_in=e_in, sexp_out=e_out, sexp_res=e_res), e_out)
+    assert H.max_err(got, want) < 2e-5 * want.abs().max().item()
+
+
 S2_CASES = [
     # cin, cout, h, w, act, slope, bn   (stride 2)
     (64, 128, 64, 96, _ffi.ACT_LRELU, 0.2, True),
@@ -135,7 +156,7 @@ def test_op_entry_points_reject_bad_sizes(H):
                L.disco_op_encoder_stack(_ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), 0, 16, _ffi.ptr(t), 1 << 20, H.stream()),
                L.disco_op_rgb8_to_lab(_ffi.ptr(t), _ffi.ptr(t), _ffi.ptr(t), None, 1, 8, 8, 4, 8, H.stream())):
         assert rc < 0 and L.disco_last_error()
-    d = _ffi.ConvDesc(1, 16, 16, 24, 0, 0, 0, 16, 1, _ffi.ACT_NONE, 0.0, 0, 0)          # 24 input channels: not a multiple of 16
+    d = _ffi.ConvDesc(1, 16, 16, 24, 0, 0, 0, 16, 1, _ffi.ACT_NONE, 0.0, 0)          # 24 input channels: not a multiple of 16
     assert L.disco_op_conv3x3(C.byref(d), _ffi.ptr(t), None, _ffi.ptr(t), None, None, None, None, _ffi.ptr(t), H.stream()) < 0
     d = _ffi.ConvDesc(0, 16, 16, 16, 0, 0, 0, 16, 1, _ffi.ACT_NONE, 0.0, 0, 0)
     assert L.disco_op_conv3x3(C.byref(d), _ffi.ptr(t), None, _ffi.ptr(t), None, None, None, None, _ffi.ptr(t), H.stream()) < 0
