@@ -176,7 +176,9 @@ struct disco_ctx {
     std::vector<void*> allocs;
     std::map<std::string, ConvLayer> conv;
     std::map<std::string, DirectLayer> direct;
-    std::map<std::string, int> sexp;     // mx: scale exponent of the q planes of every tensor, by producer (set by calibration)
+    std::map<std::string, int> sexp;     // scale exponent of every activation tensor, by producer (set by calibration)
+    std::map<std::string, int> sexp_nat; // calibration: the exponent each tensor would take on its own (max |x| 2^e in [16, 32))
+    std::map<std::string, std::string> tie;   // tensor -> the earlier tensor it is concatenated with on read (they share one exponent)
     std::map<std::string, float> amax;   // calibration: max |x| of every conv output (fp16 range guard, diagnostics)
     unsigned int* d_sat = nullptr;       // mx: q-plane elements that had to be clamped since the last read
     bool calibrated = false;
@@ -542,8 +544,9 @@ struct Plan {
     // subnormals, move it by 2^10 and produce again; then fix the exponent so that the maximum lands in [16, 32) - 2^11 of fp16
     // headroom (and 14x of fp8's +-448) for other inputs, values down to 2^-7 of the maximum keep a normal fp16 lo word - and
     // produce once more with the final exponent.  `tie`: a tensor that is concatenated on read with an earlier one (skip
-    // connections; the conv accumulates both sources in ONE domain) takes the earlier tensor's exponent, which must then leave its
-    // own values inside fp16's comfortable range - otherwise this checkpoint cannot run and the error names the layer.
+    // connections; the conv accumulates both sources in ONE domain) runs this pass on the earlier tensor's current exponent; after
+    // the pass the pair takes the SMALLER of the two natural exponents (calibrate_ctx), so that neither leaves the [16, 32) target
+    // upwards (the fp8 planes clamp at 448).  A pair whose ranges differ by more than 2^12 cannot share a scale: the error names it.
     template <class F>
     void calibrate(const std::string& key, Act& t, F&& produce, const std::string& tie = "") {
         if (!calib || dry || !ok()) return;
@@ -575,16 +578,19 @@ struct Plan {
         c->amax[key] = amax;
         int e = 0;
         if (amax > 0.f) { std::frexp(amax, &e); e = 5 - e; }                // amax 2^e in [16, 32)
+        c->sexp_nat[key] = e;
         if (!tie.empty()) {
             auto it = c->sexp.find(tie);
             if (it == c->sexp.end()) { set_error("calibration order: %s is tied to %s, which has no exponent yet", key.c_str(), tie.c_str()); rc = DISCO_ESTATE; return; }
-            const float tied = std::ldexp(amax, it->second);
-            if (amax > 0.f && !(tied <= 8192.f && tied >= 1.f / 64.f)) {
+            auto nt = c->sexp_nat.find(tie);
+            const int e_tie = nt == c->sexp_nat.end() ? it->second : nt->second;
+            if (amax > 0.f && c->amax[tie] > 0.f && std::abs(e - e_tie) > 12) {
                 set_error("%s and %s are concatenated on read and must share one scale, but their ranges differ too much (max |x| %g vs %g): "
                           "this checkpoint cannot run in fp16 hi/lo arithmetic", key.c_str(), tie.c_str(), (double)amax, (double)c->amax[tie]);
                 rc = DISCO_EUNSUPPORTED; return;
             }
-            e = it->second;
+            c->tie[key] = tie;
+            e = it->second;           // this pass: the partner's current exponent (the concat conv needs equal ones)
         }
         c->sexp[key] = e;
         if (t.sexp != e) { t.sexp = e; produce(); }
@@ -945,7 +951,16 @@ int calibrate_ctx(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, 
         if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) rc = hip_fail(hipGetLastError(), "calibration forward");
     }
     for (void* b : bufs) if (b) hipFree(b);
-    if (!rc) c->calibrated = true;
+    if (!rc) {
+        // tensors that are concatenated on read: the pair shares the smaller natural exponent (an all-zero member does not count)
+        for (const auto& kv : c->tie) {
+            const bool z0 = c->amax[kv.first] == 0.f, z1 = c->amax[kv.second] == 0.f;
+            const int e0 = c->sexp_nat[kv.first], e1 = c->sexp_nat[kv.second];
+            const int g = z0 ? e1 : (z1 ? e0 : std::min(e0, e1));
+            c->sexp[kv.first] = g; c->sexp[kv.second] = g;
+        }
+        c->calibrated = true;
+    }
     return rc;
 }
 

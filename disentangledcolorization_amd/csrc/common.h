@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <atomic>
 #include <stddef.h>
 #include "../../include/disco_hip.h"
 
@@ -223,6 +224,27 @@ void conv3x3_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map,
 constexpr int DISCO_MAX_DEVICES = 64;
 // ordinal of the calling thread's current HIP device, clamped into [0, DISCO_MAX_DEVICES) (per-device one-time setup tables)
 inline int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0; return d % DISCO_MAX_DEVICES; }
+// One-time per-device setup of a kernel's dynamic-LDS limit.  `done` is a zero-initialised table of DISCO_MAX_DEVICES flags (one table
+// per kernel / instantiation); an entry is set only after hipFuncSetAttribute SUCCEEDED, so a failing first call is reported by every
+// launch instead of being swallowed by a consumed once-flag (two threads racing here both set the same value: harmless).
+inline hipError_t set_dyn_lds_once(std::atomic<int>* done, const void* kern, int bytes) {
+    std::atomic<int>& f = done[current_device()];
+    if (f.load(std::memory_order_acquire)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) f.store(1, std::memory_order_release);
+    return e;
+}
+// compute units of the calling thread's current device (cached per device ordinal)
+inline int num_cus_current() {
+    static std::atomic<int> table[DISCO_MAX_DEVICES];
+    std::atomic<int>& t = table[current_device()];
+    int v = t.load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    t.store(v, std::memory_order_relaxed);
+    return v;
+}
 int diag_mfma_rate(int mode, int iters, double* tflops);   // diag.hip
 // ConvTranspose2d(4,s2,p1) weight (c_in,c_out,4,4) -> equivalent 3x3 conv weight (4*c_out, c_in, 3, 3), phase-major
 void deconv_as_conv3x3_host(const float* h_w_iohw, int c_in, int c_out, float* h_w_oihw);

@@ -725,14 +725,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #endif
 }
 
-inline int num_cus_mx() {
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
-}
+inline int num_cus_mx() { return num_cus_current(); }
 
 template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0>
 int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
@@ -742,12 +735,8 @@ int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR>;
     // function attributes are per device and per kernel instantiation (this static lives in the instantiation)
-    static std::once_flag attr_once[DISCO_MAX_DEVICES];
-    hipError_t attr_err = hipSuccess;
-    std::call_once(attr_once[current_device()], [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    });
-    DISCO_HIP_CHECK(attr_err);
+    static std::atomic<int> attr_done[DISCO_MAX_DEVICES];
+    DISCO_HIP_CHECK(set_dyn_lds_once(attr_done, reinterpret_cast<const void*>(kern), smem));
     const int combos = cdiv(a.w_out, TW) * cdiv(a.h_out, TH) * cdiv(a.c_out, 32 * NT);
     int groups = a.n;
     {

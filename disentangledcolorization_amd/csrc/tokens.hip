@@ -957,13 +957,8 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         {
             PostAttnArgs pa{att, cur, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, dst, T};
             constexpr size_t smem = POST_ATTN_SMEM;
-            static std::once_flag attr_once[DISCO_MAX_DEVICES];      // per device; two host threads may get here together
-            hipError_t attr_err = hipSuccess;
-            std::call_once(attr_once[current_device()], [&] {
-                attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(post_attention_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            });
-            DISCO_HIP_CHECK(attr_err);
+            static std::atomic<int> attr_done[DISCO_MAX_DEVICES];      // per device; two host threads may get here together
+            DISCO_HIP_CHECK(set_dyn_lds_once(attr_done, reinterpret_cast<const void*>(post_attention_kernel), (int)smem));
             hipLaunchKernelGGL(post_attention_kernel, dim3(cdiv(T, 64)), dim3(256), smem, s, pa);
             DISCO_LAUNCH_CHECK("post_attention_kernel");
         }
@@ -1037,12 +1032,8 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
     // the dynamic-LDS limit is a per-device attribute of each kernel: the three instantiations share one function-pointer
     // type (so one lambda body), hence the table is keyed by variant index, not by a static inside the lambda
     auto launch = [&](auto kern, int variant, size_t smem) -> int {
-        static std::once_flag attr_once[3][DISCO_MAX_DEVICES];
-        hipError_t err = hipSuccess;
-        std::call_once(attr_once[variant][current_device()], [&] {
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM);
-        });
-        DISCO_HIP_CHECK(err);
+        static std::atomic<int> attr_done[3][DISCO_MAX_DEVICES];
+        DISCO_HIP_CHECK(set_dyn_lds_once(attr_done[variant], reinterpret_cast<const void*>(kern), MAX_SMEM));
         hipLaunchKernelGGL(kern, dim3(n), dim3(1024), smem, s, x, d, img_stride, t_stride, c_stride, sizes, init_idx,
                            fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
         return DISCO_OK;
@@ -1057,12 +1048,8 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
         // scan fallback: one int of LDS per token on top of the kernel's static arrays
         const size_t scan_smem = (size_t)l * sizeof(int);
         if (scan_smem > (size_t)MAX_SMEM) { set_error("kmeans: %d tokens exceed what one workgroup can index in LDS (%d)", l, MAX_SMEM / 4); return DISCO_ESHAPE; }
-        static std::once_flag scan_once[DISCO_MAX_DEVICES];
-        hipError_t err = hipSuccess;
-        std::call_once(scan_once[current_device()], [&] {
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_anchor_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SMEM);
-        });
-        DISCO_HIP_CHECK(err);
+        static std::atomic<int> scan_done[DISCO_MAX_DEVICES];
+        DISCO_HIP_CHECK(set_dyn_lds_once(scan_done, reinterpret_cast<const void*>(kmeans_anchor_scan_kernel<false>), MAX_SMEM));
         hipLaunchKernelGGL(kmeans_anchor_scan_kernel<false>, dim3(n), dim3(256), scan_smem, s, x, d, img_stride,
                            t_stride, c_stride, sizes, init_idx, fallback_rows, max_fallback, assign, anchor, hint_mask, info, l, k);
     }

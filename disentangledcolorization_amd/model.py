@@ -163,12 +163,18 @@ class AnchorColorProb(nn.Module):
         self.rank = rank
         self.precision = _PRECISIONS[precision or default_precision()]
         self.sync_kmeans_events = True   # emulate the reference's torch.randint fallback draws (one sync per forward)
+        # The activation scales (one power-of-two exponent per tensor; the fp8 planes of the default precision have 14x headroom)
+        # are fixed at load time on two SYNTHETIC images.  The first `range_checks` forwards of a context therefore read the clamp
+        # counter (one host synchronisation each): if the caller's images clamped anything, the context is re-calibrated on those
+        # very images (ranges only widen) and the batch is run again, with a warning.  0 switches the check off.
+        self.range_checks = 3
         self._build_tree()
         self._ctx = None
         self._ctx_device = None
         self._workspace = None
         self._ws_need = {}
         self._keep = None
+        self._range_checks_left = {}
         if init_weights:
             from .synth import synth_state_dict
             super().load_state_dict(synth_state_dict(130, hint2regress=self.hint2regress), strict=True)
@@ -239,9 +245,9 @@ class AnchorColorProb(nn.Module):
         return ctx
 
     def calibrate(self, input_grays):
-        """Widen the fp8 activation scales of the mx8 mode with the ranges of the caller's own L images (N<=64,1,H,W);
-        blocking.  The context is already calibrated on synthetic images at load time - use this when `saturation_count()`
-        reports clamping on real data."""
+        """Widen the activation ranges (the per-tensor scale exponents) with those of the caller's own L images (N<=64,1,H,W);
+        blocking.  The context is calibrated on two synthetic images at load time, and the first `range_checks` forwards
+        re-calibrate by themselves when they clamp; call this up front with representative images to avoid that re-run."""
         g = input_grays.contiguous().float()
         if not g.is_cuda or g.dim() != 4 or g.shape[1] != 1:
             raise ValueError("expected a CUDA/HIP tensor (N,1,H,W)")
@@ -448,6 +454,16 @@ class AnchorColorProb(nn.Module):
                 if want_events and int(events.max()) > MF:
                     raise _ffi.DiscoError("k-means used more than %d empty-cluster draws" % MF)
                 self._keep = (init_idx, rows, events)
+            left = self._range_checks_left.get(id(ctx), self.range_checks)
+            if left > 0:
+                self._range_checks_left = {id(ctx): left - 1}
+                clamped = self.saturation_count()
+                if clamped:
+                    import warnings
+                    warnings.warn("%d fp8 activation values were clamped: this input is outside the ranges the context was calibrated on "
+                                  "(two synthetic images at load time); re-calibrating on this batch and running it again" % clamped)
+                    self.calibrate(gray[:64])
+                    return self.forward_once(gray, ab, test_mode, sampled_T, init_idx, hint_pos, fallback_stream, fallback_bases, want_events)
         if rep > 1:
             aff_out = aff.expand(rep, -1, -1, -1) if n == 1 else aff.repeat_interleave(rep, 0)
             mask_out = mask.expand(rep, -1, -1, -1) if n == 1 else mask.repeat_interleave(rep, 0)

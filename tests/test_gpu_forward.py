@@ -451,12 +451,11 @@ def test_fp8_saturation_counter_and_calibration_record(synth_sd):
         _ffi.check(L.disco_calibration_entry(m._ctx, i, C.byref(key), C.byref(amax), C.byref(sexp)))
         seen[key.value.decode()] = (amax.value, sexp.value)
         assert amax.value >= 0
-        tied = key.value.decode() in ("gray16", "enhanceNet.up2.conv1", "enhanceNet.up1.conv1") or ".deconv" in key.value.decode()
-        if amax.value > 0:
-            if tied:      # concatenated on read with an earlier tensor: that one's exponent (Plan::calibrate)
-                assert 1 / 64 <= amax.value * 2.0 ** sexp.value <= 8192
-            else:
-                assert 16 <= amax.value * 2.0 ** sexp.value < 32
+        if amax.value > 0:      # (a tensor that is concatenated on read with another shares the pair's smaller exponent)
+            assert 1 / 256 <= amax.value * 2.0 ** sexp.value < 32
+    for a_, b_ in (("gray16", "upfeat"), ("enhanceNet.up2.conv1", "enhanceNet.down1.conv.2"), ("enhanceNet.up1.conv1", "enhanceNet.inConv.conv.0"),
+                   ("segnet.net.deconv3.0", "segnet.net.conv3b.0"), ("segnet.net.deconv0.0", "segnet.net.conv0b.0")):
+        assert seen[a_][1] == seen[b_][1] and 16 <= max(seen[a_][0], seen[b_][0]) * 2.0 ** seen[a_][1] < 32
     assert "enhanceNet.up1.conv2.2" in seen and "upfeat" in seen and "repnet.conv5_3.4" in seen
     # user calibration on the caller's own images: ranges only widen, results stay within the parity bar and the anchors
     # (decided upstream on f16x3) do not move
@@ -560,3 +559,31 @@ def test_checkpoints_with_activations_far_from_one(synth_sd, q_to_ab, which):
     assert torch.isfinite(want[2]).all() and want[2].abs().max() < 0.999, "the stress checkpoint must stay an informative comparison"
     assert torch.equal(out[5].cpu(), want[5]), "anchors"
     assert _err(out[0], want[0]) < LOGIT_TOL * max(1.0, want[0].abs().max().item()) and _err(out[2], want[2]) <= AB_TOL
+
+
+def test_out_of_range_input_recalibrates_itself(synth_sd, q_to_ab):
+    """The scales are fixed at load time on two synthetic images with |L| <= 1.  An input 400x outside that range clamps the fp8 planes
+    (14x headroom; the gray plane shares the exponent of the up-sampled features it is concatenated with, which leaves it some more):
+    one of the first forwards of a context notices (clamp counter), warns, re-calibrates on that very batch and runs it again, so the
+    correction products work again instead of silently degrading to plain-fp16 accuracy.  (The activations of this absurd input are
+    400x the usual ones and most outputs sit in tanh's saturation, so the comparison is relative to the un-recalibrated run.)"""
+    gray, ab = synth.synth_inputs(2, 128, 128, seed=23)
+    gray = gray * 400.0
+    _seed(130); want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=8).forward(gray, ab)
+    errs = {}
+    for checks in (0, 3):
+        m = AnchorColorProb(n_clusters=8, enhanced=True, init_weights=False)
+        m.load_state_dict(synth_sd)
+        m = m.cuda().eval()
+        m.range_checks = checks
+        _seed(130)
+        if checks:
+            with pytest.warns(UserWarning, match="re-calibrating"):
+                out = m(gray.cuda(), ab.cuda(), True, 0)
+        else:
+            out = m(gray.cuda(), ab.cuda(), True, 0)
+        torch.cuda.synchronize()
+        assert (m.saturation_count() == 0) == bool(checks)
+        assert torch.equal(out[5].cpu(), want[5])              # the anchors are decided on the f16x3 stacks: no fp8 planes there
+        errs[checks] = _err(out[2], want[2])
+    assert errs[3] < 0.5 * errs[0] and errs[3] <= 1e-2, errs

@@ -88,9 +88,10 @@ def main():
             if args.mx in (1, 3):
                 continue
         hs = hin // 2 if up0 else hin
-        src0 = torch.randn(2, n, hs, hs, c0, device="cuda").half()
-        src1 = torch.randn(2, n, hin, hin, c1, device="cuda").half() if c1 else None
-        w = torch.randn(co, c0 + c1, 3, 3) * 0.05
+        z = 0.0 if args.zeros else 1.0       # --zeros: the same launch on all-zero operands (how much of the time is the power-managed clock?)
+        src0 = (z * torch.randn(2, n, hs, hs, c0, device="cuda")).half()
+        src1 = (z * torch.randn(2, n, hin, hin, c1, device="cuda")).half() if c1 else None
+        w = torch.randn(co, c0 + c1, 3, 3) * 0.05 * z
         packed = H.pack_conv(w)
         ho = (hin - 1) // stride + 1
         out = torch.empty(2, n, ho, ho, co, device="cuda", dtype=torch.float16)

@@ -63,6 +63,10 @@ def main():
             marked = basic.mark_color_hints(gray, pred_ab, gates, base_ABs=pred_ab)
             Image.fromarray(basic.normLabs_to_rgb8(marked, H, W)[0].cpu().numpy()).save(os.path.join(args.out, stem + "-anchors.png"))
         print("colorized", path, "(%dx%d)" % (W, H))
+    clamped = model.saturation_count()
+    if clamped:       # (the first forwards of a context re-calibrate by themselves; this catches later images)
+        print("warning: %d fp8 activation values were clamped on these images - call model.calibrate(gray) on representative inputs" % clamped,
+              file=sys.stderr)
 
 
 if __name__ == "__main__":

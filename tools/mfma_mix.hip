@@ -19,6 +19,9 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // MIX 3: fp8 K=64 only
 // MIX 4: per accumulator and K=64: 4 f16 + 1 fp8 K=64
 // MIX 5: per accumulator and K=64: 8 f16 + 1 fp8 K=64   (w_h a_h + w_l a_h in fp16, only the activation residual in fp8: "x2q")
+// MIX 6: f16x3 CHAINED: the 12 MFMAs of four 16-channel blocks (w_lo a_hi, w_hi a_lo, w_hi a_hi each) back to back on ONE accumulator,
+//        then the next accumulator - the issue pattern of MIX 2-5 (MIX 1 rotates over the 4 accumulators: issue-limited even on zeros)
+// MIX 7: plain f16, chained the same way (12 per accumulator)
 template <int MIX, int WPS>
 __global__ __launch_bounds__(WPS * 256) void loop_kernel(const f16x8* __restrict__ ops, const i32x8* __restrict__ ops8,
                                                           float* __restrict__ out, unsigned long long* __restrict__ clk, int iters) {
@@ -47,6 +50,15 @@ __global__ __launch_bounds__(WPS * 256) void loop_kernel(const f16x8* __restrict
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[i], al, acc[i], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[i], a[i], acc[i], 0, 0, 0);
+        } else if (MIX == 6 || MIX == 7) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(MIX == 6 ? bl : b[(i + k + 1) & 3], a[k], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[(i + k) & 3], MIX == 6 ? al : a[(k + 1) & 3], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[(i + k) & 3], a[k], acc[i], 0, 0, 0);
+                }
         } else if (MIX == 2 || MIX == 4 || MIX == 5) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -96,7 +108,7 @@ template <int MIX, int WPS>
 static void run(const char* name, const f16x8* d_ops, const i32x8* d_ops8, float* d_out, unsigned long long* d_clk, int cus, int iters, int reps) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int blocks = cus * 4;     // several workgroups per CU over the run
-    const double mf16 = MIX == 0 || MIX == 1 ? 12 : (MIX == 3 ? 0 : (MIX == 5 ? 32 : 16)), m8 = MIX == 2 ? 8 : (MIX == 3 ? 8 : (MIX == 4 || MIX == 5 ? 4 : 0));
+    const double mf16 = MIX == 0 || MIX == 1 ? 12 : (MIX == 6 || MIX == 7 ? 48 : (MIX == 3 ? 0 : (MIX == 5 ? 32 : 16))), m8 = MIX == 2 ? 8 : (MIX == 3 ? 8 : (MIX == 4 || MIX == 5 ? 4 : 0));
     for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
         hipLaunchKernelGGL((loop_kernel<MIX, WPS>), dim3(blocks), dim3(WPS * 256), 0, 0, d_ops, d_ops8, d_out, d_clk, iters);
@@ -165,6 +177,9 @@ int main(int argc, char** argv) {
         run<0, 1>("f16 32x32x16 (distinct hi operands)", d_ops, d_ops8, d_out, d_clk, cus, long_iters, 2);
         run<1, 2>("f16x3 mix (hi*lo, lo*hi, hi*hi)", d_ops, d_ops8, d_out, d_clk, cus, long_iters, 3);
         run<1, 1>("f16x3 mix (hi*lo, lo*hi, hi*hi)", d_ops, d_ops8, d_out, d_clk, cus, long_iters, 2);
+        run<6, 2>("f16x3 mix, CHAINED per accumulator", d_ops, d_ops8, d_out, d_clk, cus, long_iters / 4, 3);
+        run<6, 1>("f16x3 mix, CHAINED per accumulator", d_ops, d_ops8, d_out, d_clk, cus, long_iters / 4, 2);
+        run<7, 2>("f16 32x32x16, CHAINED per accumulator", d_ops, d_ops8, d_out, d_clk, cus, long_iters / 4, 3);
         run<3, 2>("fp8 e4m3 32x32x64 only", d_ops, d_ops8, d_out, d_clk, cus, long_iters, 3);
         run<2, 2>("4 f16 + 2 fp8-K64 per K=64 (f16 + 2 fp8 corr.)", d_ops, d_ops8, d_out, d_clk, cus, long_iters * 3 / 4, 3);
         run<2, 1>("4 f16 + 2 fp8-K64 per K=64 (f16 + 2 fp8 corr.)", d_ops, d_ops8, d_out, d_clk, cus, long_iters * 3 / 4, 2);
