@@ -239,6 +239,7 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
     }
     if (csum != a.c_in) { set_error("conv3x3_mx: sources carry %d channels, layer takes %d", csum, a.c_in); return DISCO_ESHAPE; }
     if (a.x2q && a.nsrc != 1) { set_error("conv3x3_mx: the f16x2+fp8 arithmetic takes one source"); return DISCO_ESHAPE; }
+    if (a.nsrc > 1 && (a.out_f32 || a.d2s_c > 0)) { set_error("conv3x3_mx: a two-source layer writes a plain activation tensor (no fp32 NCHW / depth-to-space output)"); return DISCO_ESHAPE; }
     {
         const size_t wb = conv_mx_packed_bytes(a.c_out, a.c_in, a.x2q);
         if (wb >= ((size_t)1 << 32)) { set_error("conv3x3_mx: packed weights too large"); return DISCO_ESHAPE; }
@@ -281,6 +282,7 @@ int launch_conv3x3_x3(const ConvArgs& c, hipStream_t s) {
         csum += sp.c;
     }
     if (csum != c.c_in) { set_error("conv3x3: sources carry %d channels, layer takes %d", csum, c.c_in); return DISCO_ESHAPE; }
+    if (c.nsrc > 1 && (c.out_f32 || c.d2s_c > 0)) { set_error("conv3x3: a two-source layer writes a plain activation tensor (no fp32 NCHW / depth-to-space output)"); return DISCO_ESHAPE; }
     a.nsrc = c.nsrc; a.n = c.n; a.h_in = c.h_in; a.w_in = c.w_in; a.c_in = c.c_in;
     a.h_out = c.h_out; a.w_out = c.w_out; a.stride = c.stride;
     a.w = c.w; a.wexp = nullptr; a.tapmask = c.tapmask; a.c_out = c.c_out; a.c_out_pad = c.c_out_pad;

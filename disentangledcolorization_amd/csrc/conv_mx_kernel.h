@@ -234,8 +234,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             if (part >= 0 && i / APT != part) continue;
             const int piece = i * NWAVE + wave;
             if ((i + 1) * NWAVE <= A_PIECES || piece < A_PIECES) {      // only the last round of pieces needs the run-time test
-                if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(dA + piece * 1024), 16, voff[NS - 1][i], soff, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(dA + piece * 1024), 16, voff[0][i], soff, 0, 0);
+                // (the offset is selected by VALUE: with the two calls behind an if / else the optimiser merged them into one call that
+                // loads its offset through a phi of POINTERS into voff - which put voff into scratch memory, read back inside the tap loop)
+                unsigned v0 = voff[0][i], v1 = voff[NS - 1][i];
+                if (NSRC2) asm("" : "+v"(v0), "+v"(v1));          // opaque values: no select-of-loads folding
+                const unsigned vsel = s1 ? v1 : v0;
+                if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(dA + piece * 1024), 16, vsel, soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(dA + piece * 1024), 16, vsel, soff, 0, 0);
             }
         }
 #pragma unroll
@@ -460,7 +465,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         // (profiles/r02_conv_pmc.txt: 4.1 VALU per MFMA on the f16+fp8x2 instantiation against 0.23 inside its tap loop).
         // Results are bit-identical to that code (tools/cvt_scale_probe.hip pins the scaled conversion against mul + v_med3 + cvt on
         // everything that rounds into the finite range; beyond it the instruction yields the NaN code, hence the slow path below).
-        unsigned lpark[MT][NTW][8];                          // lo words of the tile (live only when the output has a lo AND q planes)
         // activation as x = max(x, x slope + 0): ReLU = slope 0 (the "+ 0" turns -0 into +0, as fmaxf(x, 0) does), none = slope 1
         const float slope_e = act == DISCO_ACT_RELU ? 0.f : (act == DISCO_ACT_LRELU ? slope : 1.f);
         const f32x2 slope2 = {slope_e, slope_e}, zero2 = {0.f, 0.f};
@@ -597,11 +601,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         }
                     }
                     // All output words are parked in the accumulator registers and stored in phase 3: hi in 0-7; f16x3: lo in 8-15;
-                    // otherwise a8 in 8-11, al8 in 12-15 and the lo words (residual-chain tensors only) in lpark.  (The lo words used to be
-                    // stored right here, "to free their registers", and the next (mt, nt) iteration's first VALU write could land in a
-                    // data register of that store one instruction behind it: the store-data hazard described at buffer_store_b128() -
-                    // lanes 12-15 / 28-31 of one dword arrived stale in the lo plane, differently from run to run.  Found when the f16x3
-                    // arithmetic - where every layer writes a lo plane - moved onto this kernel.)
+                    // otherwise a8 in 8-11, al8 in 12-15, and the lo words of the few tensors that carry lo AND fp8 planes (the HourGlass2's
+                    // residual chain) are stored right here through buffer_store_b128(), whose wait states cover the store-data hazard that
+                    // round 2 ran into at this very place (a plain store, the next iteration's first VALU write in a data register one
+                    // instruction behind it: lanes 12-15 / 28-31 of one dword arrived stale, differently from run to run).  Parking them
+                    // in 32 more registers pushed the two-source instantiation to 256 VGPRs and its SGPR spills into scratch memory.
 #pragma unroll
                     for (int d = 0; d < 8; ++d) acc[mt][nt][d] = __builtin_bit_cast(float, hd[d]);
                     if constexpr (X3) {
@@ -609,8 +613,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         for (int d = 0; d < 8; ++d) acc[mt][nt][8 + d] = __builtin_bit_cast(float, ld[d]);
                     } else {
                         if (wr_lo) {
+                            const int cob = (by_e * NT + wn * NTW + nt) * 32;
 #pragma unroll
-                            for (int d = 0; d < 8; ++d) lpark[mt][nt][d] = ld[d];
+                            for (int q = 0; q < 2; ++q) {
+                                const bool cok = cob + 16 * q + 8 * kh < a.c_out;
+                                const unsigned vb = (vo[mt] == OOB || !cok) ? OOB : vo[mt] + 16u * kh;
+                                buffer_store_b128(i32x4{(int)ld[4 * q], (int)ld[4 * q + 1], (int)ld[4 * q + 2], (int)ld[4 * q + 3]}, ro, vb, so_hi[nt][q] + (unsigned)a.out_plane * 2u);
+                            }
                         }
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -685,9 +694,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         const unsigned vb = (vo[mt] == OOB || !cok) ? OOB : vo[mt];
                         const i32x4 d4 = {__float_as_int(t[4 * q]), __float_as_int(t[4 * q + 1]), __float_as_int(t[4 * q + 2]), __float_as_int(t[4 * q + 3])};
                         buffer_store_b128(d4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q]);
-                        if (wr_lo) {
-                            const i32x4 l4 = X3 ? i32x4{__float_as_int(t[8 + 4 * q]), __float_as_int(t[9 + 4 * q]), __float_as_int(t[10 + 4 * q]), __float_as_int(t[11 + 4 * q])}
-                                                : i32x4{(int)lpark[mt][nt][4 * q], (int)lpark[mt][nt][4 * q + 1], (int)lpark[mt][nt][4 * q + 2], (int)lpark[mt][nt][4 * q + 3]};
+                        if (X3) {       // (the other arithmetics stored their lo words in phase 1)
+                            const i32x4 l4 = {__float_as_int(t[8 + 4 * q]), __float_as_int(t[9 + 4 * q]), __float_as_int(t[10 + 4 * q]), __float_as_int(t[11 + 4 * q])};
                             buffer_store_b128(l4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u);
                         }
                         if (wr_q) {
@@ -712,7 +720,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #ifdef MX_DEV_MODE       // ISA inspection builds: one epilogue mode only
     epilogue(std::integral_constant<int, MX_DEV_MODE>{});
 #else
-    if (a.out_f32) epilogue(std::integral_constant<int, 2>{});
+    // two-source (concat-on-read) layers only ever write plain activation tensors (the launchers refuse anything else): their
+    // instantiations carry ONE epilogue, which keeps them under the register budget without scratch memory (round 2: 59-87 SGPR
+    // spills through 32 B/lane of scratch in the instantiation that serves inConv.inConv.0 and both `combine` layers)
+    if constexpr (NSRC2) epilogue(std::integral_constant<int, 0>{});
+    else if (a.out_f32) epilogue(std::integral_constant<int, 2>{});
     else if (a.d2s_c > 0) epilogue(std::integral_constant<int, 1>{});
     else epilogue(std::integral_constant<int, 0>{});
 #endif

@@ -162,12 +162,17 @@ int main(int argc, char** argv) {
     f16x8* d_ops; i32x8* d_ops8; float* d_out; unsigned long long* d_clk;
     hipMalloc(&d_ops, h.size() * 2); hipMalloc(&d_ops8, h8.size()); hipMalloc(&d_out, 4); hipMalloc(&d_clk, 16);
     const int long_iters = argc > 1 ? atoi(argv[1]) : 20000;
-    for (int data = 0; data < 2; ++data) {
-        printf("==== operand data: %s ====\n", data == 0 ? "zeros" : "N(0,1) fp16 hi, 2^-11-scaled lo, random e4m3 bytes");
+    const int ndata = argc > 2 ? atoi(argv[2]) : 2;      // > 2: also the toggle-rate experiments (lo operands with their low mantissa bits cleared)
+    for (int data = 0; data < ndata; ++data) {
+        const int lo_clear = data == 2 ? 5 : (data == 3 ? 8 : 0);
+        printf("==== operand data: %s%s ====\n", data == 0 ? "zeros" : "N(0,1) fp16 hi, 2^-11-scaled lo, random e4m3 bytes",
+               data == 2 ? "; lo operands: low 5 mantissa bits cleared" : (data == 3 ? "; lo operands: low 8 mantissa bits cleared; hi operands ReLU-like (half zeros)" : ""));
         for (size_t i = 0; i < h.size(); ++i) {
             float v = data == 0 ? 0.f : gauss();
             if (i >= 8 * 64 * 8) v *= 4.8e-4f;
+            else if (data == 3 && i < 4 * 64 * 8 && v < 0.f) v = 0.f;       // a[] = pixel operands
             h[i] = (_Float16)v;
+            if (lo_clear && i >= 8 * 64 * 8) { unsigned short b; memcpy(&b, &h[i], 2); b &= (unsigned short)~((1u << lo_clear) - 1u); memcpy(&h[i], &b, 2); }
         }
         for (auto& v : h8) { v = data == 0 ? 0 : (rand() & 0xff); if ((v & 0x7f) == 0x7f) v &= 0xfe; }
         hipMemcpy(d_ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
