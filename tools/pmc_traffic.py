@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """HBM bytes per conv launch from two rocprofv3 PMC passes (run on the GPU box, see the recipe below) ->
-profiles/r02_pmc_traffic.json, which bench.py reports as roofline.traffic (it carries the hash of the conv sources it was measured
+profiles/r03_pmc_traffic.json, which bench.py reports as roofline.traffic (it carries the hash of the conv sources it was measured
 on; bench.py reports null when the sources have changed since).
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o fetch --output-format csv -- \
-        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
+        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --micro 1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o write --output-format csv -- \
         python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
     python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/pmc_traffic.json
@@ -20,17 +20,29 @@ import os
 import sys
 
 
+FORWARDS = 9          # full 64-image forwards of `bench.py --steps 1 --warmup 1 --micro 1`: 2 initial + 1 warm-up + 1 timed + 1 exactness check + 4 profiled
+PER_FORWARD = 69      # MFMA conv launches per forward
+
+
 def total(dirname, counter):
+    """Sum of `counter` over the conv launches of the full-size forwards.  The calibration pass of disco_finalize (2 images, every producer
+    at least twice) comes first in dispatch order and is dropped: its launches are ~3 % of a 64-image launch each and would only dilute
+    a per-launch average."""
     files = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit("no counter_collection.csv under " + dirname)
-    s, launches = 0.0, 0
+    rows = []
     for f in files:
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if row.get("Counter_Name") == counter and ("conv3x3_mfma2_kernel" in row.get("Kernel_Name", "") or "conv3x3_mx_kernel" in row.get("Kernel_Name", "")):
-                    s += float(row["Counter_Value"]); launches += 1
-    return s, launches
+                if row.get("Counter_Name") == counter and "conv3x3_mx_kernel" in row.get("Kernel_Name", ""):
+                    rows.append((int(row.get("Dispatch_Id", len(rows))), float(row["Counter_Value"])))
+    rows.sort()
+    keep = FORWARDS * PER_FORWARD
+    if len(rows) < keep:
+        raise SystemExit("%d conv launches, expected at least %d" % (len(rows), keep))
+    rows = rows[len(rows) - keep:]
+    return sum(v for _, v in rows), len(rows)
 
 
 def main():
@@ -46,10 +58,10 @@ def main():
     json.dump({
         "source_hash": bench.source_hash(),
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
-                  "`python bench.py --steps 1 --warmup 1` (tools/pmc_traffic.py)",
+                  "`python bench.py --steps 1 --warmup 1 --no-alt --micro 1` (tools/pmc_traffic.py)",
         "unit_note": "counter unit is KiB; per MI355X_MICROARCH.md the gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of "
                      "wide coalesced streaming reads, so reads are doubled below; WRITE_SIZE is uncalibrated and taken as is",
-        "conv_launches (conv3x3_mx_kernel, all arithmetics; conv3x3_mfma2_kernel if any)": nf, "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
+        "conv_launches (conv3x3_mx_kernel, all arithmetics; 64-image forwards only: the calibration pass is dropped)": nf, "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
         "hbm_read_bytes_per_launch_corrected": int(rd), "hbm_write_bytes_per_launch": int(wr),
         "hbm_bytes_per_launch": int(rd + wr)}, open(out, "w"), indent=1)
     print(open(out).read())
