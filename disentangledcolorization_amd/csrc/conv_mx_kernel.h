@@ -71,6 +71,9 @@ __device__ __forceinline__ void buffer_store_b128(i32x4 d, __amdgpu_buffer_rsrc_
     // the descriptor / offset are reloaded with v_readlane_b32 right in front of the store.  Found in round 3 (tools/conv_determinism_probe.py):
     // the masked depth-to-space instantiation of the f16x2+fp8 arithmetic (116 spilled SGPRs) wrote its hi plane through stale offsets,
     // differently from run to run.
+    // (readfirstlane: the offset is wave-uniform by construction, but in a few instantiations the compiler keeps it in a VGPR, which an
+    // "s" constraint turns into a compile error; where it already lives in an SGPR this folds away)
+    soff = __builtin_amdgcn_readfirstlane(soff);
     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(d), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 
