@@ -420,7 +420,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     // (constant address space: the loads are scalar and everything derived from them stays wave-uniform)
     typedef const __attribute__((address_space(4))) ConvMxArgs KArgs;
     KArgs* ep = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(by_e), "+s"(oy0_e), "+s"(ox0_e), "+v"(par_e), "+s"(ep));
+    // (two statements: an asm with any VGPR output makes ALL its outputs divergent for the compiler - the scalar offsets derived from
+    // by_e then lived in VGPRs, and the residual loads that take them as soffset ran in waterfall loops)
+    asm volatile("" : "+s"(by_e), "+s"(oy0_e), "+s"(ox0_e), "+s"(ep));
+    asm volatile("" : "+v"(par_e));
     KArgs& a = *ep;                   // shadows the by-value argument inside the epilogue
     const int act = a.act;
     const float slope = a.slope;

@@ -22,6 +22,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // MIX 6: f16x3 CHAINED: the 12 MFMAs of four 16-channel blocks (w_lo a_hi, w_hi a_lo, w_hi a_hi each) back to back on ONE accumulator,
 //        then the next accumulator - the issue pattern of MIX 2-5 (MIX 1 rotates over the 4 accumulators: issue-limited even on zeros)
 // MIX 7: plain f16, chained the same way (12 per accumulator)
+// MIX 8 / 9: as MIX 2 with the K=64 instruction's operands declared fp6 (e2m3) / fp4 (e2m1) - half the passes of fp8 if the pipe runs them
+//            at the 2x datasheet rate: would the correction products get cheaper?  (MIX 10 / 11: fp6 / fp4 K=64 only)
 template <int MIX, int WPS>
 __global__ __launch_bounds__(WPS * 256) void loop_kernel(const f16x8* __restrict__ ops, const i32x8* __restrict__ ops8,
                                                           float* __restrict__ out, unsigned long long* __restrict__ clk, int iters) {
@@ -59,6 +61,21 @@ __global__ __launch_bounds__(WPS * 256) void loop_kernel(const f16x8* __restrict
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[(i + k) & 3], MIX == 6 ? al : a[(k + 1) & 3], acc[i], 0, 0, 0);
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[(i + k) & 3], a[k], acc[i], 0, 0, 0);
                 }
+        } else if (MIX == 8 || MIX == 9) {
+            constexpr int F = MIX == 8 ? 2 : 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[(i + k) & 3], a[k], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[i & 1], a8[0], acc[i], F, F, 0, 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[0], a8[1], acc[i], F, F, 0, 0, 0, 0);
+            }
+        } else if (MIX == 10 || MIX == 11) {
+            constexpr int F = MIX == 10 ? 2 : 4;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[(i + r) & 1], a8[r], acc[i], F, F, 0, 0, 0, 0);
         } else if (MIX == 2 || MIX == 4 || MIX == 5) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -108,7 +125,7 @@ template <int MIX, int WPS>
 static void run(const char* name, const f16x8* d_ops, const i32x8* d_ops8, float* d_out, unsigned long long* d_clk, int cus, int iters, int reps) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int blocks = cus * 4;     // several workgroups per CU over the run
-    const double mf16 = MIX == 0 || MIX == 1 ? 12 : (MIX == 6 || MIX == 7 ? 48 : (MIX == 3 ? 0 : (MIX == 5 ? 32 : 16))), m8 = MIX == 2 ? 8 : (MIX == 3 ? 8 : (MIX == 4 || MIX == 5 ? 4 : 0));
+    const double mf16 = MIX == 0 || MIX == 1 ? 12 : (MIX == 6 || MIX == 7 ? 48 : (MIX == 3 || MIX >= 10 ? 0 : (MIX == 5 ? 32 : 16))), m8 = MIX == 2 || MIX == 8 || MIX == 9 ? 8 : (MIX == 3 || MIX >= 10 ? 8 : (MIX == 4 || MIX == 5 ? 4 : 0));
     for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
         hipLaunchKernelGGL((loop_kernel<MIX, WPS>), dim3(blocks), dim3(WPS * 256), 0, 0, d_ops, d_ops8, d_out, d_clk, iters);
@@ -187,6 +204,10 @@ int main(int argc, char** argv) {
         run<7, 2>("f16 32x32x16, CHAINED per accumulator", d_ops, d_ops8, d_out, d_clk, cus, long_iters / 4, 3);
         run<3, 2>("fp8 e4m3 32x32x64 only", d_ops, d_ops8, d_out, d_clk, cus, long_iters, 3);
         run<2, 2>("4 f16 + 2 fp8-K64 per K=64 (f16 + 2 fp8 corr.)", d_ops, d_ops8, d_out, d_clk, cus, long_iters * 3 / 4, 3);
+        run<8, 2>("4 f16 + 2 fp6-K64 per K=64 (units as if fp8)", d_ops, d_ops8, d_out, d_clk, cus, long_iters * 3 / 4, 3);
+        run<9, 2>("4 f16 + 2 fp4-K64 per K=64 (units as if fp8)", d_ops, d_ops8, d_out, d_clk, cus, long_iters * 3 / 4, 3);
+        run<10, 2>("fp6 e2m3 32x32x64 only (units as if fp8)", d_ops, d_ops8, d_out, d_clk, cus, long_iters, 2);
+        run<11, 2>("fp4 e2m1 32x32x64 only (units as if fp8)", d_ops, d_ops8, d_out, d_clk, cus, long_iters, 2);
         run<2, 1>("4 f16 + 2 fp8-K64 per K=64 (f16 + 2 fp8 corr.)", d_ops, d_ops8, d_out, d_clk, cus, long_iters * 3 / 4, 2);
         run<4, 2>("4 f16 + 1 fp8-K64 per K=64", d_ops, d_ops8, d_out, d_clk, cus, long_iters * 3 / 4, 2);
         run<5, 2>("8 f16 + 1 fp8-K64 per K=64 (x2q)", d_ops, d_ops8, d_out, d_clk, cus, long_iters / 2, 3);
