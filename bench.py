@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="fix the TOTAL batch instead (tests; ragged shards allowed)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default=None, choices=["mx8", "x2q", "mx8all", "f16x3"],
+    ap.add_argument("--precision", default=None, choices=["mx6", "mx8", "x2q", "mx8all", "f16x3"],
                     help="conv arithmetic per stack (disentangledcolorization_amd/model.py); default: the package default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing of the opt-in precision mode (x2q) that a default N=1 run reports next to `value`")
@@ -285,10 +285,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"mx8": "f16x3 (fp16 hi/lo split, 3 MFMA products) for SpixelNet+ColorProbNet; f16+fp8x2 (fp16 main product + two fp8 e4m3 "
+            "dtype": {"mx6": "f16x3 (fp16 hi/lo split, 3 MFMA products) for SpixelNet+ColorProbNet; f16+fp6x2 (fp16 main product + two fp6 e2m3 "
+                             "correction products in one K=64 MFMA) for HourGlass2; fp32 accumulate",
+                      "mx8": "f16x3 (fp16 hi/lo split, 3 MFMA products) for SpixelNet+ColorProbNet; f16+fp8x2 (fp16 main product + two fp8 e4m3 "
                              "correction products in one K=64 MFMA) for HourGlass2; fp32 accumulate",
                       "x2q": "f16x3 for SpixelNet; f16x2+fp8 (w_h a_h + w_l a_h in fp16, fp8(w) fp8(a_l) in one K=64 MFMA per 64 channels) for "
-                             "ColorProbNet; f16+fp8x2 for HourGlass2; fp32 accumulate",
+                             "ColorProbNet; f16+fp6x2 for HourGlass2; fp32 accumulate",
                       "mx8all": "f16+fp8x2 (fp16 main product + two fp8 e4m3 correction products), fp32 accumulate - not anchor-safe",
                       "f16x3": "f16x3 (fp16 hi/lo split operands, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
@@ -314,7 +316,7 @@ def main():
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
             }
             out["stage_ms_per_step"] = {k: round(v / prof_steps, 3) for k, v in stage_ms.items()}        # of the profiled single-stream forwards
-            if world == 1 and not args.no_alt and args.precision == "mx8":
+            if world == 1 and not args.no_alt and args.precision == "mx6":
                 # the opt-in arithmetic on the same inputs, timed the same way (NOT `value`: DESIGN.md section 2 says why it is opt-in)
                 out["opt_in_precision"] = measure_alt("x2q", sd, gray, ab, n_global, args, sync)
             if world == 1 and not args.no_cpu_baseline:

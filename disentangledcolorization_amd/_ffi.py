@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("DISCO_HIP_LIB") or os.path.join(_HERE, "libdisco_hip.
 
 OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
-PREC_F16X3, PREC_MX8, PREC_MX8_ALL, PREC_X2Q = 0, 2, 3, 4
-PLANE_LO, PLANE_Q, PLANE_QL = 1, 2, 4
+PREC_F16X3, PREC_MX8, PREC_MX8_ALL, PREC_X2Q, PREC_MX6 = 0, 2, 3, 4, 5
+PLANE_LO, PLANE_Q, PLANE_QL, PLANE_Q6 = 1, 2, 4, 8
 
 
 class DiscoError(RuntimeError):
@@ -52,7 +52,7 @@ class ConvMxDesc(C.Structure):
                 ("up0", C.c_int32), ("up1", C.c_int32), ("sexp0", C.c_int32), ("sexp1", C.c_int32), ("c_out", C.c_int32),
                 ("stride", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("out_planes", C.c_int32),
                 ("out_sexp", C.c_int32), ("out_f32", C.c_int32), ("res_planes", C.c_int32), ("res_sexp", C.c_int32), ("x2q", C.c_int32),
-                ("d2s", C.c_int32)]
+                ("q6", C.c_int32), ("d2s", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/disco_hip.h declares

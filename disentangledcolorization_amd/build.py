@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdisco_hip.so")
-SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.hip", "conv_mx_ar1.hip", "conv_mx_ar2.hip", "conv_direct.hip", "color.hip", "spixel.hip", "tokens.hip", "diag.hip"]
+SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.hip", "conv_mx_ar1.hip", "conv_mx_ar2.hip", "conv_mx_ar3.hip", "conv_direct.hip", "color.hip", "spixel.hip", "tokens.hip", "diag.hip"]
 HEADERS = ["common.h", "conv_mx_kernel.h", os.path.join("..", "..", "include", "disco_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]

@@ -116,7 +116,8 @@ struct ConvLayer {
     int c_in = 0, c_in_pad = 0, c_out = 0;
     int kind = 0;                 // 0 plain 3x3, 1 ConvTranspose 4x4 s2 as 4-phase conv, 2 upsample+3x3 as 4-phase conv
     bool mx = false;              // packed for conv3x3_mx_kernel (fp16 main product + fp8 corrections)
-    int x2q = 0;                  // mx: packed for the kernel's f16x2 + fp8 arithmetic (sources with al8-only q planes)
+    int x2q = 0;                  // mx: weight-pack variant / arithmetic of the kernel: 0 = f16 + fp8x2, 1 = f16x2 + fp8 (sources with al8-only q
+                                  // planes), 2 = f16 + fp6x2 (sources with fp6 q planes)
     int c_out_k = 0;              // mx: output channels the kernel computes (c_out padded with zero weights so that act
                                   // outputs carry whole 32-channel blocks; per phase for the depth-to-space kinds)
     int c_real = 0;               // real (reference) output channels, per phase for kinds 1 and 2: FLOP accounting
@@ -276,12 +277,18 @@ void bn_affine(disco_ctx* c, const std::string& key, std::vector<float>& scale, 
 // DISCO_PREC_MX8_ALL runs every layer on the mx kernel (measurements only: not anchor-safe).
 // DISCO_PREC_X2Q: as MX8, and the ColorProbNet on the kernel's second arithmetic (f16x2 + fp8: both fp16 products of the hi
 // plane, only the activation residual through fp8 - conv_mx.hip), 5 pipe units instead of 6.
-enum { ARITH_F16X3 = 0, ARITH_MX8 = 1, ARITH_X2Q = 2 };
-bool any_mx(const disco_ctx* c) { return c->opt.precision == DISCO_PREC_MX8 || c->opt.precision == DISCO_PREC_MX8_ALL || c->opt.precision == DISCO_PREC_X2Q; }
+// DISCO_PREC_MX6 (the default) and DISCO_PREC_X2Q: the enhanceNet on f16 + fp6x2 - the same two correction products with fp6 e2m3 operands,
+// which the K = 64 MFMA runs in half the passes - except its first layer, whose sources (upfeat, gray) are written by kernels that
+// produce fp8 planes: it reads those and writes fp6 ones.
+enum { ARITH_F16X3 = 0, ARITH_MX8 = 1, ARITH_X2Q = 2, ARITH_MX6 = 3 };
+bool any_mx(const disco_ctx* c) { return c->opt.precision == DISCO_PREC_MX8 || c->opt.precision == DISCO_PREC_MX8_ALL || c->opt.precision == DISCO_PREC_X2Q || c->opt.precision == DISCO_PREC_MX6; }
 int arith_of(const disco_ctx* c, const std::string& key) {
     if (c->opt.precision == DISCO_PREC_MX8_ALL) return ARITH_MX8;
-    if (c->opt.precision != DISCO_PREC_MX8 && c->opt.precision != DISCO_PREC_X2Q) return ARITH_F16X3;
-    if (key.compare(0, 11, "enhanceNet.") == 0) return ARITH_MX8;
+    if (c->opt.precision != DISCO_PREC_MX8 && c->opt.precision != DISCO_PREC_X2Q && c->opt.precision != DISCO_PREC_MX6) return ARITH_F16X3;
+    if (key.compare(0, 11, "enhanceNet.") == 0) {
+        if (c->opt.precision == DISCO_PREC_MX8) return ARITH_MX8;
+        return key == "enhanceNet.inConv.inConv.0" ? ARITH_MX8 : ARITH_MX6;
+    }
     if (c->opt.precision == DISCO_PREC_X2Q && key.compare(0, 7, "repnet.") == 0) return ARITH_X2Q;
     return ARITH_F16X3;
 }
@@ -300,7 +307,7 @@ int upload_padded(disco_ctx* c, std::vector<float> v, size_t n, float fill, floa
 int finish_mx(disco_ctx* c, ConvLayer& L, const std::vector<float>& w, int co, int ci, const int* ci_map, int c_in_pad, bool act_out, int x2q = 0) {
     L.mx = true; L.x2q = x2q; L.c_in = ci; L.c_in_pad = c_in_pad;
     L.c_out_k = act_out ? pad_cout_mx(co) : co;
-    if (x2q && c_in_pad % 64) { set_error("the f16x2+fp8 arithmetic needs a multiple of 64 input channels (%d)", c_in_pad); return DISCO_ESHAPE; }
+    if (x2q == 1 && c_in_pad % 64) { set_error("the f16x2+fp8 arithmetic needs a multiple of 64 input channels (%d)", c_in_pad); return DISCO_ESHAPE; }
     std::vector<char> packed(conv_mx_packed_bytes(L.c_out_k, c_in_pad, x2q));
     std::vector<int32_t> wexp((size_t)round_up(L.c_out_k, 32));
     conv_mx_pack_host(w.data(), co, ci, ci_map, c_in_pad, packed.data(), wexp.data(), x2q);     // rows >= co pack as zeros
@@ -332,8 +339,8 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
     L.c_in = ci; L.c_out = co; L.c_real = co;
     int rc;
     if (use_mx(c, key)) {
-        const int x2q = arith_of(c, key) == ARITH_X2Q;
-        const int cpad = c_in_pad_override ? c_in_pad_override : round_up(ci, x2q ? 64 : 32);
+        const int x2q = arith_of(c, key) == ARITH_X2Q ? 1 : (arith_of(c, key) == ARITH_MX6 ? 2 : 0);       // pack variant
+        const int cpad = c_in_pad_override ? c_in_pad_override : round_up(ci, x2q == 1 ? 64 : 32);
         if ((rc = finish_mx(c, L, w, co, ci, ci_map ? ci_map->data() : nullptr, cpad, act_out, x2q))) return rc;
         if ((rc = upload_padded(c, bias, (size_t)L.c_out_k, 0.f, &L.d_bias))) return rc;
         if (!post_bn.empty()) {
@@ -392,7 +399,7 @@ int finish_phase_mx(disco_ctx* c, ConvLayer& L, const std::vector<float>& w4, in
         for (int o = 0; o < co; ++o)
             std::copy(w4.begin() + ((size_t)(ph * co + o)) * ci * 9, w4.begin() + ((size_t)(ph * co + o) + 1) * ci * 9,
                       wp.begin() + ((size_t)(ph * cop + o)) * ci * 9);
-    int rc = finish_mx(c, L, wp, 4 * cop, ci, nullptr, round_up(ci, x2q ? 64 : 32), true, x2q);
+    int rc = finish_mx(c, L, wp, 4 * cop, ci, nullptr, round_up(ci, x2q == 1 ? 64 : 32), true, x2q);
     if (rc) return rc;
     L.c_out = 4 * cop; L.c_real = co;
     std::vector<uint32_t> mask(cdiv(L.c_out_k, 32));
@@ -438,7 +445,7 @@ int make_upconv(disco_ctx* c, const std::string& key) {
     L.c_in = ci; L.c_out = 4 * co; L.c_real = co; L.c_in_pad = round_up(ci, 16); L.kind = 2;
     int rc;
     if (use_mx(c, key)) {
-        if ((rc = finish_phase_mx(c, L, w4, co, ci, T(c, key + ".bias").data, arith_of(c, key) == ARITH_X2Q))) return rc;
+        if ((rc = finish_phase_mx(c, L, w4, co, ci, T(c, key + ".bias").data, arith_of(c, key) == ARITH_X2Q ? 1 : (arith_of(c, key) == ARITH_MX6 ? 2 : 0)))) return rc;
         c->conv[key] = L;
         return DISCO_OK;
     }
@@ -506,18 +513,18 @@ struct Plan {
     }
     void drop(void* p) { if (p) arena.release(dry ? (size_t)(uintptr_t)p - 256 : (size_t)((char*)p - base)); }
     // planes of an activation tensor: F_LO = fp16 lo plane, F_Q = fp8 q planes a8|al8 (scale exponent of producer `key`),
-    // F_QL = al8-only q planes (the operand of the f16x2+fp8 arithmetic)
-    enum { F_LO = 1, F_Q = 2, F_QL = 4 };
+    // F_QL = al8-only q planes (the operand of the f16x2+fp8 arithmetic), F_Q6 = fp6 q planes (f16+fp6x2)
+    enum { F_LO = 1, F_Q = 2, F_QL = 4, F_Q6 = 8 };
     int stage_arith = ARITH_F16X3;     // arithmetic of the stack being planned (set per network by the plan)
     bool mx() const { return stage_arith != ARITH_F16X3; }
     int cpad(int ch) const { return round_up(ch, stage_arith == ARITH_X2Q ? 64 : (mx() ? 32 : 16)); }
-    int dfmt() const { return stage_arith == ARITH_X2Q ? (int)F_QL : (mx() ? (int)F_Q : (int)F_LO); }          // what a conv -> conv tensor carries
+    int dfmt() const { return stage_arith == ARITH_X2Q ? (int)F_QL : (stage_arith == ARITH_MX6 ? (int)F_Q6 : (mx() ? (int)F_Q : (int)F_LO)); }          // what a conv -> conv tensor carries
     Act act(int n, int h, int w, int ch, int fmt) {
         Act t; t.n = n; t.h = h; t.w = w; t.c = ch;
         const size_t el = t.elems();
         t.plane = (fmt & F_LO) ? el : 0;
-        t.q_off = (fmt & (F_Q | F_QL)) ? el * 2 * ((fmt & F_LO) ? 2 : 1) : 0;
-        t.q_kind = (fmt & F_QL) ? 1 : 0;
+        t.q_off = (fmt & (F_Q | F_QL | F_Q6)) ? el * 2 * ((fmt & F_LO) ? 2 : 1) : 0;
+        t.q_kind = (fmt & F_QL) ? 1 : ((fmt & F_Q6) ? 2 : 0);
         t.p = (f16*)raw(t.bytes());
         return t;
     }
@@ -630,7 +637,7 @@ struct Plan {
                 ca.res = res ? res->p : nullptr; ca.res_plane = res ? (long)res->plane : 0; ca.res_sexp = res ? res->sexp : 0;
                 ca.out = out.p; ca.out_plane = (long)out.plane; ca.out_q_off = out.q_off; ca.out_sexp = out.sexp; ca.out_q_kind = out.q_kind;
                 ca.out_f32 = out_f32; ca.d2s_c = d2s ? co_t / 4 : 0; ca.softmax = softmax ? 1 : 0;
-                ca.act = actc; ca.slope = slope; ca.sat = calib ? nullptr : c->d_sat; ca.x2q = L.x2q;
+                ca.act = actc; ca.slope = slope; ca.sat = calib ? nullptr : c->d_sat; ca.x2q = L.x2q == 1; ca.q6 = L.x2q == 2;
                 rc = launch_conv3x3_mx(ca, s);
             };
             launch();
@@ -662,8 +669,8 @@ struct Plan {
             const double taps = L.kind == 1 ? 16.0 * L.c_real : (L.kind == 2 ? 36.0 * L.c_real : 9.0 * L.c_real);
             // compulsory HBM bytes: every source plane the kernel reads once (4 B per element: hi + lo, or hi + two fp8 planes), every
             // output plane written once, the residual read once, the packed weights once
-            const double bpe_out = out_f32 ? 4.0 : 2.0 * (1 + ((ofmt & F_LO) ? 1 : 0) + ((ofmt & F_Q) ? 1 : 0)) + ((ofmt & F_QL) ? 1.0 : 0.0);
-            double bytes = (L.x2q ? 3.0 : 4.0) * in0.n * ((double)in0.c * in0.h * in0.w + (in1 ? (double)in1->c * in1->h * in1->w : 0.0));
+            const double bpe_out = out_f32 ? 4.0 : 2.0 * (1 + ((ofmt & F_LO) ? 1 : 0) + ((ofmt & F_Q) ? 1 : 0)) + ((ofmt & F_QL) ? 1.0 : 0.0) + ((ofmt & F_Q6) ? 1.5 : 0.0);
+            double bytes = (L.x2q == 1 ? 3.0 : (L.x2q == 2 ? 3.5 : 4.0)) * in0.n * ((double)in0.c * in0.h * in0.w + (in1 ? (double)in1->c * in1->h * in1->w : 0.0));
             bytes += bpe_out * in0.n * (double)(out_f32 ? L.c_real : co_t) * ho * wo;
             if (res) bytes += 4.0 * in0.n * (double)co_t * ho * wo;
             bytes += L.mx ? (double)conv_mx_packed_bytes(co_t, L.c_in_pad, L.x2q) : (double)conv3x3_packed_bytes(L.c_out, L.c_in_pad);
@@ -849,8 +856,10 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
 
     // ---- a12 upfeat + a13 HourGlass2 + tanh (model.py:194-197) --------------------------------------------------
     P.stage_arith = arith_of(c, "enhanceNet.");
-    Act full = P.act(n2, H, W, 64, P.dfmt());
-    Act g16 = P.act(n2, H, W, P.cpad(16), P.dfmt());
+    // (the upfeat / gray kernels write fp8 q planes; under the fp6 arithmetic inConv.inConv.0 reads those and writes fp6 ones)
+    const int infmt = P.stage_arith == ARITH_MX6 ? (int)Plan::F_Q : P.dfmt();
+    Act full = P.act(n2, H, W, 64, infmt);
+    Act g16 = P.act(n2, H, W, P.cpad(16), infmt);
     if (!dry && P.ok() && P.scale_of("upfeat", &full.sexp) && P.scale_of("gray16", &g16.sexp)) {}
     {
         unsigned int* sat = calib ? nullptr : c->d_sat;
@@ -867,7 +876,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     t = P.conv(en + "down1.conv.0", e1, nullptr, 0, 0, 2, RELU, 0.f);
     Act e2 = P.conv(en + "down1.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
     t = P.conv(en + "down2.conv.0", e2, nullptr, 0, 0, 2, RELU, 0.f);
-    const int rfmt = P.mx() ? (Plan::F_LO | Plan::F_Q) : Plan::F_LO;      // residual-chain tensors: convolved AND added back
+    const int rfmt = P.mx() ? (Plan::F_LO | P.dfmt()) : Plan::F_LO;      // residual-chain tensors: convolved AND added back
     Act x = P.conv(en + "down2.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, false, false, rfmt); P.drop(t);
     for (int r = 0; r < 3; ++r) {
         const std::string k = en + "residual." + std::to_string(r) + ".conv.";
@@ -1015,7 +1024,7 @@ int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (!opt || !out) { set_error("null argument"); return DISCO_EINVAL; }
     if (opt->sp_size != 16) { set_error("sp_size %d unsupported (16 only, inference.py:146)", opt->sp_size); return DISCO_EUNSUPPORTED; }
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
-    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL && opt->precision != DISCO_PREC_X2Q) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
+    if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL && opt->precision != DISCO_PREC_X2Q && opt->precision != DISCO_PREC_MX6) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
     if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }
     if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("segnet_only context takes no colorizer flags"); return DISCO_EINVAL; }
     int ndev = 0;
@@ -1336,8 +1345,8 @@ static Act flat_act(const void* p, int n, int c_pad, int h, int w, int planes, i
     Act t; t.p = (f16*)p; t.n = n; t.h = h; t.w = w; t.c = c_pad; t.sexp = sexp;
     const size_t el = t.elems();
     t.plane = (planes & DISCO_PLANE_LO) ? el : 0;
-    t.q_off = (planes & (DISCO_PLANE_Q | DISCO_PLANE_QL)) ? el * 2 * ((planes & DISCO_PLANE_LO) ? 2 : 1) : 0;
-    t.q_kind = (planes & DISCO_PLANE_QL) ? 1 : 0;
+    t.q_off = (planes & (DISCO_PLANE_Q | DISCO_PLANE_QL | DISCO_PLANE_Q6)) ? el * 2 * ((planes & DISCO_PLANE_LO) ? 2 : 1) : 0;
+    t.q_kind = (planes & DISCO_PLANE_QL) ? 1 : ((planes & DISCO_PLANE_Q6) ? 2 : 0);
     return t;
 }
 
@@ -1349,7 +1358,11 @@ int disco_op_act_bytes(int n, int c_pad, int h, int w, int planes, size_t* bytes
 
 int disco_op_nchw_to_act_mx(const float* d_src, void* d_dst, int n, int ch, int h, int w, int c_pad, int planes, int sexp, void* stream) {
     if (!positive("nchw_to_act_mx", {n, ch, h, w, c_pad})) return DISCO_ESHAPE;
-    if (!d_src || !d_dst || c_pad < ch || c_pad % ((planes & (DISCO_PLANE_Q | DISCO_PLANE_QL)) ? 32 : 16) || (planes & DISCO_PLANE_Q && planes & DISCO_PLANE_QL)) { set_error("bad argument (c_pad must be a multiple of 16, 32 with q planes, >= c)"); return DISCO_EINVAL; }
+    if (d_dst && (planes & DISCO_PLANE_Q6)) {       // fp6 fields are OR-ed into their slots
+        const Act t = flat_act(d_dst, n, c_pad, h, w, planes, sexp);
+        DISCO_HIP_CHECK(hipMemsetAsync((char*)d_dst + t.q_off, 0, t.q_bytes(), (hipStream_t)stream));
+    }
+    if (!d_src || !d_dst || c_pad < ch || c_pad % ((planes & (DISCO_PLANE_Q | DISCO_PLANE_QL | DISCO_PLANE_Q6)) ? 32 : 16) || ((planes & DISCO_PLANE_Q ? 1 : 0) + (planes & DISCO_PLANE_QL ? 1 : 0) + (planes & DISCO_PLANE_Q6 ? 1 : 0) > 1)) { set_error("bad argument (c_pad must be a multiple of 16, 32 with q planes, >= c)"); return DISCO_EINVAL; }
     return launch_nchw_to_act_mx(d_src, flat_act(d_dst, n, c_pad, h, w, planes, sexp), ch, (hipStream_t)stream);
 }
 
@@ -1367,13 +1380,14 @@ int disco_op_act_mx_to_nchw(const void* d_src, float* d_dst, int n, int ch, int 
 
 int disco_op_conv3x3_mx_pack(const float* h_w, int c_out, int c_in, int x2q, void* d_packed, int32_t* d_wexp, size_t* bytes) {
     if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }
-    const int cpad = round_up(c_in, x2q ? 64 : 32);
-    *bytes = conv_mx_packed_bytes(c_out, cpad, x2q ? 1 : 0);
+    if (x2q < 0 || x2q > 2) { set_error("conv3x3_mx_pack: variant %d", x2q); return DISCO_EINVAL; }
+    const int cpad = round_up(c_in, x2q == 1 ? 64 : 32);
+    *bytes = conv_mx_packed_bytes(c_out, cpad, x2q);
     if (!d_packed) return DISCO_OK;
     if (!h_w || !d_wexp) { set_error("null weight"); return DISCO_EINVAL; }
     std::vector<char> packed(*bytes);
     std::vector<int32_t> wexp((size_t)round_up(c_out, 32));
-    conv_mx_pack_host(h_w, c_out, c_in, nullptr, cpad, packed.data(), wexp.data(), x2q ? 1 : 0);
+    conv_mx_pack_host(h_w, c_out, c_in, nullptr, cpad, packed.data(), wexp.data(), x2q);
     DISCO_HIP_CHECK(hipMemcpy(d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice));
     DISCO_HIP_CHECK(hipMemcpy(d_wexp, wexp.data(), wexp.size() * 4, hipMemcpyHostToDevice));
     return DISCO_OK;
@@ -1386,7 +1400,8 @@ int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const v
     if (!positive("conv3x3_mx", {d->n, d->h_in, d->w_in, d->c_in0, d->c_out}) || d->c_in1 < 0) { if (d->c_in1 < 0) set_error("conv3x3_mx: c_in1 %d", d->c_in1); return DISCO_ESHAPE; }
     ConvMxArgs ca{};
     const int h0 = d->up0 ? d->h_in / 2 : d->h_in, w0 = d->up0 ? d->w_in / 2 : d->w_in;
-    const int src_planes = d->x2q ? DISCO_PLANE_QL : DISCO_PLANE_Q;
+    if (d->x2q && d->q6) { set_error("conv3x3_mx op: x2q and q6 are different arithmetics"); return DISCO_EINVAL; }
+    const int src_planes = d->x2q ? DISCO_PLANE_QL : (d->q6 ? DISCO_PLANE_Q6 : DISCO_PLANE_Q);
     const Act s0 = flat_act(d_src0, d->n, d->c_in0, h0, w0, src_planes, d->sexp0);
     if (s0.q_off >= ((size_t)1 << 32)) { set_error("conv3x3_mx: source too large"); return DISCO_ESHAPE; }
     ca.src[0] = {s0.p, (uint32_t)s0.q_off, d->c_in0, h0, w0, d->up0, d->sexp0};
@@ -1417,7 +1432,7 @@ int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const v
                               : flat_act(d_res, d->n, d->c_out, ca.h_out, ca.w_out, d->res_planes, 0);
         ca.res = rr.p; ca.res_plane = (long)rr.plane; ca.res_sexp = d->res_sexp;
     }
-    ca.act = d->act; ca.slope = d->slope; ca.sat = d_sat; ca.x2q = d->x2q ? 1 : 0;
+    ca.act = d->act; ca.slope = d->slope; ca.sat = d_sat; ca.x2q = d->x2q ? 1 : 0; ca.q6 = d->q6 ? 1 : 0;
     return launch_conv3x3_mx(ca, (hipStream_t)stream);
 }
 

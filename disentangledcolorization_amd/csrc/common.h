@@ -48,18 +48,32 @@ static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 //   plane a8 = fp8(xs) followed by the plane al8 = fp8((xs - hi) * 2^11)   (the correction operands of conv3x3_mx_kernel).
 //   q_kind 1: ONLY the al8 planes, [N][C/32][H][W][32] (1 byte per element): the operand of the f16x2+fp8 arithmetic, which
 //   keeps both fp16 products of the hi plane and sends just the activation residual through fp8.
+//   q_kind 2: MX fp6 (OCP e2m3) planes in the geometry of q_kind 0: a6 and al6, block-scaled per pixel and 32 channels (mx6_block_scale()
+//   below).  A pixel's 32-byte slot of a plane holds the 32 six-bit fields of its 32-channel block as a little-endian bit stream in
+//   bytes 0-23, its E8M0 scale byte in byte 24 (bytes 25-27 zero, 28-31 never written): field 4g + i = channel 8g + i, field
+//   16 + 4g + i = channel 8g + 4 + i (g, i = 0..3) - the order in which the two lanes that own a pixel in the conv epilogue hold
+//   their channels, so each writes 12 contiguous bytes (mx6_field_channel()).
+//   The K = 64 MFMA runs fp6 operands in half the passes of fp8 (tools/fp6_probe.hip, profiles/r03_mfma_mix.txt).
 struct Act {
     f16* p = nullptr;  // hi plane; lo plane at p + plane
     int n = 0, h = 0, w = 0, c = 0;
     size_t plane = 0;  // elements between the hi and the lo plane (= n*h*w*c), 0: no lo plane
     size_t q_off = 0;  // bytes between p and the q planes, 0: none
     int sexp = 0;
-    int q_kind = 0;    // 0: a8 | al8 per 32-channel block, 1: al8 only
+    int q_kind = 0;    // 0: a8 | al8 per 32-channel block, 1: al8 only, 2: a6 | al6 (fp6 slots)
     size_t elems() const { return (size_t)n * h * w * c; }
-    size_t q_bytes() const { return q_off ? elems() * (q_kind ? 1 : 2) : 0; }
+    size_t q_bytes() const { return q_off ? elems() * (q_kind == 1 ? 1 : 2) : 0; }
     size_t bytes() const { return elems() * sizeof(f16) * (1 + (plane ? 1 : 0)) + q_bytes(); }
 };
 constexpr int MX_LO_SHIFT = 11;     // al8 carries 2^11 more scale than a8 (|x - fp16(x)| <= 2^-11 |x|)
+// fp6 slots carry an E8M0 block scale per pixel and 32 channels (the MX format proper; dword 6 of the slot, which the MFMA takes
+// as its per-lane scale operand straight from the fragment registers): with E = the fp16 exponent of the slot's largest |hi word|,
+// a6 = hi / 2^(E - 2) in (-8, 8) (saturating at 7.5: within the top binade's rounding step) under the byte 127 + E - 2, and
+// al6 = lo / 2^(E - 14) (|lo| <= 2^(E - 11)) under the byte one below (the weights' side already carries the 2^-11 of MX_LO_SHIFT).
+__host__ __device__ inline int mx6_block_scale(f16 amax_hi) { return (int)((__builtin_bit_cast(unsigned short, amax_hi) >> 10) & 31u) + 110; }
+// channel (0..31 within its block) of six-bit field j of an fp6 slot, and the inverse
+__host__ __device__ inline int mx6_field_channel(int j) { return 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3); }
+__host__ __device__ inline int mx6_channel_field(int c) { return 16 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3); }
 
 // four floats -> four fp8 e4m3 bytes (round to nearest even), clamped to the finite range; *sat counts clamped values
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d, unsigned* sat = nullptr) {
@@ -201,13 +215,18 @@ struct ConvMxArgs {
     // arithmetic: 0 = f16 + fp8x2 (sources carry a8|al8 planes), 1 = f16x2 + fp8 ("x2q": w_h a_h + w_l a_h in fp16, fp8(w) fp8(a_l);
     // one source with al8-only planes, c_in a multiple of 64, weights packed with x2q = 1)
     int x2q;
+    int q6;                   // 1: the f16 + fp6x2 arithmetic (AR 3): as 0 with fp6 e2m3 correction operands (sources with q_kind 2 planes,
+                              // weights packed with variant 2): half the passes of the fp8 K = 64 MFMA
     int out_q_kind;           // layout of the output's q planes (Act::q_kind)
     int x3;                   // 1: the f16x3 arithmetic on this kernel (launch_conv3x3_x3): sources = hi + lo planes, MxSrc::q_off = byte
                               // distance between them, weights = conv3x3_pack_host's image, no q planes anywhere
 };
-size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int x2q = 0);
+// variant: 0 = f16 + fp8x2, 1 = f16x2 + fp8 (x2q), 2 = f16 + fp6x2
+size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int variant = 0);
 // h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map as in conv3x3_pack_host; c_in_pad multiple of 32 (x2q: 64); h_wexp: cdiv(c_out,32)*32 ints
-void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int x2q = 0);
+void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int variant = 0);
+unsigned char fp6_e2m3_from_float(float x);      // round to nearest even, saturating to +-7.5
+float fp6_e2m3_to_float(unsigned char code);
 int launch_conv3x3_mx(const ConvMxArgs& a, hipStream_t s);
 // the f16x3 layer described by a ConvArgs on conv3x3_mx_kernel (AR = 2)
 int launch_conv3x3_x3(const ConvArgs& a, hipStream_t s);

@@ -1,5 +1,6 @@
 // conv_mx.hip — host side of the 3x3 implicit-GEMM conv (kernel: conv_mx_kernel.h): argument checks, the dispatch over the three
 // arithmetics, weight packing, layout conversion and calibration helpers.
+#include <cstring>
 #include "conv_mx_kernel.h"
 
 namespace disco {
@@ -8,15 +9,39 @@ namespace disco {
 extern template int dispatch_mx_ar<0>(const ConvMxArgs&, hipStream_t);
 extern template int dispatch_mx_ar<1>(const ConvMxArgs&, hipStream_t);
 extern template int dispatch_mx_ar<2>(const ConvMxArgs&, hipStream_t);
+extern template int dispatch_mx_ar<3>(const ConvMxArgs&, hipStream_t);
 
 int dispatch_mx(const ConvMxArgs& a, hipStream_t s) {
     if (a.x2q) return dispatch_mx_ar<1>(a, s);
+    if (a.q6) return dispatch_mx_ar<3>(a, s);
     return a.x3 ? dispatch_mx_ar<2>(a, s) : dispatch_mx_ar<0>(a, s);
 }
 
 namespace {
 
 // ---- layout conversion / calibration helpers ------------------------------------------------------------------------------
+// fp6 e2m3 code of x: round to nearest even, saturating at +-7.5 (what v_cvt_scalef32_pk32_fp6_f16 does: tools/fp6_probe.hip)
+__device__ __host__ inline unsigned fp6_code(float x) {
+    const unsigned s = std::signbit(x) ? 32u : 0u;
+    float ax = fabsf(x);
+    if (!(ax == ax) || ax >= 7.5f) return s | 31u;
+    int e = 0;
+    if (ax >= 4.f) e = 2; else if (ax >= 2.f) e = 1;
+    const float step = ldexpf(1.f, e - 3);
+    const float v = nearbyintf(ax / step) * step;                 // nearest even multiple of the step (may reach the next binade)
+    if (v >= 7.5f) return s | 31u;
+    if (v < 1.f) return s | (unsigned)(v * 8.f);
+    int ee = 0;
+    if (v >= 4.f) ee = 2; else if (v >= 2.f) ee = 1;
+    return s | ((unsigned)(ee + 1) << 3) | (unsigned)((v / ldexpf(1.f, ee) - 1.f) * 8.f);
+}
+__device__ inline unsigned fp6_code_dev(float x) { return fp6_code(x); }
+__device__ __host__ inline float fp6_value(unsigned c) {
+    const unsigned e = (c >> 3) & 3u, m = c & 7u;
+    const float f = e == 0 ? m * 0.125f : ldexpf(1.f + m / 8.f, (int)e - 1);
+    return (c & 32u) ? -f : f;
+}
+
 __global__ void nchw_to_act_mx_kernel(const float* __restrict__ src, f16* __restrict__ dst, long plane, long q_off, int sexp,
                                       int n, int c, int h, int w, int c_pad, int q_kind) {
     // one thread per (image, 16-channel block, pixel): reads 16 strided fp32, writes 32 B hi (+ lo) (+ 16 B of each q plane)
@@ -45,8 +70,32 @@ __global__ void nchw_to_act_mx_kernel(const float* __restrict__ src, f16* __rest
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[plane + j] = lo[j];
     }
-    if (q_off) {
-        unsigned char* q = reinterpret_cast<unsigned char*>(dst) + q_off + (((long)img * (c_pad / 32) + (blk >> 1)) * (q_kind ? 1 : 2)) * hw * 32 + pix * 32 + (blk & 1) * 16;
+    if (q_off && q_kind == 2) {
+        // fp6 slots (test helper: the two threads of a 32-channel block write disjoint fields of the same bytes, hence the atomics;
+        // the buffer is zero-filled by the caller).  Block exponent: of the largest |fp16 hi word| of the pixel's 32 channels.
+        unsigned int* q32 = reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(dst) + q_off + (((long)img * (c_pad / 32) + (blk >> 1)) * 2) * hw * 32 + pix * 32);
+        float bmax = 0.f;
+        for (int j = 0; j < 32; ++j) {
+            const int ch = (blk >> 1) * 32 + j;
+            bmax = fmaxf(bmax, fabsf((float)(f16)((ch < c ? src[((long)img * c + ch) * hw + pix] : 0.f) * sc)));
+        }
+        const int sa = mx6_block_scale((f16)bmax);
+        const float inv = ldexpf(1.f, 127 - sa);                       // a6 = hi / 2^(sa - 127), al6 = lo 2^11 / 2^(sa - 1 - 127)
+        for (int j = 0; j < 16; ++j) {
+            const int ch = (blk & 1) * 16 + j, f = mx6_channel_field(ch);
+            const float v = (float)hi[j], l = (float)lo[j];          // what the conv epilogue converts: the fp16 words
+            for (int pl = 0; pl < 2; ++pl) {
+                const unsigned code = fp6_code_dev(pl ? l * qls * 2.f * inv : v * inv);
+                const int bit = 6 * f, d = bit >> 5, o = bit & 31;
+                const unsigned long long sh = (unsigned long long)code << o;
+                unsigned int* w0 = q32 + pl * hw * 8 + d;
+                atomicOr(w0, (unsigned)sh);
+                if (sh >> 32) atomicOr(w0 + 1, (unsigned)(sh >> 32));
+            }
+        }
+        if (!(blk & 1)) { q32[6] = (unsigned)sa; q32[hw * 8 + 6] = (unsigned)(sa - 1); }
+    } else if (q_off) {
+        unsigned char* q = reinterpret_cast<unsigned char*>(dst) + q_off + (((long)img * (c_pad / 32) + (blk >> 1)) * (q_kind == 1 ? 1 : 2)) * hw * 32 + pix * 32 + (blk & 1) * 16;
         if (q_kind) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) q[j] = l8[j];
@@ -72,14 +121,24 @@ __global__ void act_q_to_nchw_kernel(const f16* __restrict__ src, long q_off, in
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * c * hw) return;
     const long pix = idx % hw; const long t = idx / hw; const int ch = (int)(t % c); const int img = (int)(t / c);
-    const unsigned char* q = reinterpret_cast<const unsigned char*>(src) + q_off + (((long)img * (c_pad / 32) + (ch >> 5)) * (q_kind ? 1 : 2)) * hw * 32 + pix * 32 + (ch & 31);
+    if (q_kind == 2) {
+        const unsigned int* q32 = reinterpret_cast<const unsigned int*>(reinterpret_cast<const unsigned char*>(src) + q_off + (((long)img * (c_pad / 32) + (ch >> 5)) * 2) * hw * 32 + pix * 32);
+        const int bit = 6 * mx6_channel_field(ch & 31), d = bit >> 5, o = bit & 31;
+        auto fld = [&](const unsigned int* w) { unsigned long long v = w[d]; if (d + 1 < 6) v |= (unsigned long long)w[d + 1] << 32; return (unsigned)((v >> o) & 63u); };
+        // value = field 2^(scale byte - 127); the al6 plane carries 2^11 more (MX_LO_SHIFT), as the fp8 one does
+        const int sa = (int)(q32[6] & 255u) - 127, sl = (int)(q32[hw * 8 + 6] & 255u) - 127;
+        if (which == 0) dst[idx] = ldexpf(fp6_value(fld(q32)), sa - sexp);
+        else dst[idx] = ldexpf((float)src[((long)img * (c_pad / 16) + (ch >> 4)) * hw * 16 + pix * 16 + (ch & 15)] + ldexpf(fp6_value(fld(q32 + hw * 8)), sl - MX_LO_SHIFT), -sexp);
+        return;
+    }
+    const unsigned char* q = reinterpret_cast<const unsigned char*>(src) + q_off + (((long)img * (c_pad / 32) + (ch >> 5)) * (q_kind == 1 ? 1 : 2)) * hw * 32 + pix * 32 + (ch & 31);
     auto dq = [](unsigned char v) -> float {
         const int sg = v >> 7, e = (v >> 3) & 15, m = v & 7;
         const float f = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.f + m / 8.f, e - 7);
         return sg ? -f : f;
     };
     if (which == 0) dst[idx] = q_kind ? 0.f : ldexpf(dq(q[0]), -sexp);        // al8-only planes have no a8 view
-    else dst[idx] = ldexpf((float)src[((long)img * (c_pad / 16) + (ch >> 4)) * hw * 16 + pix * 16 + (ch & 15)] + ldexpf(dq(q[q_kind ? 0 : hw * 32]), -MX_LO_SHIFT), -sexp);
+    else dst[idx] = ldexpf((float)src[((long)img * (c_pad / 16) + (ch >> 4)) * hw * 16 + pix * 16 + (ch & 15)] + ldexpf(dq(q[q_kind == 1 ? 0 : hw * 32]), -MX_LO_SHIFT), -sexp);
 }
 
 }  // namespace
@@ -129,20 +188,27 @@ unsigned char fp8_e4m3_from_float(float x) {
     return sign | (unsigned char)(((ex + 7) << 3) | ((int)rq - 8));
 }
 
-size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int x2q) {
-    return (size_t)cdiv(c_out, 32) * (x2q ? (c_in_pad / 64) * 5 : c_in_pad / 16) * W_NB;
+unsigned char fp6_e2m3_from_float(float x) { return (unsigned char)fp6_code(x); }
+float fp6_e2m3_to_float(unsigned char c) { return fp6_value(c); }
+
+size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int variant) {
+    return (size_t)cdiv(c_out, 32) * (variant == 1 ? (c_in_pad / 64) * 5 : c_in_pad / 16) * W_NB;
 }
 
-void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int x2q) {
+void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int variant) {
+    const int x2q = variant == 1;
+    const bool q6 = variant == 2;
     unsigned char* dst = reinterpret_cast<unsigned char*>(h_packed);
     const int nb_n = cdiv(c_out, 32), ngrp = c_in_pad / 32;
-    // per output channel: 2^wexp maps the largest |w| into [128, 256) (fp8 e4m3 tops out at 448)
+    // per output channel: 2^wexp maps the largest |w| into [128, 256) (fp8 e4m3 tops out at 448); fp6: into [4, 8) (values in
+    // (7.25, 8) saturate at 7.5: at most the one largest weight of a row, by < 7 %, in a correction term)
     for (int co = 0; co < nb_n * 32; ++co) {
         float mx = 0.f;
         if (co < c_out)
             for (size_t i = 0; i < (size_t)c_in * 9; ++i) mx = std::max(mx, std::fabs(h_w[(size_t)co * c_in * 9 + i]));
         int e = 0;
-        if (mx > 0.f) { std::frexp(mx, &e); e = 8 - e; }     // mx 2^e in [128, 256)
+        if (mx > 0.f) { std::frexp(mx, &e); e = (q6 ? 3 : 8) - e; }     // mx 2^e in [128, 256) / [4, 8)
+        if (q6 && mx > 0.f && std::ldexp(mx, e) > 7.5f) e -= 1;          // ... fp6: rather lose a bit than clamp: [3.75, 7.5]
         h_wexp[co] = std::min(std::max(e, -100), 100);
     }
     auto wat = [&](int co, int cip, int tap) -> float {
@@ -190,10 +256,26 @@ void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map,
                     // Q chunk (ck = 2g+1): lane's 32 bytes = channels 0..31 of wl8 (kh = 0) or w8 (kh = 1); piece j = bytes 16 j .. 16 j + 15
                     unsigned char* qb = dst + (((size_t)nb * (2 * ngrp) + 2 * g + 1) * 9 + tap) * 2 * WBLK;
                     const float ws = std::ldexp(1.f, h_wexp[co]), wls = std::ldexp(1.f, h_wexp[co] + MX_LO_SHIFT);
+                    if (q6) {
+                        // the lane's 32 bytes = the fp6 slot of its row: field f = channel mx6_field_channel(f) of wl6 (kh = 0) / w6 (kh = 1),
+                        // a little-endian stream of 32 six-bit fields in bytes 0-23
+                        unsigned char slot[32] = {0};
+                        for (int f = 0; f < 32; ++f) {
+                            const float w = wat(co, g * 32 + mx6_field_channel(f), tap);
+                            const float wl = w - (float)(f16)w;
+                            const unsigned code = kh == 0 ? fp6_code(wl * wls) : fp6_code(w * ws);
+                            const int bit = 6 * f;
+                            const unsigned v = code << (bit & 7);
+                            slot[bit >> 3] |= (unsigned char)v;
+                            slot[(bit >> 3) + 1] |= (unsigned char)(v >> 8);
+                        }
+                        for (int j = 0; j < 2; ++j) memcpy(qb + j * WBLK + lane * 16, slot + 16 * j, 16);
+                    }
                     for (int j = 0; j < 2; ++j) {
                         f16* hp = reinterpret_cast<f16*>(hb + j * WBLK + lane * 16);
                         for (int i = 0; i < 8; ++i) hp[i] = (f16)wat(co, g * 32 + 16 * j + 8 * kh + i, tap);
                         unsigned char* qp = qb + j * WBLK + lane * 16;
+                        if (q6) continue;
                         for (int i = 0; i < 16; ++i) {
                             const float w = wat(co, g * 32 + 16 * j + i, tap);
                             const float wl = w - (float)(f16)w;
@@ -228,6 +310,7 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
     int csum = 0;
     for (int i = 0; i < a.nsrc; ++i) {
         const MxSrc& sp = a.src[i];
+        if (a.x2q && a.q6) { set_error("conv3x3_mx: one arithmetic at a time"); return DISCO_EINVAL; }
         if (sp.c % (a.x2q ? 64 : 32) || !sp.q_off) { set_error("conv3x3_mx: source %d needs q planes and a multiple of %d channels (got %d)", i, a.x2q ? 64 : 32, sp.c); return DISCO_ESHAPE; }
         const size_t per = (size_t)a.n * sp.c * sp.h * sp.w * 2;          // bytes of the hi plane = bytes of the a8|al8 planes (al8 only: half)
         const size_t bytes = (size_t)sp.q_off + (a.x2q ? per / 2 : per);
@@ -239,16 +322,21 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
     }
     if (csum != a.c_in) { set_error("conv3x3_mx: sources carry %d channels, layer takes %d", csum, a.c_in); return DISCO_ESHAPE; }
     if (a.x2q && a.nsrc != 1) { set_error("conv3x3_mx: the f16x2+fp8 arithmetic takes one source"); return DISCO_ESHAPE; }
+    if (!a.out_f32 && a.out_q_off) {
+        // which q-plane formats an instantiation can write (conv_mx_kernel.h, CAN_Q6 / CAN_Q8)
+        if (a.q6 && a.out_q_kind != 2) { set_error("conv3x3_mx: the f16+fp6x2 arithmetic writes fp6 q planes only (out_q_kind %d)", a.out_q_kind); return DISCO_ESHAPE; }
+        if (!a.q6 && a.out_q_kind == 2 && !(a.nsrc == 2 && !a.x2q)) { set_error("conv3x3_mx: fp6 q planes are written by the f16+fp6x2 arithmetic and by two-source f16+fp8x2 layers only"); return DISCO_ESHAPE; }
+    }
     if (a.nsrc > 1 && (a.out_f32 || a.d2s_c > 0)) { set_error("conv3x3_mx: a two-source layer writes a plain activation tensor (no fp32 NCHW / depth-to-space output)"); return DISCO_ESHAPE; }
     {
-        const size_t wb = conv_mx_packed_bytes(a.c_out, a.c_in, a.x2q);
+        const size_t wb = conv_mx_packed_bytes(a.c_out, a.c_in, a.x2q ? 1 : 0);
         if (wb >= ((size_t)1 << 32)) { set_error("conv3x3_mx: packed weights too large"); return DISCO_ESHAPE; }
         a.w_bytes = (uint32_t)wb;
     }
     {
         const size_t oelems = (size_t)a.n * (a.d2s_c > 0 ? (size_t)a.d2s_c * 4 : (size_t)a.c_out_pad) * a.h_out * a.w_out;
         size_t ob = a.out_f32 ? (size_t)a.n * a.c_out * a.h_out * a.w_out * 4 : oelems * 2;
-        if (!a.out_f32) ob = std::max(ob, std::max((size_t)a.out_plane * 2 + (a.out_plane ? oelems * 2 : 0), a.out_q_off + (a.out_q_off ? oelems * (a.out_q_kind ? 1 : 2) : 0)));
+        if (!a.out_f32) ob = std::max(ob, std::max((size_t)a.out_plane * 2 + (a.out_plane ? oelems * 2 : 0), a.out_q_off + (a.out_q_off ? oelems * (a.out_q_kind == 1 ? 1 : 2) : 0)));
         const size_t rb = a.res ? (size_t)a.res_plane * 2 + oelems * 2 : 16;
         if (ob >= ((size_t)1 << 32) || rb >= ((size_t)1 << 32)) { set_error("conv3x3_mx: output tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", ob); return DISCO_ESHAPE; }
         if (!a.out_f32 && !a.out) { set_error("conv3x3_mx: null output"); return DISCO_EINVAL; }

@@ -43,6 +43,9 @@
 #include <vector>
 #include "common.h"
 
+#ifndef MX_QFMT
+#define MX_QFMT 0       // operand format of the K = 64 correction MFMA: 0 = fp8 e4m3.  2 (fp6 e2m3) / 4 (fp4): SPEED EXPERIMENTS ONLY - the data stay fp8 bytes
+#endif
 #ifndef MX_ABL
 #define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk
 #endif
@@ -97,6 +100,15 @@ __device__ __forceinline__ unsigned fp8x4_scaled(f32x2 a, f32x2 b, float scale) 
     return __builtin_bit_cast(unsigned, r);
 }
 
+// buffer_store_dwordx3 with the same wait states as buffer_store_b128() (a 96-bit store has the same data hazard)
+typedef int i32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void buffer_store_b96(i32x3 d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx3 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(d), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+
 template <int TW, int TH, int STRIDE>
 struct GeoMx {
     static constexpr int MB = TW * TH / 32;
@@ -110,10 +122,13 @@ struct GeoMx {
 };
 
 // NSRC2: the layer concatenates two sources on read (the descriptor and offsets of the second source exist only then).
-// AR: 0 = f16 + fp8x2, 1 = f16x2 + fp8 (x2q), 2 = f16x3 (below)
+// AR: 0 = f16 + fp8x2, 1 = f16x2 + fp8 (x2q), 2 = f16x3 (below), 3 = f16 + fp6x2: AR 0 with the two correction operands in fp6 e2m3
+// (Act::q_kind 2 sources, conv_mx_pack_host variant 2): the K = 64 MFMA takes half the passes (tools/fp6_probe.hip pins the operand
+// layout and the conversion; profiles/r03_mfma_mix.txt the rate)
 template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
-    constexpr bool XQ = AR == 1, X3 = AR == 2;
+    constexpr bool XQ = AR == 1, X3 = AR == 2, Q6 = AR == 3;
+    constexpr int QFMT = Q6 ? 2 : MX_QFMT;                // operand format code of the K = 64 MFMA: 0 = fp8 e4m3, 2 = fp6 e2m3
     static_assert(!(XQ && NSRC2), "the f16x2+fp8 arithmetic takes one source");
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = GeoMx<TW, TH, STRIDE>;
@@ -171,8 +186,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     // E8M0 scale operands of the fp8 products: weight side per lane (= per output channel row), pixel side uniform per source
     int wsc[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) wsc[j] = X3 ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];
-    constexpr int asc0 = 127, asc1 = 127;          // pixel-side E8M0 scale: 1 (the tensor's scale stays in the accumulators)
+    for (int j = 0; j < NTW; ++j) wsc[j] = X3 ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];       // (wexp: fp8 or fp6 scaling, conv_mx_pack_host)
+    // pixel-side E8M0 scale: 1 (the tensor's scale stays in the accumulators); fp6 planes hold xs 2^-3
+    constexpr int asc0 = 127, asc1 = asc0;                // fp8 activation planes: no block scale.  fp6 slots: dword 6 of the fragment (below)
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[0].p, 0, a.src_bytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[NSRC2 ? 1 : 0].p, 0, a.src_bytes[NSRC2 ? 1 : 0], 0x00020000);
@@ -368,7 +384,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                     if (ISQ) {
                         const i32x8 bw = {rb[nt][0][0], rb[nt][0][1], rb[nt][0][2], rb[nt][0][3], rb[nt][1][0], rb[nt][1][1], rb[nt][1][2], rb[nt][1][3]};
                         const i32x8 ap = {ra[mt][0][0], ra[mt][0][1], ra[mt][0][2], ra[mt][0][3], ra[mt][1][0], ra[mt][1][1], ra[mt][1][2], ra[mt][1][3]};
-                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], 0, 0, 0, wsc[nt], 0, asc);
+                        // fp6 slots carry their own E8M0 block scale (per pixel and 32 channels) in byte 24 = dword 6 of the fragment, which
+                        // the MFMA ignores as operand data: the lane's scale operand comes straight out of its fragment registers
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], QFMT, QFMT, 0, wsc[nt], 0, Q6 ? ra[mt][1][2] : asc);
                     } else if (KIND == 2) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
@@ -435,7 +453,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         const int oh = MODE == 1 ? 2 * a.h_out : a.h_out, ow = MODE == 1 ? 2 * a.w_out : a.w_out;
         const unsigned ohw = (unsigned)(oh * ow);
         const bool wr_lo = MODE != 2 && a.out_plane != 0, wr_q = MODE != 2 && a.out_q_off != 0;
-        const bool ql_only = a.out_q_kind != 0;              // al8-only q planes: one byte per element, no a8 plane
+        const bool ql_only = a.out_q_kind == 1;              // al8-only q planes: one byte per element, no a8 plane
+        // fp6 slots (the consumer runs the f16 + fp6x2 arithmetic).  Compiled in where the forward needs it: AR 3 writes ONLY fp6 q planes, AR 0
+        // only fp8 ones - except its two-source instantiations (inConv.inConv.0 reads the fp8 planes of the upfeat / gray kernels and feeds
+        // an fp6 layer), which carry one epilogue mode and have the registers for both (the launchers check the combination)
+        constexpr bool CAN_Q6 = Q6 || (AR == 0 && NSRC2), CAN_Q8 = !Q6;
+        const bool q6_out = CAN_Q6 && (!CAN_Q8 || a.out_q_kind == 2);
         constexpr float qs = 1.f;             // the epilogue leaves x 2^out_sexp: the fp8 planes take it as it is
         const __amdgpu_buffer_rsrc_t ro = MODE == 2 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.out_f32, 0, a.out_bytes, 0x00020000)
                                                     : __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
@@ -557,6 +580,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                             bmax = fmaxf(fmaxf(bmax, fabsf(x[p][0])), fabsf(x[p][1]));
                             bmax = fmaxf(fmaxf(bmax, fabsf(x[p + 1][0])), fabsf(x[p + 1][1]));
                         }
+                        if (q6_out) {
+                            // fp6 slots: ONE v_cvt_scalef32_pk32_fp6_f16 turns this lane's 16 hi words and its 16 lo residuals (x 2^12, as
+                            // fp16) into the 96 + 96 bits of its half of the pixel's a6 and al6 slots: fields in register order = channels
+                            // 8 g + 4 kh + i (Act::q_kind 2), divided by the block scale 2^(E - 2), rounded to nearest even, saturated at
+                            // +-7.5 (tools/fp6_probe.hip) - no permlanes for the data, no clamp path, nothing to count: the block scale
+                            // (mx6_block_scale() of the largest |hi| among the pixel's 32 channels = this lane's 16 and its partner's in the
+                            // other half-wave) follows the data wherever they go
+                            const unsigned bmb = __float_as_uint(bmax);
+                            const auto bsw = __builtin_amdgcn_permlane32_swap(bmb, bmb, false, false);
+                            const float pmax = fmaxf(__uint_as_float(bsw[0]), __uint_as_float(bsw[1]));
+                            const unsigned sa = (unsigned)mx6_block_scale((f16)pmax);
+                            const float bscale = __uint_as_float(sa << 23);
+                            f16x32 src;
+#pragma unroll
+                            for (int p = 0; p < 8; ++p) {
+                                const f16x2 h2 = __builtin_bit_cast(f16x2, hd[p]);
+                                const f16x2 l2 = __builtin_convertvector(lf[p] * 4096.f, f16x2);
+                                src[2 * p] = h2[0]; src[2 * p + 1] = h2[1]; src[16 + 2 * p] = l2[0]; src[16 + 2 * p + 1] = l2[1];
+                            }
+                            const i32x6 r6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(src, bscale);
+                            a8[0] = (unsigned)r6[0]; a8[1] = (unsigned)r6[1]; a8[2] = (unsigned)r6[2]; a8[3] = sa;
+                            l8[0] = (unsigned)r6[3]; l8[1] = (unsigned)r6[4]; l8[2] = (unsigned)r6[5]; l8[3] = sa - 1u;
+                        } else {
                         // The conversion does not saturate (a value that rounds above 448 becomes the NaN code 0x7f), and calibration
                         // leaves 14x headroom: only when a value of this block is beyond the range (|al8| <= |a8| by construction, so
                         // max |x| decides; wave-uniform test) its operands are clamped first - in place, and counted
@@ -578,6 +624,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                             a8[g] = fp8x4_scaled(x[2 * g], x[2 * g + 1], qinv);
                             l8[g] = fp8x4_scaled(lf[2 * g], lf[2 * g + 1], qlinv);
                         }
+                        }
                     }
                     // v_permlane32_swap: lower.(group 1) <-> upper.(group 0), lower.(group 3) <-> upper.(group 2): the lower
                     // half-wave then holds channels 0-7 and 16-23 of its pixel, the upper half 8-15 and 24-31
@@ -597,7 +644,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                                 ld[4 * q + d] = sl[0]; ld[4 * q + 2 + d] = sl[1];
                             }
                     }
-                    if (!X3 && wr_q) {
+                    if (!X3 && wr_q && !q6_out) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             auto sa = __builtin_amdgcn_permlane32_swap(a8[2 * q], a8[2 * q + 1], false, false);
@@ -704,7 +751,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                             const i32x4 l4 = {__float_as_int(t[8 + 4 * q]), __float_as_int(t[9 + 4 * q]), __float_as_int(t[10 + 4 * q]), __float_as_int(t[11 + 4 * q])};
                             buffer_store_b128(l4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u);
                         }
-                        if (wr_q) {
+                        if (wr_q && q6_out) {
+                            // fp6 slots: this lane owns bytes 12 kh .. 12 kh + 11 of its pixel's slot in either plane (once per 32-channel block)
+                            if (q == 0) {
+                                const unsigned v6 = (vo[mt] == OOB || cob >= a.c_out) ? OOB : vo[mt] + 12u * kh;
+                                buffer_store_b96(i32x3{__float_as_int(t[8]), __float_as_int(t[9]), __float_as_int(t[10])}, ro, v6, so_q[nt][0]);
+                                buffer_store_b96(i32x3{__float_as_int(t[12]), __float_as_int(t[13]), __float_as_int(t[14])}, ro, v6, so_q[nt][0] + ohw * 32u);
+                                // ... and the lower half-wave the two block scales (dword 6 of the slots)
+                                const unsigned v7 = (v6 == OOB || kh) ? OOB : vo[mt] + 24u;
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[11]), ro, v7, so_q[nt][0], 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[15]), ro, v7, so_q[nt][0] + ohw * 32u, 0);
+                            }
+                        } else if (wr_q) {
                             // q planes: this lane owns bytes 8 kh .. 8 kh + 7 of its pixel's 16-byte half (cb & 16)
                             const i32x2 q0 = {__float_as_int(t[8 + 2 * q]), __float_as_int(t[9 + 2 * q])};
                             const i32x2 q1 = {__float_as_int(t[12 + 2 * q]), __float_as_int(t[13 + 2 * q])};

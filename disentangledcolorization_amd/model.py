@@ -32,11 +32,11 @@ KMEANS_ITERS = 20  # clusterkit.py:43 iter_limit -> at most (K-1)*20 empty-clust
 MAX_ACT_BYTES = (1 << 32) - (1 << 20)
 
 
-# conv arithmetic per stack (include/disco_hip.h DISCO_PREC_*): "mx8" = f16x3 on SpixelNet + ColorProbNet (the anchor-deciding
-# stacks), f16+fp8x2 on HourGlass2; "x2q" = additionally the ColorProbNet on f16x2+fp8; "f16x3" everywhere; "mx8all":
+# conv arithmetic per stack (include/disco_hip.h DISCO_PREC_*): "mx6" (default) = f16x3 on SpixelNet + ColorProbNet (the anchor-deciding
+# stacks), f16+fp6x2 on HourGlass2; "mx8" = f16+fp8x2 on HourGlass2 (round 2's default); "x2q" = additionally the ColorProbNet on f16x2+fp8; "f16x3" everywhere; "mx8all":
 # measurements only
-_PRECISIONS = {"f16x3": _ffi.PREC_F16X3, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}
-DEFAULT_PRECISION = "mx8"
+_PRECISIONS = {"f16x3": _ffi.PREC_F16X3, "mx6": _ffi.PREC_MX6, "mx8": _ffi.PREC_MX8, "mx8all": _ffi.PREC_MX8_ALL, "x2q": _ffi.PREC_X2Q}
+DEFAULT_PRECISION = "mx6"
 
 
 def default_precision():

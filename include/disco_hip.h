@@ -71,7 +71,11 @@ typedef struct disco_ctx disco_ctx;
                               stay on DISCO_PREC_F16X3.  Measured: max |ab - reference| ~1e-4, anchors identical. */
 #define DISCO_PREC_MX8_ALL 3 /* every conv stack on the fp8-corrected kernel: ~6% faster again, but the ~3e-5 perturbation it
                               leaves at the encoder output flips k-means anchors in ~1% of images (measurements only) */
-#define DISCO_PREC_X2Q 4     /* as DISCO_PREC_MX8, and the ColorProbNet on the same kernel's second arithmetic: w_h a_h + w_l a_h
+#define DISCO_PREC_MX6 5     /* the default since round 3: as DISCO_PREC_MX8 with the two correction products of the HourGlass2 in fp6 (OCP e2m3)
+                              instead of fp8: the K = 64 MFMA runs fp6 operands in half the passes.  Same structure, same per-tensor
+                              scales; the first HourGlass2 layer still reads fp8 planes (its producers write those) and writes fp6 ones.
+                              Measured: max |ab - reference| ~2-3e-4 (MX8: 1.3e-4), anchors identical (they are decided upstream). */
+#define DISCO_PREC_X2Q 4     /* as DISCO_PREC_MX6, and the ColorProbNet on the same kernel's second arithmetic: w_h a_h + w_l a_h
                               in fp16 and only the activation residual in fp8 (5 matrix-pipe units per 32 channels and tap
                               instead of 6).  ~1.4e-5 at the encoder output where F16X3 leaves ~5e-6; anchors differ from the fp32 reference
                               in 0.66 % of images (F16X3: 0.10 %): opt-in. */
@@ -213,6 +217,9 @@ int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d
 #define DISCO_PLANE_LO 1
 #define DISCO_PLANE_Q 2
 #define DISCO_PLANE_QL 4   /* instead of DISCO_PLANE_Q: only the al8 planes, [N][C/32][H][W][32] (operands of the x2q arithmetic) */
+#define DISCO_PLANE_Q6 8   /* instead of DISCO_PLANE_Q: fp6 (OCP e2m3) planes in the same geometry: a6 = fp6(xs 2^-3), al6 = fp6((xs - hi) 2^8);
+                              a pixel's 32-byte slot holds the 32 six-bit fields of its 32-channel block in bytes 0-23 (little-endian bit
+                              stream; field 4g+i = channel 8g+i, field 16+4g+i = channel 8g+4+i) - operands of the f16 + fp6x2 arithmetic */
 int disco_op_act_bytes(int n, int c_pad, int h, int w, int planes, size_t *bytes);
 int disco_op_nchw_to_act_mx(const float *d_src, void *d_dst, int n, int c, int h, int w, int c_pad, int planes, int sexp,
                             void *stream);
@@ -234,11 +241,14 @@ typedef struct disco_conv_mx_desc {
     int32_t res_sexp;          /* scale exponent of the residual buffer */
     int32_t x2q;               /* 1: the f16x2 + fp8 arithmetic: one source with DISCO_PLANE_QL planes, c_in0 a multiple of 64,
                                   weights packed with x2q = 1 */
+    int32_t q6;                /* 1: the f16 + fp6x2 arithmetic (the default of the HourGlass2): sources with DISCO_PLANE_Q6 planes, weights packed
+                                  with variant 2; q planes of the output: DISCO_PLANE_Q6 */
     int32_t d2s;               /* 1: depth-to-space epilogue (the sub-pixel up-convs / transposed convs of the forward): c_out = 4 C
                                   phase-major output channels, channel ph*C + c of input pixel (y, x) goes to channel c of pixel
                                   (2y + ph/2, 2x + ph%2) of an (n, C, 2h, 2w) activation buffer; C a multiple of 32; stride 1 */
 } disco_conv_mx_desc;
-/* d_packed == NULL: only *bytes.  d_wexp: device int32 [round_up(c_out, 32)], the per-output-channel weight scale exponents */
+/* d_packed == NULL: only *bytes.  d_wexp: device int32 [round_up(c_out, 32)], the per-output-channel weight scale exponents.
+ * x2q: the pack variant = arithmetic: 0 f16 + fp8x2, 1 f16x2 + fp8 (x2q), 2 f16 + fp6x2 */
 int disco_op_conv3x3_mx_pack(const float *h_w_oihw, int c_out, int c_in, int x2q, void *d_packed, int32_t *d_wexp,
                              size_t *bytes);
 int disco_op_conv3x3_mx(const disco_conv_mx_desc *d, const void *d_src0, const void *d_src1, const void *d_packed_w,

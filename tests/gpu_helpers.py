@@ -118,7 +118,7 @@ def pack_conv_mx(w, x2q=False):
     w = w.detach().cpu().float().contiguous()
     co, ci = w.shape[:2]
     nbytes = C.c_size_t()
-    _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(None, co, ci, int(x2q), None, None, C.byref(nbytes)))
+    _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(None, co, ci, int(x2q), None, None, C.byref(nbytes)))        # x2q: the pack variant 0 / 1 / 2
     buf = torch.empty(nbytes.value, device=DEV, dtype=torch.uint8)
     wexp = torch.empty((co + 31) // 32 * 32, device=DEV, dtype=torch.int32)
     _ffi.check(_ffi.lib().disco_op_conv3x3_mx_pack(_ffi.ptr(w), co, ci, int(x2q), _ffi.ptr(buf), _ffi.ptr(wexp), C.byref(nbytes)))
@@ -126,16 +126,16 @@ def pack_conv_mx(w, x2q=False):
 
 
 def conv3x3_mx(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1, act=_ffi.ACT_NONE, slope=0.0, bn_scale=None,
-               bn_shift=None, res=None, out_planes=_ffi.PLANE_LO, out_sexp=0, out_f32=False, packed=None, x2q=False, d2s=False, tapmask=False):
+               bn_shift=None, res=None, out_planes=_ffi.PLANE_LO, out_sexp=0, out_f32=False, packed=None, x2q=False, d2s=False, tapmask=False, q6=False):
     """src*: MxAct with q planes (x2q: one source with al8-only planes, PLANE_QL); res: MxAct (hi [+ lo]).
     Returns (MxAct | fp32 NCHW tensor, saturation count)."""
     h_in, w_in = src0.h * (2 if up0 else 1), src0.w * (2 if up0 else 1)
     co = w.shape[0]
-    buf, wexp = packed or pack_conv_mx(w, x2q)
+    buf, wexp = packed or pack_conv_mx(w, 2 if q6 else int(x2q))
     ho, wo = (h_in - 1) // stride + 1, (w_in - 1) // stride + 1
     d = _ffi.ConvMxDesc(src0.n, h_in, w_in, src0.c_pad, src1.c_pad if src1 is not None else 0, int(up0), int(up1), src0.sexp,
                         src1.sexp if src1 is not None else 0, co, stride, act, slope, out_planes, out_sexp, int(out_f32),
-                        res.planes if res is not None else 0, res.sexp if res is not None else 0, int(x2q), int(d2s))
+                        res.planes if res is not None else 0, res.sexp if res is not None else 0, int(x2q), int(q6), int(d2s))
     out = torch.empty(src0.n, co, ho, wo, device=DEV, dtype=torch.float32) if out_f32 else (
         MxAct(src0.n, co // 4, 2 * ho, 2 * wo, out_planes, out_sexp) if d2s else MxAct(src0.n, co, ho, wo, out_planes, out_sexp))
     sat = torch.zeros(1, device=DEV, dtype=torch.int32)

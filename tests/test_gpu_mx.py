@@ -226,3 +226,98 @@ def test_conv3x3_mx_masked_depth_to_space_is_run_to_run_deterministic(H, x2q):
     for o in bufs[1:]:
         assert torch.equal(o, bufs[0])
     assert sat == 0 and H.max_err(out.read(2), want) < TOL * max(1.0, want.abs().max().item())
+
+
+# ---- the f16 + fp6x2 arithmetic (AR 3, the HourGlass2's default since round 3) ---------------------------------------------------------
+Q6 = _ffi.PLANE_Q6
+TOL6 = 4e-4      # the correction products carry 3 mantissa bits and fp6's narrow exponent range: ~2^-14 of the accumulated |w||a| mass
+                 # (fp8: 2^-16); end to end this leaves 2-3e-4 on ab against the 1e-3 bar
+
+
+def test_mx6_layout_roundtrip(H):
+    """MX fp6 q planes: one E8M0 scale per pixel and 32 channels (byte 24 of the slot), so a6 is x to 3 mantissa bits for every value
+    within a factor 4 of ITS pixel-block's maximum (fp6 e2m3 has 2 exponent bits; below that the subnormal step of the block's scale),
+    whatever the tensor's range; hi + al6 is x to 2^-14.5 of the block maximum."""
+    x = torch.randn(2, 64, 9, 11, generator=g(0)) * 3
+    x[:, :, :4] *= 2.0 ** -6                                   # rows at 1/64 of the rest: a per-tensor scale would flush them to fp6 zero
+    a = H.to_act_mx(x, LO | Q6)
+    assert H.max_err(a.read(0).cpu(), x) < 2e-7 * 16
+    a6 = a.read(1).cpu()
+    bmax = x.reshape(2, 2, 32, 9, 11).abs().amax(2, keepdim=True).expand(2, 2, 32, 9, 11).reshape(x.shape)
+    big = x.abs() > bmax / 4
+    assert ((a6 - x).abs()[big] <= x.abs()[big] * 2 ** -3.9).all()
+    assert ((a6 - x).abs() <= bmax * 2 ** -3.9).all()
+    assert ((a.read(2).cpu() - x).abs() <= bmax * 2 ** -14.5).all()
+
+
+MX6_CASES = [
+    # cin, cout, h, w, stride, act, slope, bn, res, out_planes
+    (64, 64, 32, 32, 1, _ffi.ACT_LRELU, 0.2, True, False, Q6),
+    (32, 64, 24, 40, 1, _ffi.ACT_RELU, 0.0, True, False, LO | Q6),
+    (64, 128, 32, 64, 2, _ffi.ACT_LRELU, 0.2, True, False, Q6),
+    (256, 32, 8, 8, 1, _ffi.ACT_RELU, 0.0, False, True, LO | Q6),
+    (96, 64, 17, 33, 1, _ffi.ACT_NONE, 0.0, False, False, Q6),      # ragged: partial tiles, odd sizes
+    (256, 256, 32, 32, 1, _ffi.ACT_RELU, 0.0, False, False, Q6),
+    (64, 64, 64, 64, 1, _ffi.ACT_RELU, 0.0, False, False, Q6),
+]
+
+
+@pytest.mark.parametrize("case", MX6_CASES)
+def test_conv3x3_mx6_matches_torch(H, case):
+    cin, cout, h, w, stride, act, slope, use_bn, use_res, planes = case
+    gen = g(cin * 1000 + cout + h + 6)
+    n = 3
+    x = torch.randn(n, cin, h, w, generator=gen)
+    if cin >= 128: x = F.relu(x)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    bn = (torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.1) if use_bn else None
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = torch.randn(n, cout, ho, wo, generator=gen) if use_res else None
+    want = _ref(x, wt, b, stride, act, slope, bn, res)
+    scale = max(1.0, want.abs().max().item())
+    kw = dict(stride=stride, act=act, slope=slope, bn_scale=bn[0] if bn else None, bn_shift=bn[1] if bn else None, q6=True)
+    out, sat = H.conv3x3_mx(H.to_act_mx(x, Q6), wt, b, res=H.to_act_mx(res, LO) if use_res else None, out_planes=planes,
+                            out_sexp=H.sexp_for(want), **kw)
+    assert sat == 0
+    if planes & LO:
+        assert H.max_err(out.read(0), want) < TOL6 * scale
+    assert H.max_err(out.read(2), want) < (TOL6 + 2 ** -12) * scale           # hi + dequantised al6: the fp6 slots landed where they belong
+    a6 = out.read(1).cpu().double()
+    assert (a6 - want).abs().max() <= scale * 2 ** -3.9 + TOL6 * scale
+    if not use_res:
+        out32, _ = H.conv3x3_mx(H.to_act_mx(x, Q6), wt, b, out_f32=True, **kw)
+        assert H.max_err(out32, want) < TOL6 * scale
+    # five repeats: byte-identical raw buffers
+    first = out.buf.clone()
+    for _ in range(3):
+        again, _ = H.conv3x3_mx(H.to_act_mx(x, Q6), wt, b, res=H.to_act_mx(res, LO) if use_res else None, out_planes=planes,
+                                out_sexp=H.sexp_for(want), **kw)
+        assert torch.equal(again.buf, first)
+
+
+def test_conv3x3_mx6_two_source_fp8_in_fp6_out_and_depth_to_space(H):
+    """The two joints of the fp6 HourGlass2: its first layer is a two-source f16+fp8x2 layer (fp8 planes from the upfeat / gray kernels)
+    that WRITES fp6 planes; its up-convs are masked 4-phase convs with the depth-to-space epilogue."""
+    gen = g(31)
+    a = torch.randn(2, 64, 24, 40, generator=gen); s = torch.randn(2, 32, 24, 40, generator=gen)
+    wt = torch.randn(64, 96, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * 96)); b = torch.randn(64, generator=gen) * 0.1
+    want = _ref(torch.cat((a, s), 1), wt, b, 1, _ffi.ACT_RELU, 0.0, None, None)
+    e = min(H.sexp_for(a), H.sexp_for(s))
+    out, sat = H.conv3x3_mx(H.to_act_mx(a, sexp=e), wt, b, src1=H.to_act_mx(s, sexp=e), act=_ffi.ACT_RELU, out_planes=Q6, out_sexp=H.sexp_for(want))
+    assert sat == 0 and H.max_err(out.read(2), want) < (TOL + 2 ** -12) * max(1.0, want.abs().max().item())
+    with pytest.raises(_ffi.DiscoError):      # a one-source f16+fp8x2 layer cannot write fp6 planes (that path is not compiled in)
+        H.conv3x3_mx(H.to_act_mx(a), torch.randn(64, 64, 3, 3) * 0.05, b, out_planes=Q6)
+    n, cin, C, h, w = 2, 128, 32, 13, 19
+    x = torch.relu(torch.randn(n, cin, h, w, generator=gen))
+    w3 = torch.randn(C, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    w4 = torch.zeros(4 * C, cin, 3, 3)
+    for py in range(2):
+        for px in range(2):
+            for ky in range(3):
+                for kx in range(3):
+                    w4[(py * 2 + px) * C:(py * 2 + px + 1) * C, :, ((py + ky - 1) >> 1) + 1, ((px + kx - 1) >> 1) + 1] += w3[:, :, ky, kx]
+    bb = torch.randn(C, generator=gen) * 0.1
+    want = F.relu(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w3.double(), bb.double(), padding=1))
+    out, sat = H.conv3x3_mx(H.to_act_mx(x, Q6), w4, bb, act=_ffi.ACT_RELU, out_planes=Q6, out_sexp=H.sexp_for(want.float()), q6=True, d2s=True, tapmask=True)
+    assert sat == 0 and H.max_err(out.read(2), want) < (TOL6 + 2 ** -12) * max(1.0, want.abs().max().item())

@@ -23,7 +23,7 @@ ap.add_argument("--modes", default="x2q,mx8all")
 args = ap.parse_args()
 K = 8
 sd = synth.synth_state_dict(130)
-modes = ["mx8"] + args.modes.split(",")
+modes = ["mx8"] + args.modes.split(",")          # ("mx8" and the default "mx6" share the f16x3 anchor path: identical anchors)
 models = {}
 for prec in modes:
     m = AnchorColorProb(n_clusters=K, enhanced=True, precision=prec, init_weights=False)

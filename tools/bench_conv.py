@@ -46,7 +46,7 @@ def bench_mx(L, args, name, c0, c1, co, hin, stride, up0):
     ho = (hin - 1) // stride + 1
     out = H.MxAct(n, co, ho, ho, _ffi.PLANE_QL if xq else _ffi.PLANE_Q, 0)
     bias = torch.zeros(co, device="cuda")
-    d = _ffi.ConvMxDesc(n, hin, hin, c0, c1, up0, 0, x0.sexp, x1.sexp if x1 else 0, co, stride, _ffi.ACT_RELU, 0.0, _ffi.PLANE_QL if xq else _ffi.PLANE_Q, 0, 0, 0, 0, int(xq))
+    d = _ffi.ConvMxDesc(n, hin, hin, c0, c1, up0, 0, x0.sexp, x1.sexp if x1 else 0, co, stride, _ffi.ACT_RELU, 0.0, _ffi.PLANE_QL if xq else _ffi.PLANE_Q, 0, 0, 0, 0, int(xq), 0)
 
     def run():
         _ffi.check(L.disco_op_conv3x3_mx(C.byref(d), _ffi.ptr(x0.buf), _ffi.ptr(x1.buf) if x1 else None, _ffi.ptr(packed), _ffi.ptr(wexp),

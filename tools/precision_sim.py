@@ -11,6 +11,8 @@ Every 3x3 conv of the oracle is replaced by an emulation of how the HIP kernel w
   x2q   : w_h a_h + w_l a_h + q8(w) q8(a_l)    (2 fp16 MFMAs + 1 fp8: the weight residual exact, the activation residual in fp8)
   x2qw  : w_h a_h + w_h a_l + q8(w_l) q8(a_h)  (the mirror image)
   mx8w1 : w_h a_h + q8(w_l) q8(a_h)            (activation residual dropped altogether)
+  mx6b / mx6u / mx6uh : as mx8 with fp6 e2m3 operands (the K=64 MFMA runs them in half the passes of fp8): MX block scales per 32
+          channels / one scale per activation tensor / that with 2 bits of headroom
 and the end-to-end deviation of pred_colors from the fp32 oracle and anchor agreement are reported.
 
     python tools/precision_sim.py [--size 128] [--seeds 4] [--modes mx8,mx8u,wh]
@@ -53,6 +55,36 @@ def q8_block(x, dim):
     return q.reshape(shp).movedim(-1, dim)
 
 
+def q6(x):
+    """fp6 e2m3 (OCP MX: 1 sign, 2 exponent, 3 mantissa bits; max 7.5, subnormal step 0.125), round to nearest even, saturating."""
+    ax = x.abs().clamp(max=7.5)
+    e = torch.floor(torch.log2(ax.clamp_min(1.0)))            # 0 for the subnormal / first binade, up to 2
+    step = torch.exp2(e - 3)
+    return torch.sign(x) * torch.round(ax / step) * step        # torch.round = half to even
+
+
+def q6_block(x, dim):
+    """fp6 e2m3 with a power-of-two scale per 32 consecutive elements along `dim`: block max in (3.75, 7.5]."""
+    x = x.movedim(dim, -1)
+    shp = x.shape
+    c = shp[-1]
+    pad = (-c) % 32
+    if pad:
+        x = F.pad(x, (0, pad))
+    xb = x.reshape(*x.shape[:-1], -1, 32)
+    amax = xb.abs().amax(-1, keepdim=True).clamp_min(1e-38)
+    s = torch.exp2(torch.ceil(torch.log2(amax / 7.5)))
+    q = q6(xb / s) * s
+    q = q.reshape(*x.shape)[..., :c]
+    return q.reshape(shp).movedim(-1, dim)
+
+
+def q6_tensor(x, headroom_bits=0):
+    amax = x.abs().max().clamp_min(1e-38)
+    s = torch.exp2(torch.ceil(torch.log2(amax / 7.5)) + headroom_bits)
+    return q6(x / s) * s
+
+
 def q8_tensor(x, headroom_bits=3):
     amax = x.abs().max().clamp_min(1e-38)
     s = torch.exp2(torch.floor(torch.log2(amax)) - (8 - headroom_bits))
@@ -87,6 +119,12 @@ class Emu:
             y = cv(ah, wh) + cv(al, wh) + cv(q8_tensor(ah), q8_tensor(wl))
         elif mode == "mx8w1":    # only the weight residual corrected (fp8), the activation residual dropped: 3 units per 32 channels
             y = cv(ah, wh) + cv(q8_tensor(ah), q8_tensor(wl))
+        elif mode == "mx6b":     # both corrections in fp6 e2m3 with MX block scales (per pixel / per cout and tap, 32 channels)
+            y = cv(ah, wh) + cv(q6_block(al, 1), q6_block(wh, 1)) + cv(q6_block(ah, 1), q6_block(wl, 1))
+        elif mode == "mx6u":     # fp6 with ONE scale per tensor (weights: per cout row)
+            y = cv(ah, wh) + cv(q6_tensor(al), q6_block(wh, 1)) + cv(q6_tensor(ah), q6_block(wl, 1))
+        elif mode == "mx6uh":    # ... with 2 bits of calibration headroom on the activation side
+            y = cv(ah, wh) + cv(q6_tensor(al, 2), q6_block(wh, 1)) + cv(q6_tensor(ah, 2), q6_block(wl, 1))
         elif mode == "mx8u":
             y = cv(ah, wh) + cv(q8_tensor(al), q8_tensor(wh)) + cv(q8_tensor(ah), q8_tensor(wl))
         else:
