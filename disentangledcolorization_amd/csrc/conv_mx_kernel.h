@@ -187,7 +187,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     int wsc[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) wsc[j] = X3 ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];       // (wexp: fp8 or fp6 scaling, conv_mx_pack_host)
-    // pixel-side E8M0 scale: 1 (the tensor's scale stays in the accumulators); fp6 planes hold xs 2^-3
+    // pixel-side E8M0 scale: 1 (the tensor's scale stays in the accumulators)
     constexpr int asc0 = 127, asc1 = asc0;                // fp8 activation planes: no block scale.  fp6 slots: dword 6 of the fragment (below)
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[0].p, 0, a.src_bytes[0], 0x00020000);

@@ -217,9 +217,11 @@ int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d
 #define DISCO_PLANE_LO 1
 #define DISCO_PLANE_Q 2
 #define DISCO_PLANE_QL 4   /* instead of DISCO_PLANE_Q: only the al8 planes, [N][C/32][H][W][32] (operands of the x2q arithmetic) */
-#define DISCO_PLANE_Q6 8   /* instead of DISCO_PLANE_Q: fp6 (OCP e2m3) planes in the same geometry: a6 = fp6(xs 2^-3), al6 = fp6((xs - hi) 2^8);
+#define DISCO_PLANE_Q6 8   /* instead of DISCO_PLANE_Q: MX fp6 (OCP e2m3) planes in the same geometry, block-scaled per pixel and 32 channels:
                               a pixel's 32-byte slot holds the 32 six-bit fields of its 32-channel block in bytes 0-23 (little-endian bit
-                              stream; field 4g+i = channel 8g+i, field 16+4g+i = channel 8g+4+i) - operands of the f16 + fp6x2 arithmetic */
+                              stream; field 4g+i = channel 8g+i, field 16+4g+i = channel 8g+4+i) and its E8M0 scale byte in byte 24;
+                              with E = the fp16 exponent of the block's largest |hi|: a6 = fp6(hi / 2^(E-2)), scale byte 127 + E - 2;
+                              al6 = fp6((xs - hi) / 2^(E-14)), scale byte 127 + E - 3 - operands of the f16 + fp6x2 arithmetic */
 int disco_op_act_bytes(int n, int c_pad, int h, int w, int planes, size_t *bytes);
 int disco_op_nchw_to_act_mx(const float *d_src, void *d_dst, int n, int c, int h, int w, int c_pad, int planes, int sexp,
                             void *stream);

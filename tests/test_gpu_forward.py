@@ -363,7 +363,23 @@ def test_precision_mode_x2q_against_oracle(synth_sd, q_to_ab):
     assert torch.equal(one[2][0], out[2][1]) and torch.equal(one[5][0], out[5][1])
 
 
-@pytest.mark.parametrize("prec", ["mx8", "x2q", "f16x3"])
+@pytest.mark.parametrize("prec", ["mx8", "f16x3"])
+def test_non_default_precision_modes_against_oracle(synth_sd, q_to_ab, prec):
+    """precision="mx8" (rounds 2-3's default: fp8 correction operands in the HourGlass2) and "f16x3" (round 1: everything on the split-fp16
+    arithmetic) stay supported next to the "mx6" default: anchors exact, |ab| within the bar (measured 1.0e-4 / 1e-5)."""
+    gray, ab = synth.synth_inputs(2, 128, 192, seed=61)
+    m = AnchorColorProb(n_clusters=8, enhanced=True, precision=prec, init_weights=False)
+    m.load_state_dict(synth_sd); m = m.cuda().eval()
+    _seed(130); out = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    assert m.saturation_count() == 0
+    _seed(130); want = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=8).forward(gray, ab)
+    assert torch.equal(out[5].cpu(), want[5])
+    assert _err(out[2], want[2]) <= (2e-4 if prec == "mx8" else 5e-5)
+    assert _err(out[0], want[0]) < 5e-5
+
+
+@pytest.mark.parametrize("prec", ["mx6", "mx8", "x2q", "f16x3"])
 def test_forward_is_run_to_run_deterministic(synth_sd, prec):
     """Every output of three forwards on the same inputs and draws must agree bit for bit, in every precision mode (a store-data
     hazard in the conv epilogue once made the lo planes - and with them everything downstream - differ from run to run)."""

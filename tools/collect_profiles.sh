@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 python $R/tools/pmc_sum.py $O/pmc_sq1 conv3x3 > $O/conv_pmc.txt; python $R/tools/pmc_sum.py $O/pmc_sq2 conv3x3 >> $O/conv_pmc.txt
 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --precision x2q > $O/bench_x2q.json 2> $O/bench_x2q.err
 python $R/tools/profile_layers.py > $O/final_layers.txt 2>&1
+python $R/tools/profile_layers.py --precision mx8 > $O/layers_mx8.txt 2>&1
 python $R/tools/profile_layers.py --precision x2q > $O/layers_x2q.txt 2>&1
 python $R/tools/bench_conv.py --mx 4 > $O/bench_conv_x2q.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -Wno-unused-value $R/tools/lds_dma_rate.hip -o /tmp/lds_dma_rate 2>/dev/null && /tmp/lds_dma_rate > $O/lds_dma_rate.txt 2>&1
