@@ -687,6 +687,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int cl = (wn * NTW + nt) * 32 + 8 * g4 + 4 * kh;
+                    // (outConv has 2 output channels, pred_mask0 9: a group of 8 channels beyond c_out is skipped - wave-uniform - with
+                    // its 16 tanhf / expf per lane)
+                    if ((by_e * NT + wn * NTW + nt) * 32 + 8 * g4 >= a.c_out) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[4 * g4 + j] = 0.f;
+                        continue;
+                    }
                     const float4 b4 = *(const __attribute__((address_space(3))) float4*)(par_e + cl);
                     float x[4] = {fmaf(acc[mt][nt][4 * g4], acc_mul, b4.x), fmaf(acc[mt][nt][4 * g4 + 1], acc_mul, b4.y), fmaf(acc[mt][nt][4 * g4 + 2], acc_mul, b4.z),
                                   fmaf(acc[mt][nt][4 * g4 + 3], acc_mul, b4.w)};
@@ -718,6 +725,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                     float sm = 0.f;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
+                        if (cob + 8 * (e >> 2) >= a.c_out) { v[e] = 0.f; continue; }          // wave-uniform
                         v[e] = cob + (e & 3) + 8 * (e >> 2) + 4 * kh < a.c_out ? expf(v[e] - mx) : 0.f;
                         sm += v[e];
                     }
@@ -773,6 +781,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
+                        if (cob + (e & 3) + 8 * (e >> 2) >= a.c_out) continue;       // no lane has this channel (wave-uniform)
                         const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;        // differs between the half-waves: per-lane offset
                         const unsigned vof = (vo[mt] == OOB || co >= a.c_out) ? OOB : vo[mt] + (unsigned)(n * a.c_out + co) * ohw * 4u;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[e]), ro, vof, 0, 0);
