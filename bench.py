@@ -303,7 +303,7 @@ def main():
         if model is not None:
             achieved = conv_fl / (conv_ms * 1e-3) if conv_ms > 0 else 0.0
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv3x3_mx_kernel (all instantiations: the f16x3, f16+fp8x2 and f16x2+fp8 arithmetics share one skeleton)",
+                "bound": "mfma", "kernel": "conv3x3_mx_kernel (all instantiations: the f16x3, f16+fp6x2, f16+fp8x2 and f16x2+fp8 arithmetics share one skeleton)",
                 "achieved": round(achieved / 1e12, 2), "peak": FP16_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic(),
                 "launches_per_step": conv_launches // prof_steps,
