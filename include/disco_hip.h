@@ -71,10 +71,11 @@ typedef struct disco_ctx disco_ctx;
                               stay on DISCO_PREC_F16X3.  Measured: max |ab - reference| ~1e-4, anchors identical. */
 #define DISCO_PREC_MX8_ALL 3 /* every conv stack on the fp8-corrected kernel: ~6% faster again, but the ~3e-5 perturbation it
                               leaves at the encoder output flips k-means anchors in ~1% of images (measurements only) */
-#define DISCO_PREC_MX6 5     /* the default since round 3: as DISCO_PREC_MX8 with the two correction products of the HourGlass2 in fp6 (OCP e2m3)
-                              instead of fp8: the K = 64 MFMA runs fp6 operands in half the passes.  Same structure, same per-tensor
-                              scales; the first HourGlass2 layer still reads fp8 planes (its producers write those) and writes fp6 ones.
-                              Measured: max |ab - reference| ~2-3e-4 (MX8: 1.3e-4), anchors identical (they are decided upstream). */
+#define DISCO_PREC_MX6 5     /* the default since round 3: as DISCO_PREC_MX8 with the two correction products of the HourGlass2 in MX fp6 (OCP e2m3,
+                              one E8M0 block scale per pixel and 32 channels on the activation side: DISCO_PLANE_Q6) instead of fp8: the K = 64
+                              MFMA runs fp6 operands in half the passes.  The first HourGlass2 layer still reads fp8 planes (its producers
+                              write those) and writes fp6 ones.  Measured: max |ab - reference| 1.2-1.3e-4 (MX8: 1.0-1.1e-4 on the same
+                              inputs), anchors identical (they are decided upstream); 2-3 % faster end to end. */
 #define DISCO_PREC_X2Q 4     /* as DISCO_PREC_MX6, and the ColorProbNet on the same kernel's second arithmetic: w_h a_h + w_l a_h
                               in fp16 and only the activation residual in fp8 (5 matrix-pipe units per 32 channels and tap
                               instead of 6).  ~1.4e-5 at the encoder output where F16X3 leaves ~5e-6; anchors differ from the fp32 reference

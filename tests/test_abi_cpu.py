@@ -154,7 +154,11 @@ def test_mx_weight_pack_and_fp8_codec(lib):
     # the f16x2+fp8 arithmetic: 5 chunks (H L H L Q) per 64 input channels
     assert lib.disco_op_conv3x3_mx_pack(None, 64, 65, 1, None, None, C.byref(nb)) == 0
     assert nb.value == 2 * (128 // 64 * 5) * 9 * 2 * 1024
+    # the f16+fp6x2 arithmetic: the geometry of variant 0 (fp6 slots are 32 bytes, 24 used); callable on the host alone
+    assert lib.disco_op_conv3x3_mx_pack(None, 64, 65, 2, None, None, C.byref(nb)) == 0
+    assert nb.value == 2 * (96 // 16) * 9 * 2 * 1024
     assert lib.disco_op_conv3x3_mx(None, None, None, None, None, None, None, None, None, None, None, None, None) < 0
     ab = C.c_size_t()
     assert lib.disco_op_act_bytes(2, 64, 8, 8, _ffi.PLANE_LO | _ffi.PLANE_Q, C.byref(ab)) == 0 and ab.value == 2 * 64 * 64 * 6
     assert lib.disco_op_act_bytes(2, 64, 8, 8, _ffi.PLANE_QL, C.byref(ab)) == 0 and ab.value == 2 * 64 * 64 * 3     # hi + al8 only
+    assert lib.disco_op_act_bytes(2, 64, 8, 8, _ffi.PLANE_Q6, C.byref(ab)) == 0 and ab.value == 2 * 64 * 64 * 4     # hi + a6 | al6 slots

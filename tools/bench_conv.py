@@ -39,14 +39,17 @@ def bench_mx(L, args, name, c0, c1, co, hin, stride, up0):
     x0 = H.to_act_mx(z * torch.relu(torch.randn(n, c0, hs, hs, device="cuda")), sexp=2)
     x1 = H.to_act_mx(z * torch.relu(torch.randn(n, c1, hin, hin, device="cuda")), sexp=2) if c1 else None
     w = torch.randn(co, c0 + c1, 3, 3) * 0.05 * z
-    xq = args.mx >= 3
-    if xq:
-        x0 = H.to_act_mx(z * torch.relu(torch.randn(n, c0, hs, hs, device="cuda")), planes=_ffi.PLANE_QL, sexp=2)
-    packed, wexp = H.pack_conv_mx(w, xq)
+    xq = args.mx in (3, 4)
+    q6 = args.mx == 6
+    planes = _ffi.PLANE_QL if xq else (_ffi.PLANE_Q6 if q6 else _ffi.PLANE_Q)
+    if xq or q6:
+        x0 = H.to_act_mx(z * torch.relu(torch.randn(n, c0, hs, hs, device="cuda")), planes=planes, sexp=2)
+        x1 = H.to_act_mx(z * torch.relu(torch.randn(n, c1, hin, hin, device="cuda")), planes=planes, sexp=2) if c1 else None
+    packed, wexp = H.pack_conv_mx(w, 2 if q6 else int(xq))
     ho = (hin - 1) // stride + 1
-    out = H.MxAct(n, co, ho, ho, _ffi.PLANE_QL if xq else _ffi.PLANE_Q, 0)
+    out = H.MxAct(n, co, ho, ho, planes, 0)
     bias = torch.zeros(co, device="cuda")
-    d = _ffi.ConvMxDesc(n, hin, hin, c0, c1, up0, 0, x0.sexp, x1.sexp if x1 else 0, co, stride, _ffi.ACT_RELU, 0.0, _ffi.PLANE_QL if xq else _ffi.PLANE_Q, 0, 0, 0, 0, int(xq), 0)
+    d = _ffi.ConvMxDesc(n, hin, hin, c0, c1, up0, 0, x0.sexp, x1.sexp if x1 else 0, co, stride, _ffi.ACT_RELU, 0.0, planes, 0, 0, 0, 0, int(xq), int(q6), 0)
 
     def run():
         _ffi.check(L.disco_op_conv3x3_mx(C.byref(d), _ffi.ptr(x0.buf), _ffi.ptr(x1.buf) if x1 else None, _ffi.ptr(packed), _ffi.ptr(wexp),
@@ -62,7 +65,7 @@ def bench_mx(L, args, name, c0, c1, co, hin, stride, up0):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
     fl = 2.0 * 9 * (c0 + c1) * co * ho * ho * n
-    print(f"{name:22s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF alg  {2 * fl / ms / 1e9:8.1f} TF-equivalent pipe units   [{'x2q' if args.mx >= 3 else 'mx'}]", flush=True)
+    print(f"{name:22s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF alg  {2 * fl / ms / 1e9:8.1f} TF-equivalent pipe units   [{'x2q' if xq else ('mx6' if q6 else 'mx8')}]", flush=True)
 
 
 def main():
@@ -72,7 +75,7 @@ def main():
     ap.add_argument("--prec", type=int, default=0)
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--zeros", type=int, default=0, help="1: all-zero activations and weights (how much of the time is the power-managed clock?)")
-    ap.add_argument("--mx", type=int, default=0, help="1: the fp16 + fp8-correction kernel (conv_mx.hip); 2: both, side by side; 3: its f16x2 + fp8 arithmetic alone; 4: that and f16x3 side by side")
+    ap.add_argument("--mx", type=int, default=0, help="1: the fp16 + fp8-correction kernel (conv_mx.hip); 2: both, side by side; 3: its f16x2 + fp8 arithmetic alone; 4: that and f16x3 side by side; 6: its f16 + fp6x2 arithmetic alone")
     args = ap.parse_args()
     L = _ffi.lib()
     for name, c0, c1, co, hin, stride, up0 in SHAPES:
@@ -81,11 +84,11 @@ def main():
         n = args.n
         if args.mx and (c0 % 32 or c1 % 32 or co < 32):
             continue
-        if args.mx >= 3 and (c0 % 64 or c1):
+        if args.mx in (3, 4) and (c0 % 64 or c1):
             continue
         if args.mx:
             bench_mx(L, args, name, c0, c1, co, hin, stride, up0)
-            if args.mx in (1, 3):
+            if args.mx in (1, 3, 6):
                 continue
         hs = hin // 2 if up0 else hin
         z = 0.0 if args.zeros else 1.0       # --zeros: the same launch on all-zero operands (how much of the time is the power-managed clock?)
