@@ -76,6 +76,9 @@ SIGNATURES = {
     "disco_forward_segnet": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "disco_sync": (_I, [_P]),
     "disco_set_profiling": (_I, [_P, _I]),
+    "disco_set_progress_event": (_I, [_P, _P, _I]),
+    "disco_set_debug_checksums": (_I, [_P, _P, _I, _I]),
+    "disco_set_debug_dump": (_I, [_P, _P, _SZ]),
     "disco_profile_count": (_I, [_P]),
     "disco_profile_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "disco_profile_conv": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),

@@ -13,7 +13,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdisco_hip.so")
-SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.hip", "conv_mx_ar1.hip", "conv_mx_ar2.hip", "conv_mx_ar3.hip", "conv_direct.hip", "color.hip", "spixel.hip", "tokens.hip", "diag.hip"]
+SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.hip", "conv_mx_ar1.hip", "conv_mx_ar2.hip", "conv_mx_ar3.hip", "conv_direct.hip", "color.hip", "spixel.hip", "pool.hip", "tokens.hip", "diag.hip"]
+# per-file extra flags (pool.hip: see the note at pool_partial_kernel)
+EXTRA_FLAGS = {"pool.hip": ["-fno-slp-vectorize"]}
 HEADERS = ["common.h", "conv_mx_kernel.h", os.path.join("..", "..", "include", "disco_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
@@ -39,7 +41,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         sp, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(sp), []) + ["-c", sp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (sp, r.stderr))

@@ -192,6 +192,14 @@ struct disco_ctx {
     Staging stg[4];
     int stg_next = 0;
     int profiling = 0;
+    // disco_set_progress_event: recorded on the next forward's stream behind its `progress_after`-th MFMA conv launch (one shot)
+    hipEvent_t progress_ev = nullptr;
+    int progress_after = 0, progress_seen = 0;
+    // disco_set_debug_checksums: every forward adds a checksum of each stage's output to row (sequence number % rows) of this table
+    unsigned long long* d_dbg = nullptr;
+    char* d_dump = nullptr; size_t dump_stride = 0;     // disco_set_debug_dump: per-row copies of the first token GEMM's input and output
+    int dbg_rows = 0, dbg_cols = 0;
+    long dbg_seq = 0;
     std::vector<ProfEntry> prof;
     struct ConvProf { hipEvent_t e0, e1; double flops; std::string key; double bytes; };
     std::vector<ConvProf> conv_prof;
@@ -529,6 +537,15 @@ struct Plan {
         return t;
     }
     void drop(Act& t) { drop((void*)t.p); t.p = nullptr; }
+    long dbg_row = -1;
+    int dbg_col = 0;
+    // debugging aid: checksum of a stage's output into the context's table (tools/stagger_probe.py finds the first stage whose
+    // result depends on what else runs on the GPU)
+    void dbg(const void* p, size_t bytes) {
+        if (dry || calib || dbg_row < 0 || !ok() || !p) return;
+        if (dbg_col < c->dbg_cols) rc = launch_checksum(p, bytes, c->d_dbg + dbg_row * c->dbg_cols + dbg_col, s);
+        ++dbg_col;
+    }
     void mark(const char* name, double flops = 0.0) {
         if (dry || !c->profiling || !ok()) return;
         hipEvent_t ev;
@@ -662,6 +679,11 @@ struct Plan {
             launch();
             if (!out_f32) calibrate(key, out, launch, tie);
         }
+        if (out_f32) dbg(out_f32, (size_t)in0.n * co_t * ho * wo * 4); else dbg(out.p, out.bytes());
+        if (!calib && c->progress_ev && ++c->progress_seen >= c->progress_after) {
+            if (hipEventRecord(c->progress_ev, s) != hipSuccess && ok()) rc = DISCO_EHIP;
+            c->progress_ev = nullptr;
+        }
         if (timed) {
             hipEventRecord(e1, s);
             // algorithmic FLOPs (the reference's dense count on its real channels): 16 taps for a ConvTranspose 4x4 s2 and 9 taps
@@ -689,6 +711,7 @@ struct Plan {
         auto launch = [&]() { rc = launch_conv_c1(gray, L.d_w, L.d_bias, nullptr, nullptr, out, L.c_out, actc, slope, calib ? nullptr : c->d_sat, s); };
         launch();
         calibrate(key, out, launch);
+        dbg(out.p, out.bytes());
         return out;
     }
 };
@@ -740,6 +763,10 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
         c->prof.clear();
         for (auto& e : c->conv_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
         c->conv_prof.clear();
+    }
+    if (!dry && !calib && c->d_dbg && c->dbg_rows > 0) {
+        P.dbg_row = c->dbg_seq++ % c->dbg_rows;
+        if (hipMemsetAsync(c->d_dbg + P.dbg_row * c->dbg_cols, 0, (size_t)c->dbg_cols * 8, s) != hipSuccess) P.rc = DISCO_EHIP;
     }
     P.mark("start");
 
@@ -793,16 +820,43 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
         pa.conf = nullptr; pa.sizes = sizes; pa.n = n; pa.H = H; pa.W = W; pa.sp = sp;
         P.rc = launch_poolfeat(pa, s);
     }
+    if (!dry && P.ok() && P.dbg_row >= 0 && c->d_dump) {
+        // debugging aid: [tokens after pool][tokens at the first GEMM][q|k|v][affinity][feats hi+lo] per row
+        char* dst = c->d_dump + (size_t)P.dbg_row * c->dump_stride;
+        const size_t sb = (size_t)n * L * 64 * 4, ab_ = (size_t)n * 9 * H * W * 4, fb = feats.bytes();
+        if (5 * sb + ab_ + fb <= c->dump_stride) {
+            hipMemcpyAsync(dst, src, sb, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(dst + 5 * sb, a->d_affinity, ab_, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(dst + 5 * sb + ab_, feats.p, fb, hipMemcpyDeviceToDevice, s);
+        }
+    }
     P.drop(pool_ws); P.drop(feats);
     if (spos) pos = pos_img;
     const int pos_rep = spos ? 1 : 0;       // wild path: one position sequence per image; hint path: per virtual image / rep
+    P.dbg(src, (size_t)n * L * 64 * 4);
     P.mark("poolfeat");
 
     // ---- a6/a7 wild path + palette logits (model.py:133-135) -------------------------------------------------
     float* enc = (float*)P.raw((size_t)n * L * 64 * 4);
     void* enc_ws = P.raw(encoder_ws_bytes(n2, L));
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s);
+    int enc_dbg_calls = 0;
+    const std::function<void(const void*, size_t)> enc_dbg = [&](const void* p, size_t b) {
+        P.dbg(p, b);
+        // the first token GEMM's operands and result, kept for inspection (disco_set_debug_checksums: table rows are followed by
+        // per-row dumps when cols < 0 was passed... see tools/stagger_probe.py --dump)
+        if (enc_dbg_calls++ == 0 && c->d_dump) {
+            char* dst = c->d_dump + (size_t)P.dbg_row * c->dump_stride;
+            const size_t sb = (size_t)n * L * 64 * 4;
+            if (sb + b <= c->dump_stride) {
+                hipMemcpyAsync(dst + sb, src, sb, hipMemcpyDeviceToDevice, s);
+                hipMemcpyAsync(dst + 2 * sb, p, b, hipMemcpyDeviceToDevice, s);
+            }
+        }
+    };
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s, P.dbg_row >= 0 ? &enc_dbg : nullptr);
+    P.dbg(enc, (size_t)n * L * 64 * 4);
     if (!dry && P.ok()) P.rc = launch_logits(enc, c->d_mid_w, a->d_pal_logit, n, L, s);
+    P.dbg(a->d_pal_logit, (size_t)n * N_VOCAB * L * 4);
     P.mark("wildpath", 2.0 * 0.134e9 * n);
 
     // ---- a8/a9 anchors (model.py:141) ---------------------------------------------------------------------------
@@ -1231,7 +1285,32 @@ int disco_forward(disco_ctx* c, const disco_forward_args* a) {
             return DISCO_EINVAL;
     }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
-    return run_plan(c, a, a->workspace_bytes, false, nullptr);
+    rc = run_plan(c, a, a->workspace_bytes, false, nullptr);
+    if (c->progress_ev) {           // fewer conv launches than asked for (or an error): never leave a waiter without its record
+        hipEventRecord(c->progress_ev, (hipStream_t)a->stream);
+        c->progress_ev = nullptr;
+    }
+    return rc;
+}
+
+int disco_set_progress_event(disco_ctx* c, void* event, int after_conv_launches) {
+    if (!c || after_conv_launches < 0) { set_error("disco_set_progress_event: bad argument"); return DISCO_EINVAL; }
+    c->progress_ev = (hipEvent_t)event;
+    c->progress_after = after_conv_launches;
+    c->progress_seen = 0;
+    return DISCO_OK;
+}
+
+int disco_set_debug_checksums(disco_ctx* c, void* d_table, int rows, int cols) {
+    if (!c || rows < 0 || cols < 0) { set_error("disco_set_debug_checksums: bad argument"); return DISCO_EINVAL; }
+    c->d_dbg = (unsigned long long*)d_table; c->dbg_rows = d_table ? rows : 0; c->dbg_cols = cols; c->dbg_seq = 0;
+    return DISCO_OK;
+}
+
+int disco_set_debug_dump(disco_ctx* c, void* d_buf, size_t bytes_per_row) {
+    if (!c) return DISCO_EINVAL;
+    c->d_dump = (char*)d_buf; c->dump_stride = d_buf ? bytes_per_row : 0;
+    return DISCO_OK;
 }
 
 int disco_sync(void* stream) {

@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <atomic>
+#include <functional>
 #include <stddef.h>
 #include "../../include/disco_hip.h"
 
@@ -74,6 +75,23 @@ __host__ __device__ inline int mx6_block_scale(f16 amax_hi) { return (int)((__bu
 // channel (0..31 within its block) of six-bit field j of an fp6 slot, and the inverse
 __host__ __device__ inline int mx6_field_channel(int j) { return 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3); }
 __host__ __device__ inline int mx6_channel_field(int c) { return 16 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3); }
+
+// v + the values of lanes ^8, ^16, ^32 (the butterfly  v += shfl_xor(v, 8); v += shfl_xor(v, 16); v += shfl_xor(v, 32)  with the same
+// operand order in the lanes of the first row, hence bit-identical there) without the LDS crossbar: DPP row rotate and the gfx950
+// permlane swaps are plain VALU instructions, where __shfl_xor compiles to ds_bpermute_b32 (pool_partial_kernel had 216 per thread).
+// (Written while hunting the concurrency fault described in pool.hip - it was not the cause - and kept: 3 VALU instead of 3 LDS ops.)
+__device__ __forceinline__ float butterfly_add_8_16_32(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    const unsigned b16 = __builtin_bit_cast(unsigned, v);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(b16, b16, false, false);      // {rows 0,0,2,2 | rows 1,1,3,3}
+    v = __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
+    const unsigned b32 = __builtin_bit_cast(unsigned, v);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(b32, b32, false, false);      // {lower half twice | upper half twice}
+    v = __builtin_bit_cast(float, (unsigned)s32[0]) + __builtin_bit_cast(float, (unsigned)s32[1]);
+#endif
+    return v;
+}
 
 // four floats -> four fp8 e4m3 bytes (round to nearest even), clamped to the finite range; *sat counts clamped values
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d, unsigned* sat = nullptr) {
@@ -265,6 +283,7 @@ inline int num_cus_current() {
     return v;
 }
 int diag_mfma_rate(int mode, int iters, double* tflops);   // diag.hip
+int launch_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s);   // diag.hip
 // ConvTranspose2d(4,s2,p1) weight (c_in,c_out,4,4) -> equivalent 3x3 conv weight (4*c_out, c_in, 3, 3), phase-major
 void deconv_as_conv3x3_host(const float* h_w_iohw, int c_in, int c_out, float* h_w_oihw);
 // nearest-x2-upsample followed by a 3x3 conv (c_out,c_in,3,3) -> 4-phase 3x3 conv on the low-res input
@@ -321,7 +340,7 @@ constexpr size_t ENC_LAYER_FLOATS = 192 * 64 + 192 + 64 * 64 + 64 + 256 * 64 + 2
 size_t encoder_ws_bytes(int n, int l);
 // pos: (l,64) shared by all images (pos_rep = 0) or (n/pos_rep, l, 64), virtual image i using image i/pos_rep
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
-                         void* ws, hipStream_t s);
+                         void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg = nullptr);
 void position_encoding_host(float* h_pos /*(h*w,64)*/, int h, int w);
 // logits: (n,L,64) x (n_out,64)^T -> NCHW (n,n_out,L)
 int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s, int n_out = N_VOCAB);

@@ -93,4 +93,23 @@ int diag_mfma_rate(int mode, int iters, double* tflops) {
     return rc;
 }
 
+
+namespace {
+__global__ void checksum_kernel(const unsigned int* __restrict__ p, size_t words, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
+        acc += (unsigned long long)p[i] * (unsigned long long)((i & 1023u) + 1u);      // position-weighted word sum: order-independent
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+}  // namespace
+
+// debugging aid (disco_set_debug_checksums): *out += checksum of `bytes` bytes at p, on stream s
+int launch_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s) {
+    hipLaunchKernelGGL(checksum_kernel, dim3(256), dim3(256), 0, s, reinterpret_cast<const unsigned int*>(p), bytes / 4, out);
+    DISCO_LAUNCH_CHECK("checksum_kernel");
+    return DISCO_OK;
+}
+
 }  // namespace disco

@@ -928,7 +928,7 @@ int launch_decode_annealed(const float* logit_nchw, const float* q_to_ab, float*
 size_t encoder_ws_bytes(int n, int l) { return (size_t)n * l * (3 * 64 + 3 * 64) * sizeof(float); }
 
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
-                         void* ws, hipStream_t s) {
+                         void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg) {
     const int T = n * l;
     float* qkv = reinterpret_cast<float*>(ws);
     float* att = qkv + (size_t)3 * T * 64;
@@ -949,9 +949,11 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         g.q_scale = (float)std::sqrt(1.0 / 8.0);
         int rc = launch_gemm<EPI_QKV>(g, s);
         if (rc) return rc;
+        if (dbg) (*dbg)(qkv, (size_t)3 * T * 64 * 4);
         hipLaunchKernelGGL(attention_kernel, dim3(cdiv(l, QPB), N_HEAD, n), dim3(256), 0, s, qkv, qkv + (size_t)T * 64,
                            qkv + (size_t)2 * T * 64, att, l);
         DISCO_LAUNCH_CHECK("attention_kernel");
+        if (dbg) (*dbg)(att, (size_t)T * 64 * 4);
         // x1 = LN1(x + att Wo^T + bo); out = LN2(x1 + relu(x1 W1^T + b1) W2^T + b2): one fused launch
         float* dst = layer == ENC_LAYERS - 1 ? out : pp[layer & 1];
         {
@@ -962,6 +964,7 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
             hipLaunchKernelGGL(post_attention_kernel, dim3(cdiv(T, 64)), dim3(256), smem, s, pa);
             DISCO_LAUNCH_CHECK("post_attention_kernel");
         }
+        if (dbg) (*dbg)(dst, (size_t)T * 64 * 4);
         cur = dst;
     }
     return DISCO_OK;

@@ -355,18 +355,27 @@ class AnchorColorProb(nn.Module):
             raise ValueError("H and W must be multiples of %d" % self.sp_size)
         return test_mode, gray, ab
 
+    def set_progress_event(self, event, after_conv_launches):
+        """The next forward_once on the current device records `event` (a torch.cuda.Event that has been recorded at least once, so
+        that its handle exists) on its stream behind its `after_conv_launches`-th MFMA conv launch (disco_set_progress_event):
+        runner.py staggers its micro-batches with it."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        _ffi.check(_ffi.lib().disco_set_progress_event(self._context(dev), C.c_void_p(event.cuda_event), int(after_conv_launches)))
+
     def max_fallback(self):
         """Upper bound of empty-cluster draws one image can consume (clusterkit.py:176-182: K-1 per pass, 20 passes)."""
         return KMEANS_ITERS * self.hint_num
 
     @torch.no_grad()
     def forward_once(self, input_grays, input_colors, test_mode=True, sampled_T=0, init_idx=None, hint_pos=None,
-                     fallback_stream=None, fallback_bases=None, want_events=True):
+                     fallback_stream=None, fallback_bases=None, want_events=True, out=None):
         """ONE native forward with every host-side draw supplied by the caller; consumes no generator state.
         init_idx (n,K) k-means rows / hint_pos (n,K) random-hint tokens; fallback_stream: the values successive
         torch.randint(L,(1,)) calls would return (a prefix of the reference's global draw stream), fallback_bases (n,):
         where in that stream image i's empty-cluster draws start.  Returns (6-tuple, events) with events (n,) int32 =
-        draws each image consumed (None when want_events is False: no host synchronisation then)."""
+        draws each image consumed (None when want_events is False: no host synchronisation then).
+        out: optional preallocated (pal, ref, pred, affinity, spix, mask) tensors to write into (sampled_T = 0 only; runner.py hands
+        slices of the whole batch's outputs to its micro-batches instead of concatenating their results)."""
         test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
         dev = gray.device
         n, _, H, W = gray.shape
@@ -392,9 +401,10 @@ class AnchorColorProb(nn.Module):
                 j = min(n, i + max_imgs)
                 o, e = self.forward_once(gray[i:j], ab[i:j], test_mode, sampled_T, None if init_idx is None else init_idx[i:j],
                                          None if hint_pos is None else hint_pos[i:j], fallback_stream,
-                                         None if fallback_bases is None else fallback_bases[i:j], want_events)
+                                         None if fallback_bases is None else fallback_bases[i:j], want_events,
+                                         None if out is None else tuple(t[i:j] for t in out))
                 parts.append(o); evs.append(e)
-            outs = tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
+            outs = out if out is not None else tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
             return outs, (np.concatenate(evs) if want_events and not self.random_hint else (np.zeros(n, np.int32) if want_events else None))
         n2 = n * rep
         L = _ffi.lib()
@@ -403,12 +413,14 @@ class AnchorColorProb(nn.Module):
             ctx = self._context(dev)
             L.disco_set_profiling(ctx, int(getattr(self, "_profiling", 0)))
             f32 = dict(device=dev, dtype=torch.float32)
-            pal = torch.empty(n, 313, h, w, **f32)
-            ref = torch.empty(n2, 2 if self.hint2regress else 313, h, w, **f32)
-            pred = torch.empty(n2, 2, H, W, **f32)
-            aff = torch.empty(n, 9, H, W, **f32)
-            spix = torch.empty(n2, 2, h, w, **f32)
-            mask = torch.empty(n, 1, h, w, **f32)
+            shapes = ((n, 313, h, w), (n2, 2 if self.hint2regress else 313, h, w), (n2, 2, H, W), (n, 9, H, W), (n2, 2, h, w), (n, 1, h, w))
+            if out is not None:
+                if rep != 1 or len(out) != 6 or any(tuple(t.shape) != sh or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous()
+                                                    for t, sh in zip(out, shapes)):
+                    raise ValueError("out: six contiguous fp32 tensors of shapes %s on %s (sampled_T = 0 only)" % (shapes, dev))
+                pal, ref, pred, aff, spix, mask = out
+            else:
+                pal, ref, pred, aff, spix, mask = (torch.empty(sh, **f32) for sh in shapes)
             ws_key = (n, H, W, T > 0)
             if ws_key not in self._ws_need:
                 need = C.c_size_t()
@@ -463,7 +475,7 @@ class AnchorColorProb(nn.Module):
                     warnings.warn("%d fp8 activation values were clamped: this input is outside the ranges the context was calibrated on "
                                   "(two synthetic images at load time); re-calibrating on this batch and running it again" % clamped)
                     self.calibrate(gray[:64])
-                    return self.forward_once(gray, ab, test_mode, sampled_T, init_idx, hint_pos, fallback_stream, fallback_bases, want_events)
+                    return self.forward_once(gray, ab, test_mode, sampled_T, init_idx, hint_pos, fallback_stream, fallback_bases, want_events, out)
         if rep > 1:
             aff_out = aff.expand(rep, -1, -1, -1) if n == 1 else aff.repeat_interleave(rep, 0)
             mask_out = mask.expand(rep, -1, -1, -1) if n == 1 else mask.repeat_interleave(rep, 0)

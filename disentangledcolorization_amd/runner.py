@@ -25,6 +25,10 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+# micro-batch i + 1 starts behind this many MFMA conv launches of micro-batch i (of 69 per forward: SpixelNet 18, ColorProbNet 27,
+# HourGlass2 24); $DISCO_STAGGER_CONVS overrides (0 = off: the micro-batches start together), profiles/r03_stagger.txt
+STAGGER_CONVS = int(os.environ.get("DISCO_STAGGER_CONVS", "26"))
+
 
 def shard_bounds(n_global, world, rank):
     """Contiguous [lo, hi) of `rank`; the first n_global % world ranks hold one extra image."""
@@ -72,14 +76,28 @@ class ShardedColorizer:
         # path - packed send buffer, async work handle, result views - on a single-GPU box: tests/test_gpu_dist.py via bench.py)
         self.force_gather = bool(force_gather)
         self._streams = None
+        # stagger: micro-batch i + 1 starts behind the `stagger_convs`-th conv launch of micro-batch i (progress_fn(event, k) arms
+        # the forward that is issued next: AnchorColorProb.set_progress_event), so that the token path / k-means of either runs under
+        # the other's convolutions; out_capable: forward_fn takes out= (preallocated result slices: no concatenation pass)
+        self.progress_fn = None
+        self.stagger_convs = 0
+        self.out_capable = False
+        self._out_channels = (313, 313)             # channels of pal_logit / ref_logit (2 with hint2regress)
+        self._stagger_events = []
         self._pending = []          # outstanding asynchronous all-gathers (async_gather=True): (work, finish callback)
         self.last_events = None     # per-image empty-cluster draws of the GLOBAL batch of the latest exact forward
 
     @classmethod
     def from_model(cls, model, group=None, micro_batches=1, exact_fallback=None, force_gather=False):
-        fn = lambda g, a, T, idx, pos, fs, fb, want: model.forward_once(g, a, True, T, idx, pos, fs, fb, want)
+        fn = lambda g, a, T, idx, pos, fs, fb, want, out=None: model.forward_once(g, a, True, T, idx, pos, fs, fb, want, out)
         exact = model.sync_kmeans_events if exact_fallback is None else exact_fallback
-        return cls(fn, model.hint_num, model.random_hint, model.sp_size, group, micro_batches, exact, model.max_fallback(), force_gather)
+        r = cls(fn, model.hint_num, model.random_hint, model.sp_size, group, micro_batches, exact, model.max_fallback(), force_gather)
+        r.out_capable = True
+        r._out_channels = (313, 2 if getattr(model, "hint2regress", False) else 313)
+        if hasattr(model, "set_progress_event"):
+            r.progress_fn = model.set_progress_event
+            r.stagger_convs = STAGGER_CONVS
+        return r
 
     # ---- local forward (optionally as micro-batches on separate streams) ----------------------------------------
     def _forward_local(self, gray, ab, sampled_T, idx, pos, fstream, fbases, want):
@@ -92,20 +110,40 @@ class ShardedColorizer:
         if self._streams is None or len(self._streams) < m:
             self._streams = [torch.cuda.Stream(device=gray.device) for _ in range(m)]
         main = torch.cuda.current_stream(gray.device)
+        stagger = self.progress_fn is not None and self.stagger_convs > 0
+        while stagger and len(self._stagger_events) < m - 1:
+            ev = torch.cuda.Event()
+            ev.record(main)                            # (torch creates the hipEvent on the first record)
+            self._stagger_events.append(ev)
+        full = None
+        if self.out_capable and int(sampled_T) == 0:
+            # the whole batch's results, allocated once on the caller's stream; every micro-batch writes its slice
+            H, W = gray.shape[2:]
+            h, w = H // self.sp, W // self.sp
+            probe = self._out_channels
+            f32 = dict(device=gray.device, dtype=torch.float32)
+            full = (torch.empty(n, probe[0], h, w, **f32), torch.empty(n, probe[1], h, w, **f32), torch.empty(n, 2, H, W, **f32),
+                    torch.empty(n, 9, H, W, **f32), torch.empty(n, 2, h, w, **f32), torch.empty(n, 1, h, w, **f32))
         parts, evs = [], []
         for i in range(m):
             lo, hi = shard_bounds(n, m, i)
             st = self._streams[i]
             st.wait_stream(main)                       # inputs were produced on the caller's stream
+            if stagger and i > 0:
+                st.wait_event(self._stagger_events[i - 1])
             with torch.cuda.stream(st):
-                o, e = self.forward_fn(gray[lo:hi], ab[lo:hi], sampled_T, None if idx is None else idx[lo:hi],
-                                       None if pos is None else pos[lo:hi], fstream, None if fbases is None else fbases[lo:hi], want)
+                if stagger and i + 1 < m:
+                    self.progress_fn(self._stagger_events[i], self.stagger_convs)
+                args = (gray[lo:hi], ab[lo:hi], sampled_T, None if idx is None else idx[lo:hi],
+                        None if pos is None else pos[lo:hi], fstream, None if fbases is None else fbases[lo:hi], want)
+                o, e = self.forward_fn(*args, tuple(t[lo:hi] for t in full)) if full is not None else self.forward_fn(*args)
                 parts.append(o); evs.append(e)
         for i in range(m):
             main.wait_stream(self._streams[i])
-            for t in parts[i]:
-                t.record_stream(main)                  # allocated on the side stream, consumed on the caller's
-        out = tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
+            if full is None:
+                for t in parts[i]:
+                    t.record_stream(main)              # allocated on the side stream, consumed on the caller's
+        out = full if full is not None else tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
         return out, (np.concatenate(evs) if want else None)
 
     def world(self):

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 6
+#define DISCO_ABI_VERSION 7
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -171,6 +171,18 @@ int disco_sync(void *stream);
 /* Per-stage timing hooks used by bench.py: after a forward with profiling enabled the context
  * holds hipEvent timings of named stages on the forward's stream. */
 int disco_set_profiling(disco_ctx *ctx, int level); /* 0 off, 1 stages, 2 stages + every MFMA conv launch */
+/* Pipelining hook (ABI 7): the NEXT disco_forward on this context records `hip_event` (a hipEvent_t the caller owns) on its stream right
+ * behind its `after_conv_launches`-th MFMA conv launch (at its end if it has fewer); one shot, NULL cancels.  A caller that runs two
+ * micro-batches on two streams lets the second wait for this event of the first: the two forwards then run half a network apart, and the
+ * latency-bound token path / k-means of either (a handful of CUs busy) executes under the other's convolutions instead of both idling
+ * the GPU at the same time (runner.py; the reference has no counterpart: it runs one batch on one stream). */
+int disco_set_progress_event(disco_ctx *ctx, void *hip_event, int after_conv_launches);
+/* Debugging aid: d_table = device uint64 [rows][cols] (NULL: off).  Forward number k (counted from this call) zeroes row k % rows and
+ * adds into column j a position-weighted word sum of the output of its j-th stage (every conv launch in order, the tokens, the encoder
+ * output, pal_logit) - tools/stagger_probe.py compares rows of forwards that must agree. */
+int disco_set_debug_checksums(disco_ctx *ctx, void *d_table, int rows, int cols);
+/* ... and per row (same row index) a copy of the first token GEMM's input (n,L,64) and output q|k|v (3,n L,64), bytes_per_row apart */
+int disco_set_debug_dump(disco_ctx *ctx, void *d_buf, size_t bytes_per_row);
 int disco_profile_count(disco_ctx *ctx);
 int disco_profile_entry(disco_ctx *ctx, int i, const char **name, float *ms, double *flops);
 /* level 2: number of conv3x3_mfma launches of the last forward, their summed duration (hipEvent pairs around
