@@ -603,3 +603,31 @@ def test_out_of_range_input_recalibrates_itself(synth_sd, q_to_ab):
         assert torch.equal(out[5].cpu(), want[5])              # the anchors are decided on the f16x3 stacks: no fp8 planes there
         errs[checks] = _err(out[2], want[2])
     assert errs[3] < 0.5 * errs[0] and errs[3] <= 1.5e-2, errs     # (measured: mx6 3.5e-2 -> 1.1e-2, mx8 1.3e-1 -> 0.8e-2)
+
+
+def test_concurrent_micro_batches_equal_the_single_stream_result(synth_sd):
+    """runner.py issues a batch as micro-batches on separate HIP streams (staggered by disco_set_progress_event).  Every output must
+    equal the one-stream result bit for bit, for 2 (bench.py's default), 4 and 8 streams.  Round 3 found pool_partial_kernel's
+    packed-fp32 path returning a wrong low half of one packed result about once per 12 forwards as soon as four or more streams
+    ran forwards concurrently (tools/stagger_probe.py, profiles/r03_stagger_probe.txt; pool.hip is built with -fno-slp-vectorize
+    since): 8 streams x 6 steps would have tripped with ~98 % probability."""
+    from disentangledcolorization_amd.runner import ShardedColorizer, global_draws, peek_randint
+    m = _model(synth_sd, 8)
+    gray, ab = synth.synth_inputs(32, 256, 256, seed=5)
+    gray, ab = gray.cuda(), ab.cuda()
+
+    def run(r):
+        _seed(130)
+        idx, pos = global_draws(32, 256, 8, False)
+        out, _ = r._forward_local(gray, ab, 0, idx, pos, peek_randint(256, r.max_fallback), None, False)
+        torch.cuda.synchronize()
+        return out
+
+    want = [t.clone() for t in run(ShardedColorizer.from_model(m, micro_batches=1, exact_fallback=False))]
+    for micro, steps in ((2, 3), (4, 4), (8, 6)):
+        r = ShardedColorizer.from_model(m, micro_batches=micro, exact_fallback=False)
+        assert r.stagger_convs > 0 and r.out_capable
+        for _ in range(steps):
+            got = run(r)
+            for k in range(6):
+                assert torch.equal(got[k], want[k]), (micro, k)
