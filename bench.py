@@ -141,7 +141,9 @@ def main():
     ap.add_argument("--precision", default=None, choices=["mx6", "mx8", "x2q", "mx8all", "f16x3"],
                     help="conv arithmetic per stack (disentangledcolorization_amd/model.py); default: the package default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra timing of the opt-in precision mode (x2q) that a default N=1 run reports next to `value`")
+    ap.add_argument("--alt", action="store_true", help="also time the opt-in precision mode (x2q) and report it next to `value` as `opt_in_precision` (it runs second, on a warm "
+                                                      "power-limited GPU: 5 % below its own stand-alone run, profiles/r03_bench_x2q.json - off by default since round 3)")
+    ap.add_argument("--no-alt", action="store_true", help="(accepted for older command lines: the default now)")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with one thread per host core (minutes on a 256-core box)")
     ap.add_argument("--micro", type=int, default=2, help="micro-batches per GPU, each on its own HIP stream: the token path / k-means of one (a few CUs busy) "
                     "overlaps with the conv stacks of the other (+1.7%% over 1).  The per-launch profile behind `roofline` is taken on ONE stream after the timed loop")
@@ -316,7 +318,7 @@ def main():
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
             }
             out["stage_ms_per_step"] = {k: round(v / prof_steps, 3) for k, v in stage_ms.items()}        # of the profiled single-stream forwards
-            if world == 1 and not args.no_alt and args.precision == "mx6":
+            if world == 1 and args.alt and not args.no_alt and args.precision == "mx6":
                 # the opt-in arithmetic on the same inputs, timed the same way (NOT `value`: DESIGN.md section 2 says why it is opt-in)
                 out["opt_in_precision"] = measure_alt("x2q", sd, gray, ab, n_global, args, sync)
             if world == 1 and not args.no_cpu_baseline:
