@@ -842,8 +842,8 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     int enc_dbg_calls = 0;
     const std::function<void(const void*, size_t)> enc_dbg = [&](const void* p, size_t b) {
         P.dbg(p, b);
-        // the first token GEMM's operands and result, kept for inspection (disco_set_debug_checksums: table rows are followed by
-        // per-row dumps when cols < 0 was passed... see tools/stagger_probe.py --dump)
+        // disco_set_debug_dump: the first token GEMM's input as it is at that moment and its result, next to the copies taken right
+        // behind the pooling kernels (tools/stagger_probe.py prints which of them differ from a serialised pass)
         if (enc_dbg_calls++ == 0 && c->d_dump) {
             char* dst = c->d_dump + (size_t)P.dbg_row * c->dump_stride;
             const size_t sb = (size_t)n * L * 64 * 4;
