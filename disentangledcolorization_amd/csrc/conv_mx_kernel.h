@@ -43,6 +43,12 @@
 #include <vector>
 #include "common.h"
 
+#ifndef MX_PIX_AUX
+#define MX_PIX_AUX 0     // cache-policy bits (aux) of the pixel / weight LDS-DMA: experiments only (2 = nt)
+#endif
+#ifndef MX_W_AUX
+#define MX_W_AUX 0
+#endif
 #ifndef MX_QFMT
 #define MX_QFMT 0       // operand format of the K = 64 correction MFMA: 0 = fp8 e4m3.  2 (fp6 e2m3) / 4 (fp4): SPEED EXPERIMENTS ONLY - the data stay fp8 bytes
 #endif
@@ -258,8 +264,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 unsigned v0 = voff[0][i], v1 = voff[NS - 1][i];
                 if (NSRC2) asm("" : "+v"(v0), "+v"(v1));          // opaque values: no select-of-loads folding
                 const unsigned vsel = s1 ? v1 : v0;
-                if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(dA + piece * 1024), 16, vsel, soff, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(dA + piece * 1024), 16, vsel, soff, 0, 0);
+                if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(dA + piece * 1024), 16, vsel, soff, 0, MX_PIX_AUX);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(dA + piece * 1024), 16, vsel, soff, 0, MX_PIX_AUX);
             }
         }
 #pragma unroll
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             const int nt = piece / 18, q = piece - nt * 18;
             if (((i + 1) * NWAVE <= W_PIECES || piece < W_PIECES) && (!MASKED || ((tmask >> (q >> 1)) & 1u)))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(dW + piece * 1024), 16, lane * 16,
-                                                         w_tile_b + (unsigned)nt * w_nt_b + (unsigned)ck * W_NB + q * 1024, 0, 0);
+                                                         w_tile_b + (unsigned)nt * w_nt_b + (unsigned)ck * W_NB + q * 1024, 0, MX_W_AUX);
         }
     };
 
