@@ -42,13 +42,21 @@ def total(dirname, counter):
     if len(rows) < keep:
         raise SystemExit("%d conv launches, expected at least %d" % (len(rows), keep))
     rows = rows[len(rows) - keep:]
-    return sum(v for _, v in rows), len(rows)
+    per_layer = [0.0] * PER_FORWARD            # launch i of a forward = layer i (the order of tools/profile_layers.py's table)
+    for i, (_, v) in enumerate(rows):
+        per_layer[i % PER_FORWARD] += v / FORWARDS
+    return sum(v for _, v in rows), len(rows), per_layer
 
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
-    fetch, nf = total(fetch_dir, "FETCH_SIZE")
-    write, nw = total(write_dir, "WRITE_SIZE")
+    fetch, nf, fetch_l = total(fetch_dir, "FETCH_SIZE")
+    write, nw, write_l = total(write_dir, "WRITE_SIZE")
+    with open(os.path.splitext(out)[0] + "_layers.txt", "w") as fh:
+        fh.write("# HBM-side MB per conv launch by position in the forward (reads = FETCH_SIZE x 2 KiB, writes = WRITE_SIZE KiB); the positions are the\n"
+                 "# rows of profiles/r03_final_layers.txt (0-17 SpixelNet, 18-44 ColorProbNet, 45-68 HourGlass2)\n")
+        for i in range(PER_FORWARD):
+            fh.write("%3d  read %8.1f MB  write %8.1f MB\n" % (i, fetch_l[i] * 2048 / 1e6, write_l[i] * 1024 / 1e6))
     if not nf or nf != nw:
         raise SystemExit("launch counts differ: %d vs %d" % (nf, nw))
     rd = fetch * 1024 * 2 / nf
