@@ -631,3 +631,28 @@ def test_concurrent_micro_batches_equal_the_single_stream_result(synth_sd):
             got = run(r)
             for k in range(6):
                 assert torch.equal(got[k], want[k]), (micro, k)
+
+
+def test_progress_event_is_recorded_once_per_arming(synth_sd):
+    """disco_set_progress_event (ABI 7): the next forward records the caller's event behind its k-th conv launch - or at its end if it has
+    fewer - exactly once; later forwards leave it alone; results do not change."""
+    m = _model(synth_sd, 8)
+    gray, ab = synth.synth_inputs(2, 128, 128, seed=3)
+    gray, ab = gray.cuda(), ab.cuda()
+    _seed(1); want = [t.clone() for t in m(gray, ab, True, 0)]
+    for k in (1, 26, 10 ** 6):
+        ev = torch.cuda.Event(enable_timing=True); start = torch.cuda.Event(enable_timing=True); end = torch.cuda.Event(enable_timing=True)
+        ev.record(); torch.cuda.synchronize()
+        start.record()
+        m.set_progress_event(ev, k)
+        _seed(1); got = m(gray, ab, True, 0)
+        end.record(); torch.cuda.synchronize()
+        assert ev.query()
+        t_ev, t_end = start.elapsed_time(ev), start.elapsed_time(end)
+        assert 0 < t_ev <= t_end + 1e-3          # recorded inside this forward ...
+        if k == 1:
+            assert t_ev < 0.5 * t_end            # ... early for k = 1
+        for a_, b_ in zip(got, want):
+            assert torch.equal(a_, b_)
+        _seed(1); m(gray, ab, True, 0); torch.cuda.synchronize()
+        assert abs(start.elapsed_time(ev) - t_ev) < 1e-6      # a later forward does not record it again
