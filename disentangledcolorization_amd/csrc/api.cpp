@@ -644,7 +644,8 @@ struct Plan {
                 const int ups[2] = {up0, up1};
                 ca.nsrc = in1 ? 2 : 1;
                 for (int i = 0; i < ca.nsrc; ++i) {
-                    if (!src[i]->q_off || src[i]->q_off >= ((size_t)1 << 32) || src[i]->q_kind != L.x2q) { set_error("conv %s: source %d has no (addressable) q planes of kind %d", key.c_str(), i, L.x2q); rc = DISCO_ESHAPE; return; }
+                    const bool tail_src = i == 1 && src[i]->c == 16 && !src[i]->q_off && L.x2q == 0;     // the H-only tail chunk (launch_conv3x3_mx checks the rest)
+                    if (!tail_src && (!src[i]->q_off || src[i]->q_off >= ((size_t)1 << 32) || src[i]->q_kind != L.x2q)) { set_error("conv %s: source %d has no (addressable) q planes of kind %d", key.c_str(), i, L.x2q); rc = DISCO_ESHAPE; return; }
                     ca.src[i] = {src[i]->p, (uint32_t)src[i]->q_off, src[i]->c, src[i]->h, src[i]->w, ups[i], src[i]->sexp};
                 }
                 ca.n = in0.n; ca.h_in = hin; ca.w_in = win; ca.c_in = L.c_in_pad;
@@ -913,12 +914,13 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     // (the upfeat / gray kernels write fp8 q planes; under the fp6 arithmetic inConv.inConv.0 reads those and writes fp6 ones)
     const int infmt = P.stage_arith == ARITH_MX6 ? (int)Plan::F_Q : P.dfmt();
     Act full = P.act(n2, H, W, 64, infmt);
-    Act g16 = P.act(n2, H, W, P.cpad(16), infmt);
+    const bool gtail = P.mx();                        // f16+fp8x2: a 16-channel fp16 tail source without q planes
+    Act g16 = gtail ? P.act(n2, H, W, 16, 0) : P.act(n2, H, W, P.cpad(16), infmt);
     if (!dry && P.ok() && P.scale_of("upfeat", &full.sexp) && P.scale_of("gray16", &g16.sexp)) {}
     {
         unsigned int* sat = calib ? nullptr : c->d_sat;
         auto up = [&]() { P.rc = launch_upfeat(dec, 1, a->d_affinity, rep, &full, nullptr, n2, 64, hs, ws, sp, sat, s); };
-        auto gr = [&]() { P.rc = launch_gray16(a->d_gray, rep, g16, sat, s); };
+        auto gr = [&]() { P.rc = gtail ? launch_gray_tail(a->d_gray, rep, g16, s) : launch_gray16(a->d_gray, rep, g16, sat, s); };
         if (!dry && P.ok()) { up(); P.calibrate("upfeat", full, up); }
         if (!dry && P.ok()) { gr(); P.calibrate("gray16", g16, gr, "upfeat"); }        // concatenated on read with the up-sampled features
     }
@@ -1171,10 +1173,13 @@ int disco_finalize(disco_ctx* c) {
     if ((rc = make_conv(c, rp + "conv10_2.1", "", ""))) return rc;
     const std::string en = "enhanceNet.";
     {   // input = cat(gray, 64 token features) in the reference; here source 0 = features, source 1 = 16-ch gray plane
-        const int cp = use_mx(c, en) ? 96 : 80;          // the gray plane is one 32- (16-) channel block
+        // (80 packed channels in every arithmetic: the f16+fp8x2 kernel takes the gray block as its H-only tail chunk with the gray
+        // channel as (g_hi, g_lo, g_hi) against (w_h, w_h, w_l) - launch_gray_tail, conv_mx_pack_host)
+        const int cp = 80;
         std::vector<int> map(cp, -1);
         for (int i = 0; i < 64; ++i) map[i] = i + 1;
         map[64] = 0;
+        if (use_mx(c, en)) { map[65] = 0; map[66] = CONV_MX_LO_OF(0); }
         if ((rc = make_conv(c, en + "inConv.inConv.0", "", "", &map, cp))) return rc;
     }
     if ((rc = make_conv(c, en + "inConv.conv.0", "", en + "inConv.conv.2"))) return rc;

@@ -242,6 +242,7 @@ struct ConvMxArgs {
 // variant: 0 = f16 + fp8x2, 1 = f16x2 + fp8 (x2q), 2 = f16 + fp6x2
 size_t conv_mx_packed_bytes(int c_out, int c_in_pad, int variant = 0);
 // h_w: effective fp32 weight (c_out, c_in, 3, 3); ci_map as in conv3x3_pack_host; c_in_pad multiple of 32 (x2q: 64); h_wexp: cdiv(c_out,32)*32 ints
+#define CONV_MX_LO_OF(ci) (-2 - (ci))      // ci_map code: the fp16 residual w - fp16(w) of real channel ci (conv_mx_pack_host)
 void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map, int c_in_pad, void* h_packed, int32_t* h_wexp, int variant = 0);
 unsigned char fp6_e2m3_from_float(float x);      // round to nearest even, saturating to +-7.5
 float fp6_e2m3_to_float(unsigned char code);
@@ -327,6 +328,8 @@ int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_
                   float* out_nchw, int n, int c, int h, int w, int sp, unsigned int* sat, hipStream_t s);
 // gray (n,1,H,W) -> act of out.c (16 or 32) channels with gray in channel 0, zeros elsewhere (rep: output image i reads gray image i/rep)
 int launch_gray16(const float* gray, int rep, const Act& out, unsigned int* sat, hipStream_t s);
+// the gray image as the 16-channel fp16 tail source of a two-source f16+fp8x2 layer: channels (g_hi, g_lo, g_hi, 0 ...), hi plane only
+int launch_gray_tail(const float* gray, int rep, const Act& out, hipStream_t s);
 
 // ---- token path ---------------------------------------------------------------------------------
 constexpr int D_MODEL = 64;

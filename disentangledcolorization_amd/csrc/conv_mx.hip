@@ -211,9 +211,13 @@ void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map,
         if (q6 && mx > 0.f && std::ldexp(mx, e) > 7.5f) e -= 1;          // ... fp6: rather lose a bit than clamp: [3.75, 7.5]
         h_wexp[co] = std::min(std::max(e, -100), 100);
     }
+    // ci_map[cip]: the real input channel of packed channel cip, -1 = none (zero weights), or CONV_MX_LO_OF(ci) = the fp16 RESIDUAL
+    // w - fp16(w) of channel ci's weights (the H-only tail chunk carries a channel as (x_hi, x_lo, x_hi) against (w_h, w_h, w_l))
     auto wat = [&](int co, int cip, int tap) -> float {
         const int ci = ci_map ? ci_map[cip] : (cip < c_in ? cip : -1);
-        return (co < c_out && ci >= 0) ? h_w[((size_t)co * c_in + ci) * 9 + tap] : 0.f;
+        if (co >= c_out || ci == -1) return 0.f;
+        if (ci <= -2) { const float w = h_w[((size_t)co * c_in + (-2 - ci)) * 9 + tap]; return w - (float)(f16)w; }
+        return h_w[((size_t)co * c_in + ci) * 9 + tap];
     };
     if (x2q) {
         // chunks of 64-channel group g64: 5 g64 + {0: w_h of channels 0-31, 1: w_l of the same, 2: w_h of 32-63, 3: w_l, 4: w8 of all 64}
@@ -246,15 +250,28 @@ void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map,
                     }
         return;
     }
+    const int nck = c_in_pad / 16;              // chunks per output block: (H, Q) per 32 channels [+ an H-only tail of 16]
+    if (c_in_pad % 32 == 16) {
+        // the tail chunk (ck = 2 ngrp): piece 0 = fp16 weights of packed channels 32 ngrp + 8 kh + 0..7, piece 1 unused (zero)
+        for (int nb = 0; nb < nb_n; ++nb)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = nb * 32 + (lane & 31), kh = lane >> 5;
+                    unsigned char* hb = dst + (((size_t)nb * nck + 2 * ngrp) * 9 + tap) * 2 * WBLK;
+                    f16* hp = reinterpret_cast<f16*>(hb + lane * 16);
+                    for (int i = 0; i < 8; ++i) hp[i] = (f16)wat(co, ngrp * 32 + 8 * kh + i, tap);
+                    memset(hb + WBLK + lane * 16, 0, 16);
+                }
+    }
     for (int nb = 0; nb < nb_n; ++nb)
         for (int g = 0; g < ngrp; ++g)
             for (int tap = 0; tap < 9; ++tap)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int co = nb * 32 + (lane & 31), kh = lane >> 5;
                     // H chunk (ck = 2g): piece j (j = 0, 1) = fp16 weights of channels 16 j + 8 kh + 0..7
-                    unsigned char* hb = dst + (((size_t)nb * (2 * ngrp) + 2 * g) * 9 + tap) * 2 * WBLK;
+                    unsigned char* hb = dst + (((size_t)nb * nck + 2 * g) * 9 + tap) * 2 * WBLK;
                     // Q chunk (ck = 2g+1): lane's 32 bytes = channels 0..31 of wl8 (kh = 0) or w8 (kh = 1); piece j = bytes 16 j .. 16 j + 15
-                    unsigned char* qb = dst + (((size_t)nb * (2 * ngrp) + 2 * g + 1) * 9 + tap) * 2 * WBLK;
+                    unsigned char* qb = dst + (((size_t)nb * nck + 2 * g + 1) * 9 + tap) * 2 * WBLK;
                     const float ws = std::ldexp(1.f, h_wexp[co]), wls = std::ldexp(1.f, h_wexp[co] + MX_LO_SHIFT);
                     if (q6) {
                         // the lane's 32 bytes = the fp6 slot of its row: field f = channel mx6_field_channel(f) of wl6 (kh = 0) / w6 (kh = 1),
@@ -311,10 +328,13 @@ int launch_conv3x3_mx(const ConvMxArgs& a_in, hipStream_t s) {
     for (int i = 0; i < a.nsrc; ++i) {
         const MxSrc& sp = a.src[i];
         if (a.x2q && a.q6) { set_error("conv3x3_mx: one arithmetic at a time"); return DISCO_EINVAL; }
-        if (sp.c % (a.x2q ? 64 : 32) || !sp.q_off) { set_error("conv3x3_mx: source %d needs q planes and a multiple of %d channels (got %d)", i, a.x2q ? 64 : 32, sp.c); return DISCO_ESHAPE; }
+        // the second source of a two-source f16+fp8x2 layer may be a 16-channel fp16 tensor WITHOUT q planes: the kernel's H-only tail
+        // chunk (conv_mx_kernel.h, KIND 3; conv_mx_pack_host's `lo` channel codes make it an exact split)
+        const bool tail = i == 1 && a.nsrc == 2 && !a.x2q && !a.q6 && sp.c == 16 && !sp.q_off && a.src[0].c % 32 == 0;
+        if (!tail && (sp.c % (a.x2q ? 64 : 32) || !sp.q_off)) { set_error("conv3x3_mx: source %d needs q planes and a multiple of %d channels (got %d)", i, a.x2q ? 64 : 32, sp.c); return DISCO_ESHAPE; }
         const size_t per = (size_t)a.n * sp.c * sp.h * sp.w * 2;          // bytes of the hi plane = bytes of the a8|al8 planes (al8 only: half)
-        const size_t bytes = (size_t)sp.q_off + (a.x2q ? per / 2 : per);
-        if (bytes >= ((size_t)1 << 32) || sp.q_off < per) { set_error("conv3x3_mx: activation tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", bytes); return DISCO_ESHAPE; }
+        const size_t bytes = tail ? per : (size_t)sp.q_off + (a.x2q ? per / 2 : per);
+        if (bytes >= ((size_t)1 << 32) || (!tail && sp.q_off < per)) { set_error("conv3x3_mx: activation tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", bytes); return DISCO_ESHAPE; }
         a.src_bytes[i] = (uint32_t)bytes;
         if ((size_t)sp.h * sp.w * 32 >= (1u << 30)) { set_error("conv3x3_mx: image too large for 30-bit in-image offsets"); return DISCO_ESHAPE; }
         if (sp.sexp != a.src[0].sexp) { set_error("conv3x3_mx: the sources carry different scale exponents (%d, %d): tensors that are concatenated on read must share one", a.src[0].sexp, sp.sexp); return DISCO_ESTATE; }

@@ -254,10 +254,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         if (XQ && isq) soff = (unsigned)img * (img_b0 >> 1) + (unsigned)(c0 >> 5) * blk_b0 + qo0;
         char* dA = smem + buf * BUF_BYTES;
         char* dW = dA + A_BYTES;
+        const bool tail = NSRC2 && AR == 0 && (nchunks & 1) && ck == nchunks - 1;       // 16-channel H-only chunk: plane 0 alone
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             if (part >= 0 && i / APT != part) continue;
             const int piece = i * NWAVE + wave;
+            if (NSRC2 && AR == 0 && tail && piece * 64 >= G::NPIX * 2) continue;       // a piece that lies entirely in plane 1
             if ((i + 1) * NWAVE <= A_PIECES || piece < A_PIECES) {      // only the last round of pieces needs the run-time test
                 // (the offset is selected by VALUE: with the two calls behind an if / else the optimiser merged them into one call that
                 // loads its offset through a phi of POINTERS into voff - which put voff into scratch memory, read back inside the tap loop)
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             if (part >= 0 && i / WPT != part) continue;
             const int piece = i * NWAVE + wave;
             const int nt = piece / 18, q = piece - nt * 18;
+            if (NSRC2 && AR == 0 && tail && (q & 1)) continue;                          // the second plane's weights
             if (((i + 1) * NWAVE <= W_PIECES || piece < W_PIECES) && (!MASKED || ((tmask >> (q >> 1)) & 1u)))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(dW + piece * 1024), 16, lane * 16,
                                                          w_tile_b + (unsigned)nt * w_nt_b + (unsigned)ck * W_NB + q * 1024, 0, MX_W_AUX);
@@ -319,12 +322,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     //              (K half kh of one K = 64 MFMA: a8 meets wl8, al8 meets w8).
     // The H and Q chunks of a 32-channel group run back to back in one loop iteration (no branch between the two bodies:
     // a branch made the register allocator keep the accumulators in two places).
+    // KIND 3 (TAIL): an H chunk of which only plane 0 (16 channels) exists - the last, odd chunk of a two-source f16+fp8x2 layer whose
+    //              second source is a 16-channel fp16 tensor without q planes (HourGlass2 input: the gray image as the channels
+    //              (g_hi, g_lo, g_hi) against the weights (w_h, w_h, w_l): an exact three-product split in ONE K = 16 MFMA per tap
+    //              where a padded 32-channel chunk pair spent three).  Its second-plane DMA pieces and weight pieces are not issued.
     // KIND 2 (X3): the f16x3 arithmetic of conv_mfma2.hip on this skeleton - planes = hi / lo of 16 channels, weight tile = w_hi / w_lo
     //              fragments (conv3x3_pack_host's image), three K = 16 MFMAs per tap in conv_mfma2's order (w_lo a_hi, w_hi a_lo,
     //              w_hi a_hi), so results are bit-identical to that kernel's
     auto chunk = [&](auto kind_tag, int ck) {
         constexpr int KIND = decltype(kind_tag)::value;
-        constexpr bool ISQ = KIND == 1;
+        constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
         if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const bool more = ck + 1 < nchunks;
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 constexpr int RB = G::PITCH * 32;                           // bytes per tile row
                 const int rowc = (mt * G::ROWS_PER_MB * STRIDE + ky) * RB;   // compile-time constant: the ds_read's immediate offset
                 ra[mt][0] = *reinterpret_cast<const i32x4*>(smem + ca0[kx] + rowc);
-                ra[mt][1] = *reinterpret_cast<const i32x4*>(smem + ca1[kx] + rowc);
+                if (!TAIL) ra[mt][1] = *reinterpret_cast<const i32x4*>(smem + ca1[kx] + rowc);
             }
             if (ROWREUSE && !live) continue;
 #if MX_ABL & 2
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #endif
                 const int off = wo + nt * W_NB + tap * 2 * WBLK;
                 rb[nt][0] = *reinterpret_cast<const i32x4*>(sW + off);
-                rb[nt][1] = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
+                if (!TAIL) rb[nt][1] = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
             }
             if ((slot + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
                     } else {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
+                        if (!TAIL) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
                     }
                 }
             // pin this tap's MFMAs here: without a use of the accumulators the optimiser sinks the whole (pure) MFMA chain of a
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 }
         }
     };
-    using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>;
+    using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>; using KT = std::integral_constant<int, 3>;
     if constexpr (X3) {
         for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck);
     } else if constexpr (XQ) {
@@ -424,9 +431,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             chunk(KQ{}, ck + 4);
         }
     } else {
-        for (int ck = 0; ck < nchunks; ck += 2) {
+        for (int ck = 0; ck + 1 < nchunks; ck += 2) {
             chunk(KH{}, ck);
             chunk(KQ{}, ck + 1);
+        }
+        if constexpr (NSRC2 && AR == 0) {
+            if (nchunks & 1) chunk(KT{}, nchunks - 1);
         }
     }
 

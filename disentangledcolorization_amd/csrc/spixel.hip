@@ -149,6 +149,21 @@ __global__ void gray16_kernel(const float* __restrict__ gray, int rep, f16* out,
     if (sat_out && sat) atomicAdd(sat_out, sat);
 }
 
+// gray as (g_hi, g_lo, g_hi, 0 x 13) per pixel, 32 bytes: against the weights (w_h, w_h, w_l) of conv_mx_pack_host's tail chunk ONE K = 16
+// MFMA per tap forms w_h g_hi + w_h g_lo + w_l g_hi - the f16x3 split of the product, exact to fp32 rounding (model.py:194: the gray
+// channel of the HourGlass2's input)
+__global__ void gray_tail_kernel(const float* __restrict__ gray, int rep, f16* __restrict__ out, int sexp, long npix_total, long HW) {
+    const float sc = ldexpf(1.f, sexp);
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix_total; pix += (long)gridDim.x * blockDim.x) {
+        const long img = pix / HW, p = pix % HW;
+        const float v = gray[(img / rep) * HW + p] * sc;
+        const f16 hi = (f16)v, lo = (f16)(v - (float)hi);
+        f16x8 a = {hi, lo, hi, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f}, z = {};
+        f16x8* o = reinterpret_cast<f16x8*>(out + pix * 16);
+        o[0] = a; o[1] = z;
+    }
+}
+
 inline int grid_for(long total, int block = 256) {
     long g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -177,6 +192,14 @@ int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_
     const long total = (long)n * c * h * sp * w * sp;
     hipLaunchKernelGGL(upfeat_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, s, tok, prob, out_nchw, n, c, h, w, sp);
     DISCO_LAUNCH_CHECK("upfeat_scalar_kernel");
+    return DISCO_OK;
+}
+
+int launch_gray_tail(const float* gray, int rep, const Act& out, hipStream_t s) {
+    if (out.c != 16 || out.plane || out.q_off) { set_error("gray_tail: a 16-channel hi-only tensor, got %d channels", out.c); return DISCO_ESHAPE; }
+    const long HW = (long)out.h * out.w, total = (long)out.n * HW;
+    hipLaunchKernelGGL(gray_tail_kernel, dim3(grid_for(total)), dim3(256), 0, s, gray, rep, out.p, out.sexp, total, HW);
+    DISCO_LAUNCH_CHECK("gray_tail_kernel");
     return DISCO_OK;
 }
 
