@@ -911,7 +911,8 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
 
     // ---- a12 upfeat + a13 HourGlass2 + tanh (model.py:194-197) --------------------------------------------------
     P.stage_arith = arith_of(c, "enhanceNet.");
-    // (the upfeat / gray kernels write fp8 q planes; under the fp6 arithmetic inConv.inConv.0 reads those and writes fp6 ones)
+    // (the upfeat kernel writes fp8 q planes; under the fp6 arithmetic inConv.inConv.0 reads those and writes fp6 ones; the gray channel
+    // is that layer's fp16 tail chunk)
     const int infmt = P.stage_arith == ARITH_MX6 ? (int)Plan::F_Q : P.dfmt();
     Act full = P.act(n2, H, W, 64, infmt);
     const bool gtail = P.mx();                        // f16+fp8x2: a 16-channel fp16 tail source without q planes

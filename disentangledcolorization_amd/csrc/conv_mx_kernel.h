@@ -471,7 +471,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         const bool wr_lo = MODE != 2 && a.out_plane != 0, wr_q = MODE != 2 && a.out_q_off != 0;
         const bool ql_only = a.out_q_kind == 1;              // al8-only q planes: one byte per element, no a8 plane
         // fp6 slots (the consumer runs the f16 + fp6x2 arithmetic).  Compiled in where the forward needs it: AR 3 writes ONLY fp6 q planes, AR 0
-        // only fp8 ones - except its two-source instantiations (inConv.inConv.0 reads the fp8 planes of the upfeat / gray kernels and feeds
+        // only fp8 ones - except its two-source instantiations (inConv.inConv.0 reads the fp8 planes of the upfeat kernel - and the gray tail chunk - and feeds
         // an fp6 layer), which carry one epilogue mode and have the registers for both (the launchers check the combination)
         constexpr bool CAN_Q6 = Q6 || (AR == 0 && NSRC2), CAN_Q8 = !Q6;
         const bool q6_out = CAN_Q6 && (!CAN_Q8 || a.out_q_kind == 2);
