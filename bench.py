@@ -113,18 +113,19 @@ def measure_alt(precision, sd, gray, ab, n_global, args, sync):
                         precision=precision, init_weights=False)
     m.load_state_dict(sd)
     m = m.cuda().eval()
-    r = ShardedColorizer.from_model(m, micro_batches=args.micro, exact_fallback=False)
+    r = ShardedColorizer.from_model(m, micro_batches=1 if args.pipeline else args.micro, exact_fallback=False)
+    r.pipeline = bool(args.pipeline)
 
     def step():
         np.random.seed(130); torch.manual_seed(130)
         return r.colorize(gray, ab, n_global, 0, gather=True, async_gather=True)
     for _ in range(2 + args.warmup):
         step()
-    sync()
+    r.wait(); sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    sync()
+    r.wait(); sync()
     dt = time.perf_counter() - t0
     return {"precision": precision, "value": round(n_global * args.steps / dt, 2), "unit": "images/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
             "note": "ColorProbNet on f16x2+fp8; passes the same parity suite; anchors differ from the fp32 reference in 0.66 % of 1 960 images (default: 0.10 %)"}
@@ -141,6 +142,9 @@ def main():
     ap.add_argument("--precision", default=None, choices=["mx6", "mx8", "x2q", "mx8all", "f16x3"],
                     help="conv arithmetic per stack (disentangledcolorization_amd/model.py); default: the package default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1, help="1 (default): successive steps alternate between two HIP streams, each a full-size forward, the second "
+                                                              "staggered behind the first (runner.py), everything joined by the synchronize() that closes the timed region; "
+                                                              "0: every step is issued as --micro micro-batches and joined before the next one")
     ap.add_argument("--alt", action="store_true", help="also time the opt-in precision mode (x2q) and report it next to `value` as `opt_in_precision` (it runs second, on a warm "
                                                       "power-limited GPU: 5 % below its own stand-alone run, profiles/r03_bench_x2q.json - off by default since round 3)")
     ap.add_argument("--no-alt", action="store_true", help="(accepted for older command lines: the default now)")
@@ -197,7 +201,8 @@ def main():
         model.set_profiling(0)                    # the timed loop is the product: no event pairs around the launches
         # DISCO_FORCE_GATHER=1 (tests/test_gpu_dist.py): run the collectives at world size 1 too
         force = os.environ.get("DISCO_FORCE_GATHER") == "1"
-        runner = ShardedColorizer.from_model(model, micro_batches=args.micro, exact_fallback=False, force_gather=force)   # no host sync while timing
+        runner = ShardedColorizer.from_model(model, micro_batches=1 if args.pipeline else args.micro, exact_fallback=False, force_gather=force)   # no host sync while timing
+        runner.pipeline = bool(args.pipeline)
 
     def seed():
         np.random.seed(130); torch.manual_seed(130)
@@ -299,7 +304,8 @@ def main():
             "config": {"workload": "BASELINE config 2: batch=64/GPU synthetic 256x256 L-channel, K=8 clustering anchors, "
                                    "forward only, synthetic checkpoint of the DISCO layout", "images_per_gpu": args.batch,
                        "global_batch": n_global, "image_size": args.size,
-                       "parallelism": "batch-sharded x%d, one packed all-gather of pred_colors+hint_mask" % world},
+                       "parallelism": "batch-sharded x%d, one packed all-gather of pred_colors+hint_mask" % world,
+                       "issue": "steps pipelined over 2 HIP streams, staggered" if args.pipeline else "%d staggered micro-batches per step" % args.micro},
             "kmeans_events": events, "fp8_saturated_elements": sat, "result_checksum": "%08x" % checksum,
         }
         if model is not None:
@@ -310,7 +316,7 @@ def main():
                 "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": pmc_traffic(),
                 "launches_per_step": conv_launches // prof_steps,
                 "measured": "hipEvent pairs around every conv launch of %d single-stream forwards of the same batch, after the timed loop "
-                            "(the timed loop itself runs un-instrumented on %d streams)" % (prof_steps, args.micro),
+                            "(the timed loop itself runs un-instrumented: %s)" % (prof_steps, "successive steps pipelined over 2 streams, full-size launches" if args.pipeline else "%d micro-batches per step on %d streams" % (args.micro, args.micro)),
                 "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_fl / max(conv_launches, 1) / 1e9, 3),
                 "algorithmic_hbm_bytes_per_launch": int(conv_bytes),

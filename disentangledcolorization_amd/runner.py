@@ -84,6 +84,17 @@ class ShardedColorizer:
         self.out_capable = False
         self._out_channels = (313, 313)             # channels of pal_logit / ref_logit (2 with hint2regress)
         self._stagger_events = []
+        # pipeline: successive colorize() calls alternate between two streams and are NOT joined with the caller's stream until wait():
+        # call k + 1 starts behind the `stagger_convs`-th conv launch of call k, so that whole batches overlap the way staggered
+        # micro-batches do - with full-size launches (a 32-image launch is ~2 % less efficient than a 64-image one) - at the price of an
+        # asynchronous contract: results (and the inputs!) must stay untouched until wait().  bench.py's timed loop runs this way.
+        self.pipeline = False
+        self._pipe_streams = None
+        self._pipe_events = None
+        self._pipe_count = 0
+        self._pipe_prev = None
+        self._pipe_busy = []
+        self._last_stream = None
         self._pending = []          # outstanding asynchronous all-gathers (async_gather=True): (work, finish callback)
         self.last_events = None     # per-image empty-cluster draws of the GLOBAL batch of the latest exact forward
 
@@ -102,6 +113,10 @@ class ShardedColorizer:
     # ---- local forward (optionally as micro-batches on separate streams) ----------------------------------------
     def _forward_local(self, gray, ab, sampled_T, idx, pos, fstream, fbases, want):
         n = gray.shape[0]
+        self._last_stream = None
+        if (self.pipeline and not want and gray.is_cuda and self.out_capable and self.progress_fn is not None and int(sampled_T) == 0
+                and self.micro <= 1 and n > 0):
+            return self._forward_pipelined(gray, ab, idx, pos, fstream, fbases)
         # a forward that reports its empty-cluster events synchronises the host before it returns, so micro-batches would
         # run one after the other anyway: the exact mode issues the shard as one batch
         m = 1 if want else min(self.micro, n)
@@ -145,6 +160,39 @@ class ShardedColorizer:
                     t.record_stream(main)              # allocated on the side stream, consumed on the caller's
         out = full if full is not None else tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
         return out, (np.concatenate(evs) if want else None)
+
+    def _forward_pipelined(self, gray, ab, idx, pos, fstream, fbases):
+        dev = gray.device
+        if self._pipe_streams is None:
+            self._pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            self._pipe_events = [torch.cuda.Event() for _ in range(2)]
+            for ev in self._pipe_events:
+                ev.record(torch.cuda.current_stream(dev))      # (torch creates the hipEvent on the first record)
+        k = self._pipe_count
+        self._pipe_count += 1
+        st = self._pipe_streams[k & 1]
+        main = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        st.wait_event(ready)                                   # the inputs were produced on the caller's stream
+        if self._pipe_prev is not None and self.stagger_convs > 0:
+            st.wait_event(self._pipe_prev)                     # ... and the previous batch is `stagger_convs` conv launches ahead
+        n = gray.shape[0]
+        H, W = gray.shape[2:]
+        h, w = H // self.sp, W // self.sp
+        f32 = dict(device=dev, dtype=torch.float32)
+        full = (torch.empty(n, self._out_channels[0], h, w, **f32), torch.empty(n, self._out_channels[1], h, w, **f32), torch.empty(n, 2, H, W, **f32),
+                torch.empty(n, 9, H, W, **f32), torch.empty(n, 2, h, w, **f32), torch.empty(n, 1, h, w, **f32))
+        for t in full:
+            t.record_stream(st)                                # allocated on the caller's stream, written on st: no reuse before st is done
+        with torch.cuda.stream(st):
+            self.progress_fn(self._pipe_events[k & 1], max(1, self.stagger_convs))
+            self.forward_fn(gray, ab, 0, idx, pos, fstream, fbases, False, full)
+        self._pipe_prev = self._pipe_events[k & 1]
+        if st not in self._pipe_busy:
+            self._pipe_busy.append(st)
+        self._last_stream = st
+        return full, None
 
     def world(self):
         if dist.is_available() and dist.is_initialized():
@@ -236,15 +284,26 @@ class ShardedColorizer:
         force = self.force_gather and dist.is_available() and dist.is_initialized()    # world size 1 normally skips the collective
         if not gather or (world == 1 and not force):
             return pred, mask
+        if self._last_stream is not None:                    # pipelined forward: pack and gather behind it, on its stream
+            with torch.cuda.stream(self._last_stream):
+                res = self._all_gather_packed(pred, mask, n_global, world, rank, rep, async_gather)
+            for t in res:
+                t.record_stream(torch.cuda.current_stream())   # allocated on the side stream, consumed on the caller's (after wait())
+            return res
         return self._all_gather_packed(pred, mask, n_global, world, rank, rep, async_gather)
 
     def wait(self):
-        """Complete every all-gather issued with async_gather=True (the current stream then waits for them)."""
+        """Complete every all-gather issued with async_gather=True and every pipelined forward (the current stream then waits for them)."""
         for work, finish in self._pending:
             work.wait()
             if finish is not None:
                 finish()
         self._pending = []
+        if self._pipe_busy:
+            main = torch.cuda.current_stream()
+            for st in self._pipe_busy:
+                main.wait_stream(st)
+            self._pipe_busy = []
 
     def _all_gather_packed(self, pred, mask, n_global, world, rank, rep, async_op=False):
         """One collective for both results: per output row [pred (2HW) | hint_mask (hw)].  Equal shards (the bench, any batch

@@ -669,3 +669,35 @@ def test_progress_event_is_recorded_once_per_arming(synth_sd):
             assert torch.equal(a_, b_)
         _seed(1); m(gray, ab, True, 0); torch.cuda.synchronize()
         assert abs(start.elapsed_time(ev) - t_ev) < 1e-6      # a later forward does not record it again
+
+
+def test_pipelined_batches_equal_the_plain_runs(synth_sd):
+    """ShardedColorizer.pipeline (bench.py's timed loop): successive colorize() calls alternate between two streams, each a full-size
+    forward staggered behind the previous one, joined only by wait().  Every batch's result must equal the plain call's, bit for bit -
+    also when the caller drops its results right away (the allocator must not hand their memory to a forward still in flight)."""
+    from disentangledcolorization_amd.runner import ShardedColorizer
+    m = _model(synth_sd, 8)
+    batches = [synth.synth_inputs(16, 256, 256, seed=40 + i) for i in range(3)]
+    batches = [(g.cuda(), a.cuda()) for g, a in batches]
+    plain = ShardedColorizer.from_model(m, micro_batches=1, exact_fallback=False)
+    want = []
+    for g_, a_ in batches:
+        _seed(130); p_, m_ = plain.colorize(g_, a_, 16, 0)
+        want.append((p_.clone(), m_.clone()))
+    torch.cuda.synchronize()
+    r = ShardedColorizer.from_model(m, micro_batches=1, exact_fallback=False)
+    r.pipeline = True
+    for rnd in range(3):
+        got = []
+        for i, (g_, a_) in enumerate(batches * 2):
+            _seed(130); res = r.colorize(g_, a_, 16, 0)
+            if rnd == 2 and i % 2:
+                del res                                  # dropped while its forward is still running
+                got.append(None)
+            else:
+                got.append(res)
+        r.wait()
+        torch.cuda.synchronize()
+        for i, res in enumerate(got):
+            if res is not None:
+                assert torch.equal(res[0], want[i % 3][0]) and torch.equal(res[1], want[i % 3][1]), (rnd, i)

@@ -5,7 +5,7 @@ on; bench.py reports null when the sources have changed since).
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o fetch --output-format csv -- \
-        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --micro 1
+        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --pipeline 0 --micro 1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o write --output-format csv -- \
         python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
     python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/pmc_traffic.json
@@ -66,7 +66,7 @@ def main():
     json.dump({
         "source_hash": bench.source_hash(),
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
-                  "`python bench.py --steps 1 --warmup 1 --no-alt --micro 1` (tools/pmc_traffic.py)",
+                  "`python bench.py --steps 1 --warmup 1 --no-alt --pipeline 0 --micro 1` (tools/pmc_traffic.py)",
         "unit_note": "counter unit is KiB; per MI355X_MICROARCH.md the gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of "
                      "wide coalesced streaming reads, so reads are doubled below; WRITE_SIZE is uncalibrated and taken as is",
         "conv_launches (conv3x3_mx_kernel, all arithmetics; 64-image forwards only: the calibration pass is dropped)": nf, "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
