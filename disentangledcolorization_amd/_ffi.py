@@ -89,6 +89,7 @@ SIGNATURES = {
     "disco_op_conv3x3_pack": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_conv3x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "disco_op_act_bytes": (_I, [_I, _I, _I, _I, _I, C.POINTER(_SZ)]),
+    "disco_op_gray_tail": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "disco_op_nchw_to_act_mx": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "disco_op_act_mx_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "disco_op_conv3x3_mx_pack": (_I, [_P, _I, _I, _I, _P, _P, C.POINTER(_SZ)]),

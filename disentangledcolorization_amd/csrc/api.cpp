@@ -1465,17 +1465,35 @@ int disco_op_act_mx_to_nchw(const void* d_src, float* d_dst, int n, int ch, int 
 
 int disco_op_conv3x3_mx_pack(const float* h_w, int c_out, int c_in, int x2q, void* d_packed, int32_t* d_wexp, size_t* bytes) {
     if (!bytes) { set_error("null bytes"); return DISCO_EINVAL; }
-    if (x2q < 0 || x2q > 2) { set_error("conv3x3_mx_pack: variant %d", x2q); return DISCO_EINVAL; }
-    const int cpad = round_up(c_in, x2q == 1 ? 64 : 32);
-    *bytes = conv_mx_packed_bytes(c_out, cpad, x2q);
+    if (x2q < 0 || x2q > 3) { set_error("conv3x3_mx_pack: variant %d", x2q); return DISCO_EINVAL; }
+    // variant 3: the f16+fp8x2 arithmetic with the LAST input channel in the kernel's 16-channel fp16 tail chunk as (x_hi, x_lo, x_hi)
+    // against (w_h, w_h, w_l) (disco_op_gray_tail builds that source; the forward's HourGlass2 input layer)
+    const bool tail = x2q == 3;
+    if (tail && (c_in < 33 || (c_in - 1) % 32)) { set_error("conv3x3_mx_pack: the tail variant takes 32 k + 1 input channels (got %d)", c_in); return DISCO_ESHAPE; }
+    const int cpad = tail ? c_in - 1 + 16 : round_up(c_in, x2q == 1 ? 64 : 32);
+    const int variant = tail ? 0 : x2q;
+    *bytes = conv_mx_packed_bytes(c_out, cpad, variant);
     if (!d_packed) return DISCO_OK;
     if (!h_w || !d_wexp) { set_error("null weight"); return DISCO_EINVAL; }
     std::vector<char> packed(*bytes);
     std::vector<int32_t> wexp((size_t)round_up(c_out, 32));
-    conv_mx_pack_host(h_w, c_out, c_in, nullptr, cpad, packed.data(), wexp.data(), x2q);
+    std::vector<int> map;
+    if (tail) {
+        map.assign(cpad, -1);
+        for (int i = 0; i < c_in; ++i) map[i] = i;
+        map[c_in] = c_in - 1; map[c_in + 1] = CONV_MX_LO_OF(c_in - 1);
+    }
+    conv_mx_pack_host(h_w, c_out, c_in, tail ? map.data() : nullptr, cpad, packed.data(), wexp.data(), variant);
     DISCO_HIP_CHECK(hipMemcpy(d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice));
     DISCO_HIP_CHECK(hipMemcpy(d_wexp, wexp.data(), wexp.size() * 4, hipMemcpyHostToDevice));
     return DISCO_OK;
+}
+
+int disco_op_gray_tail(const float* d_gray, void* d_out, int n, int h, int w, int sexp, void* stream) {
+    if (!d_gray || !d_out) { set_error("null argument"); return DISCO_EINVAL; }
+    if (!positive("gray_tail", {n, h, w})) return DISCO_ESHAPE;
+    Act o = flat_act(d_out, n, 16, h, w, 0, sexp);
+    return launch_gray_tail(d_gray, 1, o, (hipStream_t)stream);
 }
 
 int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const void* d_src1, const void* d_packed_w, const int32_t* d_wexp,
@@ -1494,7 +1512,8 @@ int disco_op_conv3x3_mx(const disco_conv_mx_desc* d, const void* d_src0, const v
     if (d->c_in1) {
         if (!d_src1) { set_error("null second source"); return DISCO_EINVAL; }
         const int h1 = d->up1 ? d->h_in / 2 : d->h_in, w1 = d->up1 ? d->w_in / 2 : d->w_in;
-        const Act s1 = flat_act(d_src1, d->n, d->c_in1, h1, w1, src_planes, d->sexp1);
+        // 16 channels: the fp16 tail source of a two-source f16+fp8x2 layer (hi plane only)
+        const Act s1 = flat_act(d_src1, d->n, d->c_in1, h1, w1, (d->c_in1 == 16 && !d->x2q && !d->q6) ? 0 : src_planes, d->sexp1);
         if (s1.q_off >= ((size_t)1 << 32)) { set_error("conv3x3_mx: source too large"); return DISCO_ESHAPE; }
         ca.src[1] = {s1.p, (uint32_t)s1.q_off, d->c_in1, h1, w1, d->up1, d->sexp1};
         ca.nsrc = 2;

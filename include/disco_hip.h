@@ -236,6 +236,10 @@ int disco_op_conv3x3(const disco_conv_desc *d, const void *d_src0, const void *d
                               with E = the fp16 exponent of the block's largest |hi|: a6 = fp6(hi / 2^(E-2)), scale byte 127 + E - 2;
                               al6 = fp6((xs - hi) / 2^(E-14)), scale byte 127 + E - 3 - operands of the f16 + fp6x2 arithmetic */
 int disco_op_act_bytes(int n, int c_pad, int h, int w, int planes, size_t *bytes);
+/* (n,1,h,w) fp32 -> the 16-channel fp16 hi-plane tensor (x_hi, x_lo, x_hi, 0 ...) x 2^sexp: the second source (c_in1 = 16) of a two-source
+ * f16 + fp8x2 layer whose weights were packed with variant 3 - the channel then enters as an exact three-product fp16 split in one
+ * K = 16 MFMA per tap (models/model.py:194-196: the gray channel of the HourGlass2's input) */
+int disco_op_gray_tail(const float *d_gray, void *d_out, int n, int h, int w, int sexp, void *stream);
 int disco_op_nchw_to_act_mx(const float *d_src, void *d_dst, int n, int c, int h, int w, int c_pad, int planes, int sexp,
                             void *stream);
 /* which = 0: hi (+ lo when present); 1: the a8 plane dequantised; 2: hi + the al8 plane dequantised */
@@ -263,7 +267,8 @@ typedef struct disco_conv_mx_desc {
                                   (2y + ph/2, 2x + ph%2) of an (n, C, 2h, 2w) activation buffer; C a multiple of 32; stride 1 */
 } disco_conv_mx_desc;
 /* d_packed == NULL: only *bytes.  d_wexp: device int32 [round_up(c_out, 32)], the per-output-channel weight scale exponents.
- * x2q: the pack variant = arithmetic: 0 f16 + fp8x2, 1 f16x2 + fp8 (x2q), 2 f16 + fp6x2 */
+ * x2q: the pack variant = arithmetic: 0 f16 + fp8x2, 1 f16x2 + fp8 (x2q), 2 f16 + fp6x2, 3 = 0 with the last of 32 k + 1 input
+ * channels in the 16-channel fp16 tail (disco_op_gray_tail) */
 int disco_op_conv3x3_mx_pack(const float *h_w_oihw, int c_out, int c_in, int x2q, void *d_packed, int32_t *d_wexp,
                              size_t *bytes);
 int disco_op_conv3x3_mx(const disco_conv_mx_desc *d, const void *d_src0, const void *d_src1, const void *d_packed_w,

@@ -153,5 +153,14 @@ def conv3x3_mx(src0, w, bias=None, *, src1=None, up0=False, up1=False, stride=1,
     return out, int(sat.item())
 
 
+def to_gray_tail(g, sexp):
+    """(n,1,h,w) fp32 -> the 16-channel fp16 tail source (x_hi, x_lo, x_hi, 0...) of a two-source f16+fp8x2 layer (disco_op_gray_tail)."""
+    g = g.to(DEV).float().contiguous()
+    n, _, h, w = g.shape
+    a = MxAct(n, 16, h, w, 0, sexp)
+    _ffi.check(_ffi.lib().disco_op_gray_tail(_ffi.ptr(g), _ffi.ptr(a.buf), n, h, w, sexp, stream()))
+    return a
+
+
 def max_err(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()

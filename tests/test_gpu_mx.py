@@ -321,3 +321,33 @@ def test_conv3x3_mx6_two_source_fp8_in_fp6_out_and_depth_to_space(H):
     want = F.relu(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w3.double(), bb.double(), padding=1))
     out, sat = H.conv3x3_mx(H.to_act_mx(x, Q6), w4, bb, act=_ffi.ACT_RELU, out_planes=Q6, out_sexp=H.sexp_for(want.float()), q6=True, d2s=True, tapmask=True)
     assert sat == 0 and H.max_err(out.read(2), want) < (TOL6 + 2 ** -12) * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 32, 32), (64, 64, 17, 33), (32, 128, 24, 40)])
+def test_conv3x3_mx_tail_chunk_matches_torch(H, shape):
+    """The HourGlass2's input layer: cat(64 features, gray) -> 64.  The features come with fp8 planes, the single extra channel as the
+    16-channel fp16 tail source (x_hi, x_lo, x_hi) against the weights (w_h, w_h, w_l): ONE K = 16 MFMA per tap forms its exact
+    three-product split (pack variant 3, disco_op_gray_tail; conv_mx_kernel.h chunk KIND 3).  Against F.conv2d on the concatenation;
+    the extra channel alone (features zero) must come out at f16x3 accuracy, far below the fp8-corrected channels' tolerance."""
+    c0, co, h, w = shape
+    gen = g(c0 * 7 + h)
+    n = 3
+    x = F.relu(torch.randn(n, c0, h, w, generator=gen))
+    gr = torch.randn(n, 1, h, w, generator=gen) * 3
+    wt = torch.randn(co, c0 + 1, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * c0))
+    wt[:, c0] *= 4                       # make the extra channel matter
+    b = torch.randn(co, generator=gen) * 0.1
+    packed = H.pack_conv_mx(wt, 3)
+    for feats, tol in ((x, TOL), (torch.zeros_like(x), 2e-6)):
+        want = _ref(torch.cat([feats, gr], 1), wt, b, 1, _ffi.ACT_LRELU, 0.2, None, None)
+        scale = max(1.0, want.abs().max().item())
+        sx = H.sexp_for(torch.cat([feats.flatten(), gr.flatten()]))
+        a0 = H.to_act_mx(feats, sexp=sx)
+        a1 = H.to_gray_tail(gr, sx)
+        out, sat = H.conv3x3_mx(a0, wt, b, src1=a1, act=_ffi.ACT_LRELU, slope=0.2, out_planes=LO, out_sexp=H.sexp_for(want), packed=packed)
+        assert sat == 0
+        assert H.max_err(out.read(0), want) < tol * scale
+    again, _ = H.conv3x3_mx(a0, wt, b, src1=a1, act=_ffi.ACT_LRELU, slope=0.2, out_planes=LO, out_sexp=H.sexp_for(want), packed=packed)
+    assert torch.equal(again.buf, out.buf)
+    with pytest.raises(_ffi.DiscoError):          # 32 k + 1 input channels only
+        H.pack_conv_mx(torch.randn(64, 64, 3, 3), 3)
