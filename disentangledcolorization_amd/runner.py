@@ -93,6 +93,7 @@ class ShardedColorizer:
         self._pipe_events = None
         self._pipe_count = 0
         self._pipe_prev = None
+        self._pipe_done = [None, None]
         self._pipe_busy = []
         self._last_stream = None
         self._pending = []          # outstanding asynchronous all-gathers (async_gather=True): (work, finish callback)
@@ -171,6 +172,10 @@ class ShardedColorizer:
         k = self._pipe_count
         self._pipe_count += 1
         st = self._pipe_streams[k & 1]
+        # back-pressure: the host never runs more than two batches ahead (the results of a batch in flight cannot be recycled by the
+        # caching allocator, so an unbounded run-ahead would hold one set of result tensors per enqueued batch)
+        if self._pipe_done[k & 1] is not None:
+            self._pipe_done[k & 1].synchronize()
         main = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
         ready.record(main)
@@ -188,6 +193,9 @@ class ShardedColorizer:
         with torch.cuda.stream(st):
             self.progress_fn(self._pipe_events[k & 1], max(1, self.stagger_convs))
             self.forward_fn(gray, ab, 0, idx, pos, fstream, fbases, False, full)
+            done = torch.cuda.Event()
+            done.record(st)
+        self._pipe_done[k & 1] = done
         self._pipe_prev = self._pipe_events[k & 1]
         if st not in self._pipe_busy:
             self._pipe_busy.append(st)
