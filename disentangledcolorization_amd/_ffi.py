@@ -99,6 +99,7 @@ SIGNATURES = {
     "disco_op_deconv4x4_pack": (_I, [_P, _I, _I, _P, C.POINTER(_SZ)]),
     "disco_op_deconv4x4": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "disco_op_poolfeat": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "disco_op_poolfeat_act": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
     "disco_op_upfeat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_encoder_weight_floats": (_SZ, []),
     "disco_op_encoder_stack": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),

@@ -79,7 +79,7 @@ __host__ __device__ inline int mx6_channel_field(int c) { return 16 * ((c >> 2) 
 // v + the values of lanes ^8, ^16, ^32 (the butterfly  v += shfl_xor(v, 8); v += shfl_xor(v, 16); v += shfl_xor(v, 32)  with the same
 // operand order in the lanes of the first row, hence bit-identical there) without the LDS crossbar: DPP row rotate and the gfx950
 // permlane swaps are plain VALU instructions, where __shfl_xor compiles to ds_bpermute_b32 (pool_partial_kernel had 216 per thread).
-// (Written while hunting the concurrency fault described in pool.hip - it was not the cause - and kept: 3 VALU instead of 3 LDS ops.)
+// (Written while hunting the fault described in pool.hip - the shuffles were not its cause - and kept: 3 VALU instead of 3 LDS ops.)
 __device__ __forceinline__ float butterfly_add_8_16_32(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
@@ -114,6 +114,25 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
     return a * b;
 }
 __device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+// ... and their packed forms (v_pk_mul_f32 / v_pk_add_f32 on register pairs).  Operands must be REAL pairs: build a broadcast with
+// pair_of() - the opaque asm keeps the compiler from folding it into an op_sel source modifier, the form that is unsafe next to MFMA
+// waves on this part (tools/pk_fault_repro.hip; tools/audit_op_sel.py scans the compiled kernels for it).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pair_of(float v) {
+    f32x2_t p = {v, v};
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(p));
+#endif
+    return p;
+}
+__device__ __forceinline__ f32x2_t mul_rn2(f32x2_t a, f32x2_t b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ f32x2_t add_rn2(f32x2_t a, f32x2_t b) {
 #pragma clang fp contract(off)
     return a + b;
 }

@@ -48,14 +48,11 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
     const float inv = 1.f / (float)npix;
     int ch_first = 0;
     if (a.sp == 16 && a.c_act == 64) {
-        // NOTE (round 3, tools/stagger_probe.py, profiles/r03_stagger_probe.txt): with the SLP vectoriser's packed fp32 code for the
-        // 72 multiply-adds below (v_pk_fma_f32 with op_sel broadcasts of the LDS-loaded probabilities, v_pk_add/mul_f32 behind SDWA
-        // conversions), this path returned a wrong LOW half of one packed result - one register of one wave, a missing contribution
-        // of ~0.1-1 % in a handful of tokens - about once per 12 forwards as soon as FOUR or more HIP streams ran forwards
-        // concurrently (never with one to three streams, never on a stream running alone, never in any other kernel; inputs and
-        // every other stage bit-identical).  Not explained: draining the loads, idling, un-unrolling and a shuffle-free butterfly
-        // did not change it; the scalar code of -fno-slp-vectorize (this file's build flag) and the generic path below did not
-        // show it in 640 / 320 concurrent forwards.  The arithmetic is the same IEEE operations in the same order: bit-identical.
+        // NOTE (round 3): built WITHOUT the SLP vectoriser (build.py).  Its packed code for the 72 multiply-adds below broadcasts the
+        // LDS-loaded probabilities with op_sel, and `v_pk_fma_f32 ... op_sel:[0,1,0]` (low result half from the HIGH dword of a source)
+        // returns a wrong low half while other waves of the CU issue MFMAs - tools/pk_fault_repro.hip shows it with registers only;
+        // here it meant a missing contribution of ~0.1-1 % in a handful of tokens about once per 12 concurrent small forwards
+        // (profiles/r03_stagger_probe.txt, r03_pk_fma_op_sel_fault.txt; tools/audit_op_sel.py guards every file).
         // The 64 act channels of a 16x16 cell, 16 bytes per load: thread = (8-channel group q = tid & 7, pixel subset r = tid >> 3),
         // pixel p = 32 i + r (i = 0..7): a wave reads 8 consecutive pixels x 64 channels = 4 planes x 256 contiguous bytes per
         // load instruction (the scalar path below moves 2 bytes per lane: 8x the instructions, address-unit bound).  Each thread
@@ -242,3 +239,21 @@ int launch_poolfeat(const PoolArgs& a, hipStream_t s) {
 }
 
 }  // namespace disco
+
+// Op-level entry point for the forward's pooling launch (the 16-byte path: 64 act channels with hi + lo planes, plus two fp32 NCHW
+// channels): tokens (n, L, 64) and the pooled NCHW channels (n, 2, h, w).  tools/concurrency_probe.py runs it next to other work.
+extern "C" int disco_op_poolfeat_act(const void* d_act, const float* d_nchw2, const float* d_prob, float* d_tokens, float* d_pooled2, int n,
+                                     int h, int w, void* d_ws, size_t ws_bytes, void* stream) {
+    using namespace disco;
+    if (!d_act || !d_nchw2 || !d_prob || !d_tokens || !d_pooled2 || !d_ws || n <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16) { set_error("poolfeat_act: bad argument"); return DISCO_EINVAL; }
+    if (ws_bytes < poolfeat_ws_bytes(n, 66, h, w, 16)) { set_error("poolfeat_act: workspace too small"); return DISCO_ENOMEM; }
+    PoolArgs pa{};
+    pa.feat_act = reinterpret_cast<const f16*>(d_act); pa.feat_plane = (long)n * 64 * h * w; pa.c_act = 64; pa.feat_mul = 1.f;
+    pa.feat_nchw = d_nchw2; pa.c_nchw = 2; pa.prob = d_prob;
+    const size_t cells = (size_t)n * (h / 16) * (w / 16);
+    pa.partial = (float*)d_ws; pa.cnt = (float*)d_ws + cells * 9 * 67;
+    pa.tok_out = d_tokens; pa.c_tok = 64; pa.nchw_out = d_pooled2; pa.c_from = 64;
+    pa.n = n; pa.H = h; pa.W = w; pa.sp = 16;
+    return launch_poolfeat(pa, (hipStream_t)stream);
+}
+

@@ -93,16 +93,22 @@ __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restric
         trow[s] = tok + ((long)img * L + (inside ? ty * ws + tx : cy * ws + cx)) * c;
     }
     unsigned sat = 0;
+    // packed arithmetic written out by hand (this file is built without the SLP vectoriser, see build.py): the nine weights as real
+    // register pairs, token pairs straight from SGPR pairs; per element the same mul, add sequence in slot order as the scalar code
+    f32x2_t pw2[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) pw2[s] = pair_of(pw[s]);
     for (int hb = 0; hb < 2 * nblk; ++hb) {            // 8 channels per trip: 9 x 8 token values in SGPRs
-        float acc[8];
+        f32x2_t acc2[4];
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float tv = trow[s][hb * 8 + j];
-                acc[j] = s == 0 ? mul_rn(tv, pw[0]) : add_rn(acc[j], mul_rn(tv, pw[s]));
+            for (int j = 0; j < 4; ++j) {
+                const f32x2_t tv = {trow[s][hb * 8 + 2 * j], trow[s][hb * 8 + 2 * j + 1]};
+                acc2[j] = s == 0 ? mul_rn2(tv, pw2[0]) : add_rn2(acc2[j], mul_rn2(tv, pw2[s]));
             }
         }
+        const float acc[8] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
         store_act8(out_act, out_plane, q_off, sexp, img, hb >> 1, hb & 1, p, HW, nblk, acc, &sat);
     }
     if (sat_out && sat) atomicAdd(sat_out, sat);

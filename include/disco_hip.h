@@ -294,6 +294,10 @@ int disco_op_deconv4x4(const void *d_src, const void *d_packed_w, const float *d
 /* superpixel ops on fp32 NCHW tensors (basic.py:274-376) */
 int disco_op_poolfeat(const float *d_feat, const float *d_prob, float *d_pooled, float *d_conf, float *d_sizes,
                       int n, int c, int h, int w, int sp, void *d_ws, size_t ws_bytes, void *stream);
+/* the forward's own pooling launch: d_act = 64 channels in the activation layout with hi + lo planes (disco_op_nchw_to_act), d_nchw2 =
+ * (n,2,h,w) fp32; -> tokens (n, h/16 w/16, 64) and the two pooled NCHW channels (n,2,h/16,w/16).  Workspace: as disco_op_poolfeat with 66 channels. */
+int disco_op_poolfeat_act(const void *d_act, const float *d_nchw2, const float *d_prob, float *d_tokens, float *d_pooled2, int n, int h, int w,
+                          void *d_ws, size_t ws_bytes, void *stream);
 int disco_op_upfeat(const float *d_tok, const float *d_prob, float *d_out, int n, int c, int h, int w, int sp,
                     void *stream);
 

@@ -162,3 +162,20 @@ def test_mx_weight_pack_and_fp8_codec(lib):
     assert lib.disco_op_act_bytes(2, 64, 8, 8, _ffi.PLANE_LO | _ffi.PLANE_Q, C.byref(ab)) == 0 and ab.value == 2 * 64 * 64 * 6
     assert lib.disco_op_act_bytes(2, 64, 8, 8, _ffi.PLANE_QL, C.byref(ab)) == 0 and ab.value == 2 * 64 * 64 * 3     # hi + al8 only
     assert lib.disco_op_act_bytes(2, 64, 8, 8, _ffi.PLANE_Q6, C.byref(ab)) == 0 and ab.value == 2 * 64 * 64 * 4     # hi + a6 | al6 slots
+
+
+def test_no_packed_fp32_instruction_with_op_sel():
+    """gfx950 erratum found in round 3 (tools/pk_fault_repro.hip): `v_pk_fma_f32 ... op_sel:[0,1,0]` (a LOW result half taken from the HIGH
+    dword of a source) returns a wrong low half while other waves of the CU issue MFMAs.  The SLP vectoriser emits such forms, so the
+    files whose packed code it generated are built with -fno-slp-vectorize; this compiles every kernel file to assembly and fails if the
+    form (on any 64-bit packed instruction) appears anywhere."""
+    import shutil
+    import subprocess
+    import sys
+    from disentangledcolorization_amd import build as B
+    if not (os.path.exists(B.HIPCC) or shutil.which(B.HIPCC)):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "audit_op_sel.py")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "unsafe instructions: 0" in r.stdout

@@ -88,10 +88,29 @@ def make_pool(n, c, hw, seed=0):
     return run
 
 
+def make_pool_act(n, hw, seed=0):
+    """The forward's own pooling launch (disco_op_poolfeat_act): 64 act channels hi + lo and two fp32 channels -> tokens."""
+    g = torch.Generator().manual_seed(seed)
+    feat = H.to_act(torch.relu(torch.randn(n, 64, hw, hw, generator=g)) * 3)
+    ab = torch.randn(n, 2, hw, hw, generator=g).to(H.DEV)
+    p = torch.softmax(torch.randn(n, 9, hw, hw, generator=g) * 2, 1).to(H.DEV)
+    h = hw // 16
+    def run(stream):
+        tok = torch.empty(n, h * h, 64, device=H.DEV); pooled2 = torch.empty(n, 2, h, h, device=H.DEV)
+        ws = torch.empty(n * h * h * 9 * 68 * 4, dtype=torch.uint8, device=H.DEV)
+        _ffi.check(L.disco_op_poolfeat_act(_ffi.ptr(feat), _ffi.ptr(ab), _ffi.ptr(p), _ffi.ptr(tok), _ffi.ptr(pooled2), n, hw, hw, _ffi.ptr(ws), ws.numel(), sp(stream)))
+        return torch.cat([tok.flatten(), pooled2.flatten()])
+    return run
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--only", default="")
+    ap.add_argument("--bg-streams", type=int, default=1, help="number of background streams (each loops the background ops)")
+    ap.add_argument("--bg-set", default="", help="with --bg mix: comma-separated indices of the background ops to keep (0 conv f16x3 512ch, 1 conv mx6 256ch, "
+                                                  "2 conv f16x3 64ch @256, 3 conv f16x3 stride 2, 4 encoder stack, 5 pooling (act path), 6 conv mx6 64ch @256)")
+    ap.add_argument("--bg", default="conv", help="conv: two large convolutions; mix: convolutions of several shapes / arithmetics, encoder stacks and poolings, as concurrent forwards would run them")
     args = ap.parse_args()
     ops = {
         "conv f16x3 256->256 @64 n=8": make_conv(8, 256, 256, 64),
@@ -102,9 +121,17 @@ def main():
         "conv mx8 256->256 @64 n=8": make_conv_mx(8, 256, 256, 64, False),
         "encoder stack n=8 l=256": make_encoder(8, 256),
         "poolfeat n=8 c=64 256^2": make_pool(8, 64, 256),
+        "poolfeat (forward's act path) n=8 256^2": make_pool_act(8, 256),
     }
-    bg_ops = [make_conv(64, 512, 512, 32, seed=5), make_conv_mx(64, 256, 256, 64, True, seed=6)]
-    s_bg, s_t = torch.cuda.Stream(), torch.cuda.Stream()
+    if args.bg == "mix":
+        bg_ops = [make_conv(8, 512, 512, 32, seed=5), make_conv_mx(8, 256, 256, 64, True, seed=6), make_conv(8, 64, 64, 256, seed=7), make_conv(8, 128, 256, 128, 2, seed=8),
+                  make_encoder(8, 256, seed=9), make_pool_act(8, 256, seed=10), make_conv_mx(8, 64, 64, 256, True, seed=11)]
+        if args.bg_set:
+            bg_ops = [bg_ops[int(i)] for i in args.bg_set.split(",")]
+    else:
+        bg_ops = [make_conv(64, 512, 512, 32, seed=5), make_conv_mx(64, 256, 256, 64, True, seed=6)]
+    s_bgs = [torch.cuda.Stream() for _ in range(args.bg_streams)]
+    s_t = torch.cuda.Stream()
     bad_total = 0
     for name, op in ops.items():
         if args.only and args.only not in name:
@@ -113,11 +140,12 @@ def main():
             ref = op(s_t).clone()
         torch.cuda.synchronize()
         keep = []
-        with torch.cuda.stream(s_bg):
-            for i in range(6 * args.reps):
-                keep.append(bg_ops[i & 1](s_bg))
-                if len(keep) > 4:
-                    keep.pop(0)
+        for i in range(6 * args.reps):
+            for j, s_bg in enumerate(s_bgs):
+                with torch.cuda.stream(s_bg):
+                    keep.append(bg_ops[(i + j) % len(bg_ops)](s_bg))
+            if len(keep) > 8 * len(s_bgs):
+                del keep[:len(s_bgs)]
         outs = []
         with torch.cuda.stream(s_t):
             for _ in range(args.reps):

@@ -1,12 +1,15 @@
-// Reduced reproducer attempt for the concurrency fault of DESIGN.md section 4 (pool_partial_kernel's packed-fp32 path).
-//   hipcc --offload-arch=gfx950 -O3 tools/pk_fault_repro.hip -o /tmp/pk_repro            (SLP-packed v_pk_fma_f32)
-//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize tools/pk_fault_repro.hip -o /tmp/pk_repro_scalar
-//   /tmp/pk_repro [bg_streams=7] [rounds=40] [bg_kind=0|1]
-// One stream runs a kernel shaped like the 16-byte path of pool_partial_kernel (per 16x16 cell: 256 pixels x 64 fp16 hi/lo channels
-// weighted by 9 probabilities from LDS, butterfly over the lanes, 4 waves combined through LDS) again and again while `bg_streams` other
-// streams keep every CU busy with persistent 512-thread workgroups holding 150 KB of LDS (bg_kind 0: MFMA + ds_read/ds_write;
-// 1: the same with buffer_load ... lds traffic, like the conv kernel's operand staging).  Every result is compared bit for bit with the
-// run made alone.
+// Stand-alone reproducer of the packed-fp32 fault of DESIGN.md section 4 (found through pool_partial_kernel, round 3).
+//   hipcc --offload-arch=gfx950 -O3 tools/pk_fault_repro.hip -o /tmp/pk_repro
+//   /tmp/pk_repro [bg_streams=7] [rounds=40] [bg_kind=0|1] [bg_lds_kib=100]
+// Part 1 (registers only): a kernel runs the same multiply-add recurrences as v_pk_fma_f32 - one operand-selection form per group of
+// accumulators - and as v_fmac_f32 on the same numbers, and counts the results that differ: alone, and while `bg_streams` other
+// streams run a 512-thread MFMA kernel on every CU.  On the MI355X boxes of this project: 0 wrong alone; next to the MFMA kernel
+// `op_sel:[0,1,0]` (low result half from the HIGH dword of src1) gives ~10^6 wrong LOW halves, every other form 0
+// (profiles/r03_pk_fma_op_sel_fault.txt).
+// Part 2: a kernel shaped like pool_partial_kernel's 16-byte path (the SLP vectoriser packs its 72 multiply-adds per pixel pair with
+// op_sel broadcasts) run again and again next to the same background and compared bit for bit with the run made alone; it fails
+// when a background workgroup leaves room for it on the CU (bg_lds_kib = 100) and never when it does not (150), and never when
+// built with -fno-slp-vectorize.  bg_kind 1 adds buffer_load ... lds traffic to the background (not needed for the fault).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +76,62 @@ __global__ __launch_bounds__(256) void pool_like(const f16* __restrict__ feat, l
     }
 }
 
+// Registers-only self-check: every lane runs the same multiply-add recurrences as packed fp32 (v_pk_fma_f32, one operand-selection form per
+// group of accumulators) and as scalar v_fmac_f32 on the same numbers, and counts the results that differ, per form.  No memory, no LDS.
+//   form 0: plain pairs                      v_pk_fma_f32 d, a, b, d
+//   form 1: src1 low dword to both halves    ... op_sel_hi:[1,0,1]
+//   form 2: src1 high dword to both halves   ... op_sel:[0,1,0]
+//   form 3: an SGPR pair as src1             v_pk_fma_f32 d, a, s[n:n+1], d
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void pk_selfcheck(unsigned* __restrict__ bad, float* __restrict__ sink, int iters, float sgpr_val) {
+    const float l = (float)(threadIdx.x & 63) * 0.001f + 1.0f;
+    f32x2 acc[4][2];
+    float sa[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[f][i] = f32x2{0.f, 0.f}; sa[f][2 * i] = 0.f; sa[f][2 * i + 1] = 0.f; }
+    float x = l, y = 0.5f + l * 0.25f;
+    const float sv = __builtin_amdgcn_readfirstlane(sgpr_val);
+    for (int it = 0; it < iters; ++it) {
+        x = x * 0.999f + 0.001f; y = y * 1.0005f - 0.0004f;
+        f32x2 pr = {y, y * 0.5f};
+        asm volatile("" : "+v"(pr));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x2 xv = {x + (float)i, x - (float)i};
+            asm volatile("" : "+v"(xv));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[0][i]) : "v"(xv), "v"(pr));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[1][i]) : "v"(xv), "v"(pr));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc[2][i]) : "v"(xv), "v"(pr));
+            acc[3][i] = __builtin_elementwise_fma(xv, f32x2{sv, sv}, acc[3][i]);
+            float a0 = xv.x, a1 = xv.y, p0 = pr.x, p1 = pr.y, s0 = sv;
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(p0), "+v"(p1), "+v"(s0));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[0][2 * i]) : "v"(a0), "v"(p0));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[0][2 * i + 1]) : "v"(a1), "v"(p1));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[1][2 * i]) : "v"(a0), "v"(p0));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[1][2 * i + 1]) : "v"(a1), "v"(p0));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[2][2 * i]) : "v"(a0), "v"(p1));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[2][2 * i + 1]) : "v"(a1), "v"(p1));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[3][2 * i]) : "v"(a0), "v"(s0));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[3][2 * i + 1]) : "v"(a1), "v"(s0));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        unsigned nb = 0, nlo = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned dl = __float_as_uint(acc[f][i].x) != __float_as_uint(sa[f][2 * i]), dh = __float_as_uint(acc[f][i].y) != __float_as_uint(sa[f][2 * i + 1]);
+            nb += dl + dh; nlo += dl;
+            s += acc[f][i].x + acc[f][i].y;
+        }
+        if (nb) { atomicAdd(bad + 2 * f, nb); atomicAdd(bad + 2 * f + 1, nlo); }
+    }
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(512, 2) void bg_kernel(const f16x8* __restrict__ ops, const char* __restrict__ stream_src, unsigned src_bytes, float* __restrict__ sink, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem_bg[];
@@ -81,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void bg_kernel(const f16x8* __restrict__ op
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     f16x8* lds = reinterpret_cast<f16x8*>(smem_bg);
-    for (int i = threadIdx.x; i < 150 * 1024 / 16; i += 512) lds[i] = a;
+    for (int i = threadIdx.x; i < 96 * 1024 / 16; i += 512) lds[i] = a;
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)stream_src, 0, src_bytes, 0x00020000);
     for (int it = 0; it < iters; ++it) {
@@ -91,12 +150,12 @@ __global__ __launch_bounds__(512, 2) void bg_kernel(const f16x8* __restrict__ op
 #pragma unroll
             for (int pce = 0; pce < 8; ++pce) {
                 const unsigned off = ((unsigned)(blockIdx.x * 8 + wave) * 8192u + (unsigned)pce * 1024u + (unsigned)it * 65536u) % (src_bytes - 8192u);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem_bg + wave * 16384 + pce * 1024), 16, lane * 16, off & ~15u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem_bg + wave * 8192 + pce * 1024), 16, lane * 16, off & ~15u, 0, 0);
             }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const f16x8 x = lds[(wave * 1024 + t * 64 + lane) & (150 * 64 - 1)];
+            const f16x8 x = lds[(wave * 512 + t * 64 + lane) % (96 * 64)];
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(i & 1 ? b : x, i & 2 ? a : x, acc[i], 0, 0, 0);
         }
@@ -110,6 +169,7 @@ __global__ __launch_bounds__(512, 2) void bg_kernel(const f16x8* __restrict__ op
 
 int main(int argc, char** argv) {
     const int nbg = argc > 1 ? atoi(argv[1]) : 7, rounds = argc > 2 ? atoi(argv[2]) : 40, kind = argc > 3 ? atoi(argv[3]) : 0;
+    const int lds_kib = argc > 4 ? atoi(argv[4]) : 100;
     const int n = 8, ws = 16, cells = n * ws * ws;
     const size_t fe = (size_t)n * 64 * HW;
     std::vector<f16> hf(2 * fe);
@@ -143,8 +203,8 @@ int main(int argc, char** argv) {
     for (int rd = 0; rd < rounds; ++rd) {
         for (int k = 0; k < 12; ++k)
             for (auto& s : bs) {
-                if (kind) hipLaunchKernelGGL(bg_kernel<1>, dim3(256), dim3(512), 150 * 1024, s, dops, dsrc, src_bytes, dsink, 300);
-                else hipLaunchKernelGGL(bg_kernel<0>, dim3(256), dim3(512), 150 * 1024, s, dops, dsrc, src_bytes, dsink, 300);
+                if (kind) hipLaunchKernelGGL(bg_kernel<1>, dim3(256), dim3(512), lds_kib * 1024, s, dops, dsrc, src_bytes, dsink, 300);
+                else hipLaunchKernelGGL(bg_kernel<0>, dim3(256), dim3(512), lds_kib * 1024, s, dops, dsrc, src_bytes, dsink, 300);
             }
         for (int rp = 0; rp < reps; ++rp) hipLaunchKernelGGL(pool_like, dim3(cells), dim3(256), smem, ts, dfeat, (long)fe, dprob, 0.25f, douts[rp], ws);
         CK(hipDeviceSynchronize());
@@ -160,6 +220,27 @@ int main(int argc, char** argv) {
             }
         }
     }
-    printf("bg streams %d (kind %d): %ld of %ld pool_like runs differ from the run made alone\n", nbg, kind, bad, total);
+    {   // registers-only self-check next to the same background
+        unsigned* dbad; CK(hipMalloc(&dbad, 32)); CK(hipMemset(dbad, 0, 32));
+        hipLaunchKernelGGL(pk_selfcheck, dim3(4096), dim3(256), 0, ts, dbad, dsink, 2000, 0.75f);
+        CK(hipDeviceSynchronize());
+        unsigned alone[8], busy[8]; CK(hipMemcpy(alone, dbad, 32, hipMemcpyDeviceToHost));
+        CK(hipMemset(dbad, 0, 32));
+        for (int rd = 0; rd < rounds; ++rd) {
+            for (int k = 0; k < 12; ++k)
+                for (auto& s2 : bs) {
+                    if (kind) hipLaunchKernelGGL(bg_kernel<1>, dim3(256), dim3(512), lds_kib * 1024, s2, dops, dsrc, src_bytes, dsink, 300);
+                    else hipLaunchKernelGGL(bg_kernel<0>, dim3(256), dim3(512), lds_kib * 1024, s2, dops, dsrc, src_bytes, dsink, 300);
+                }
+            for (int rp = 0; rp < 10; ++rp) hipLaunchKernelGGL(pk_selfcheck, dim3(4096), dim3(256), 0, ts, dbad, dsink, 2000, 0.75f);
+            CK(hipDeviceSynchronize());
+        }
+        CK(hipMemcpy(busy, dbad, 32, hipMemcpyDeviceToHost));
+        const char* names[4] = {"plain pairs", "op_sel_hi:[1,0,1] (src1 low dword to both halves)", "op_sel:[0,1,0] (src1 high dword to both halves)", "SGPR pair as src1"};
+        printf("registers-only self-check, v_pk_fma_f32 against v_fmac_f32 on the same numbers (%d launches x 4096 x 256 lanes x 4 results per form):\n", rounds * 10);
+        for (int f = 0; f < 4; ++f)
+            printf("  %-52s alone: %u wrong   next to the background: %u wrong (%u of them in the LOW half)\n", names[f], alone[2 * f], busy[2 * f], busy[2 * f + 1]);
+    }
+    printf("bg streams %d (kind %d, %d KiB LDS): %ld of %ld pool_like runs differ from the run made alone\n", nbg, kind, lds_kib, bad, total);
     return 0;
 }
