@@ -83,12 +83,13 @@ __global__ __launch_bounds__(256) void pool_like(const f16* __restrict__ feat, l
 //   form 2: src1 high dword to both halves   ... op_sel:[0,1,0]
 //   form 3: an SGPR pair as src1             v_pk_fma_f32 d, a, s[n:n+1], d
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int NF = 9;
 __global__ __launch_bounds__(256) void pk_selfcheck(unsigned* __restrict__ bad, float* __restrict__ sink, int iters, float sgpr_val) {
     const float l = (float)(threadIdx.x & 63) * 0.001f + 1.0f;
-    f32x2 acc[4][2];
-    float sa[4][4];
+    f32x2 acc[NF][2];
+    float sa[NF][4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int i = 0; i < 2; ++i) { acc[f][i] = f32x2{0.f, 0.f}; sa[f][2 * i] = 0.f; sa[f][2 * i + 1] = 0.f; }
     float x = l, y = 0.5f + l * 0.25f;
@@ -115,11 +116,26 @@ __global__ __launch_bounds__(256) void pk_selfcheck(unsigned* __restrict__ bad, 
             asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[2][2 * i + 1]) : "v"(a1), "v"(p1));
             asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[3][2 * i]) : "v"(a0), "v"(s0));
             asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[3][2 * i + 1]) : "v"(a1), "v"(s0));
+            // more forms: 4 op_sel:[1,0,0] (src0 high -> low half), 5 op_sel_hi:[0,1,1] (src0 low -> high half), 6 v_pk_mul_f32 op_sel:[0,1], 7 v_pk_add_f32 op_sel:[0,1],
+            // 8 op_sel_hi:[0,0,1] (both sources: low dwords to the high half)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc[4][i]) : "v"(xv), "v"(pr));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[5][i]) : "v"(xv), "v"(pr));
+            { f32x2 t; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(t) : "v"(xv), "v"(pr)); acc[6][i] = t; }
+            { f32x2 t; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(t) : "v"(xv), "v"(pr)); acc[7][i] = t; }
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,0,1]" : "+v"(acc[8][i]) : "v"(xv), "v"(pr));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[4][2 * i]) : "v"(a1), "v"(p0));          // low half: src0 HIGH x src1 low
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[4][2 * i + 1]) : "v"(a1), "v"(p1));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[5][2 * i]) : "v"(a0), "v"(p0));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[5][2 * i + 1]) : "v"(a0), "v"(p1));      // high half: src0 LOW x src1 high
+            { float t0, t1; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(a0), "v"(p1)); asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(a1), "v"(p1)); sa[6][2 * i] = t0; sa[6][2 * i + 1] = t1; }
+            { float t0, t1; asm volatile("v_add_f32 %0, %1, %2" : "=v"(t0) : "v"(a0), "v"(p1)); asm volatile("v_add_f32 %0, %1, %2" : "=v"(t1) : "v"(a1), "v"(p1)); sa[7][2 * i] = t0; sa[7][2 * i + 1] = t1; }
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[8][2 * i]) : "v"(a0), "v"(p0));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(sa[8][2 * i + 1]) : "v"(a0), "v"(p0));      // high half: src0 low x src1 low
         }
     }
     float s = 0.f;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < NF; ++f) {
         unsigned nb = 0, nlo = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -221,11 +237,11 @@ int main(int argc, char** argv) {
         }
     }
     {   // registers-only self-check next to the same background
-        unsigned* dbad; CK(hipMalloc(&dbad, 32)); CK(hipMemset(dbad, 0, 32));
+        unsigned* dbad; CK(hipMalloc(&dbad, 8 * NF)); CK(hipMemset(dbad, 0, 8 * NF));
         hipLaunchKernelGGL(pk_selfcheck, dim3(4096), dim3(256), 0, ts, dbad, dsink, 2000, 0.75f);
         CK(hipDeviceSynchronize());
-        unsigned alone[8], busy[8]; CK(hipMemcpy(alone, dbad, 32, hipMemcpyDeviceToHost));
-        CK(hipMemset(dbad, 0, 32));
+        unsigned alone[2 * NF], busy[2 * NF]; CK(hipMemcpy(alone, dbad, 8 * NF, hipMemcpyDeviceToHost));
+        CK(hipMemset(dbad, 0, 8 * NF));
         for (int rd = 0; rd < rounds; ++rd) {
             for (int k = 0; k < 12; ++k)
                 for (auto& s2 : bs) {
@@ -235,11 +251,13 @@ int main(int argc, char** argv) {
             for (int rp = 0; rp < 10; ++rp) hipLaunchKernelGGL(pk_selfcheck, dim3(4096), dim3(256), 0, ts, dbad, dsink, 2000, 0.75f);
             CK(hipDeviceSynchronize());
         }
-        CK(hipMemcpy(busy, dbad, 32, hipMemcpyDeviceToHost));
-        const char* names[4] = {"plain pairs", "op_sel_hi:[1,0,1] (src1 low dword to both halves)", "op_sel:[0,1,0] (src1 high dword to both halves)", "SGPR pair as src1"};
+        CK(hipMemcpy(busy, dbad, 8 * NF, hipMemcpyDeviceToHost));
+        const char* names[NF] = {"v_pk_fma_f32, plain pairs", "v_pk_fma_f32 op_sel_hi:[1,0,1] (src1 low -> both)", "v_pk_fma_f32 op_sel:[0,1,0] (src1 HIGH -> both)", "v_pk_fma_f32, broadcast pair in VGPRs",
+                                 "v_pk_fma_f32 op_sel:[1,0,0] (src0 HIGH -> low half)", "v_pk_fma_f32 op_sel_hi:[0,1,1] (src0 low -> high half)", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[0,1]",
+                                 "v_pk_fma_f32 op_sel_hi:[0,0,1] (src0, src1 low -> high half)"};
         printf("registers-only self-check, v_pk_fma_f32 against v_fmac_f32 on the same numbers (%d launches x 4096 x 256 lanes x 4 results per form):\n", rounds * 10);
-        for (int f = 0; f < 4; ++f)
-            printf("  %-52s alone: %u wrong   next to the background: %u wrong (%u of them in the LOW half)\n", names[f], alone[2 * f], busy[2 * f], busy[2 * f + 1]);
+        for (int f = 0; f < NF; ++f)
+            printf("  %-60s alone: %u wrong   next to the background: %u wrong (%u of them in the LOW half)\n", names[f], alone[2 * f], busy[2 * f], busy[2 * f + 1]);
     }
     printf("bg streams %d (kind %d, %d KiB LDS): %ld of %ld pool_like runs differ from the run made alone\n", nbg, kind, lds_kib, bad, total);
     return 0;
