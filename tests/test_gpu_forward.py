@@ -620,10 +620,11 @@ def test_out_of_range_input_recalibrates_itself(synth_sd, q_to_ab):
 
 def test_concurrent_micro_batches_equal_the_single_stream_result(synth_sd):
     """runner.py issues a batch as micro-batches on separate HIP streams (staggered by disco_set_progress_event).  Every output must
-    equal the one-stream result bit for bit, for 2 (bench.py's default), 4 and 8 streams.  Round 3 found pool_partial_kernel's
-    packed-fp32 path returning a wrong low half of one packed result about once per 12 forwards as soon as four or more streams
-    ran forwards concurrently (tools/stagger_probe.py, profiles/r03_stagger_probe.txt; pool.hip is built with -fno-slp-vectorize
-    since): 8 streams x 6 steps would have tripped with ~98 % probability."""
+    equal the one-stream result bit for bit, for 2, 4 and 8 streams.  Round 3 found pool_partial_kernel returning a wrong low half of
+    one packed fp32 result about once per 12 forwards as soon as small forwards (<= 16 images: conv tiles that leave room on the CU)
+    ran concurrently: `v_pk_fma_f32 ... op_sel:[0,1,0]` is unsafe next to MFMA waves on this part (tools/pk_fault_repro.hip,
+    profiles/r03_pk_fma_op_sel_fault.txt); the affected files are built without the SLP vectoriser and tools/audit_op_sel.py guards
+    the rest.  8 streams x 6 steps would have tripped with ~98 % probability."""
     from disentangledcolorization_amd.runner import ShardedColorizer, global_draws, peek_randint
     m = _model(synth_sd, 8)
     gray, ab = synth.synth_inputs(32, 256, 256, seed=5)
