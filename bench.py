@@ -36,7 +36,7 @@ sys.path.insert(0, REPO)
 GFLOP_PER_IMAGE = 255.470          # algorithmic work of one 256x256 image
 FP16_MFMA_PEAK = 2.5e15            # dense, MI355X_MICROARCH.md
 FP32_MFMA_PEAK = 157.3e12
-CONV_SOURCES = ["conv_mx_kernel.h", "conv_mx.hip", "common.h", "api.cpp"]
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
 
 
 def cpu_baseline(sd, seconds_budget=30.0, all_cores=False):
@@ -75,9 +75,12 @@ def cpu_baseline(sd, seconds_budget=30.0, all_cores=False):
 
 
 def source_hash():
+    """Hash of everything libdisco_hip.so is built from (build.SOURCES + HEADERS: every translation unit incl. the per-arithmetic
+    instantiation lists, the packers and the pooling kernels - round 3 hashed four files only)."""
+    from disentangledcolorization_amd import build as B
     h = hashlib.sha256()
-    for f in CONV_SOURCES:
-        with open(os.path.join(REPO, "disentangledcolorization_amd", "csrc", f), "rb") as fh:
+    for f in sorted(B.SOURCES) + sorted(B.HEADERS):
+        with open(os.path.join(B.CSRC, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
@@ -87,22 +90,27 @@ def pmc_traffic():
     + WRITE_SIZE).  PMC counters cannot be read from inside a timed run, so the file carries the hash of the kernel sources it
     was measured on; a stale file is reported as null rather than as a number."""
     try:
-        with open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", PMC_TRAFFIC_FILE)) as f:
             d = json.load(f)
         return d["hbm_bytes_per_launch"] if d.get("source_hash") == source_hash() else None
     except Exception:
         return None
 
 
-def fake_forward(gray, ab, T, idx, pos, fstream, fbases, want):
-    """DISCO_BENCH_FAKE: CPU stand-in with the model's output contract (depends on the per-image k-means rows)."""
+def fake_forward(gray, ab, T, idx, pos, fstream, fbases, want, out=None):
+    """DISCO_BENCH_FAKE: CPU stand-in with the model's output contract (depends on the per-image k-means rows); out: preallocated
+    result tensors to fill (the pipelined path hands them in, as AnchorColorProb.forward_once does)."""
     n, _, H, W = gray.shape
     h, w = H // 16, W // 16
     d = torch.as_tensor(idx if idx is not None else pos, dtype=torch.float32)
     pred = torch.tanh(gray.repeat(1, 2, 1, 1) * 0.5 + d.sum(1).reshape(n, 1, 1, 1) * 1e-3)
     mask = torch.zeros(n, h * w)
     mask.scatter_add_(1, torch.as_tensor(idx if idx is not None else pos, dtype=torch.long), torch.ones(n, d.shape[1]))
-    return (None, None, pred, None, None, mask.reshape(n, 1, h, w)), (np.zeros(n, np.int32) if want else None)
+    mask = mask.reshape(n, 1, h, w)
+    if out is not None:
+        out[2].copy_(pred); out[5].copy_(mask)
+        return out, (np.zeros(n, np.int32) if want else None)
+    return (None, None, pred, None, None, mask), (np.zeros(n, np.int32) if want else None)
 
 
 def measure_alt(precision, sd, gray, ab, n_global, args, sync):
@@ -190,7 +198,12 @@ def main():
     gray, ab = gray_all[lo:hi].to(dev), ab_all[lo:hi].to(dev)    # inputs resident in HBM before timing
     model = sd = None
     if fake:
-        runner = ShardedColorizer(fake_forward, n_clusters=8, micro_batches=args.micro, exact_fallback=False)
+        runner = ShardedColorizer(fake_forward, n_clusters=8, micro_batches=1 if args.pipeline else args.micro, exact_fallback=False)
+        # the timed loop's real configuration - steps pipelined over two (host stand-in) streams, results written in place, the packed
+        # all-gather enqueued asynchronously behind each forward - so that the gloo tests run the code an 8-GPU node will run
+        runner.out_capable = True
+        runner.progress_fn = lambda ev, k: None
+        runner.pipeline = bool(args.pipeline)
     else:
         from disentangledcolorization_amd.model import AnchorColorProb
         sd = synth.synth_state_dict(130)
@@ -289,7 +302,7 @@ def main():
         ips = n_global * args.steps / elapsed
         out = {
             "metric": "colorized 256x256 images/sec", "value": round(ips, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"mx6": "f16x3 (fp16 hi/lo split, 3 MFMA products) for SpixelNet+ColorProbNet; f16+fp6x2 (fp16 main product + two fp6 e2m3 "

@@ -183,6 +183,10 @@ struct disco_ctx {
     std::map<std::string, float> amax;   // calibration: max |x| of every conv output (fp16 range guard, diagnostics)
     unsigned int* d_sat = nullptr;       // mx: q-plane elements that had to be clamped since the last read
     bool calibrated = false;
+    // One host thread at a time inside a context: the forward entry points, calibration and the setters below lock this.  The GPU work
+    // of successive calls still overlaps across the streams they were given; what is serialised is the host-side issue (staging ring,
+    // one-shot progress event, profiling vectors, calibration tables are plain members).
+    std::mutex mu;
     float* d_enc[2] = {nullptr, nullptr};
     float* d_mid_w = nullptr; float* d_emb_w = nullptr; float* d_trg_w = nullptr; float* d_q_to_ab = nullptr;
     std::map<std::pair<int, int>, float*> pos_cache;
@@ -570,7 +574,7 @@ struct Plan {
     // produce once more with the final exponent.  `tie`: a tensor that is concatenated on read with an earlier one (skip
     // connections; the conv accumulates both sources in ONE domain) runs this pass on the earlier tensor's current exponent; after
     // the pass the pair takes the SMALLER of the two natural exponents (calibrate_ctx), so that neither leaves the [16, 32) target
-    // upwards (the fp8 planes clamp at 448).  A pair whose ranges differ by more than 2^12 cannot share a scale: the error names it.
+    // upwards (the fp8 planes clamp at 448).  A pair whose ranges differ by more than 2^10 cannot share a scale: the error names it.
     template <class F>
     void calibrate(const std::string& key, Act& t, F&& produce, const std::string& tie = "") {
         if (!calib || dry || !ok()) return;
@@ -608,7 +612,9 @@ struct Plan {
             if (it == c->sexp.end()) { set_error("calibration order: %s is tied to %s, which has no exponent yet", key.c_str(), tie.c_str()); rc = DISCO_ESTATE; return; }
             auto nt = c->sexp_nat.find(tie);
             const int e_tie = nt == c->sexp_nat.end() ? it->second : nt->second;
-            if (amax > 0.f && c->amax[tie] > 0.f && std::abs(e - e_tie) > 12) {
+            // (2^10: the tied tensor is produced once at its partner's exponent during this pass - a maximum of [16, 32) 2^10 still fits
+            // fp16; round 3 allowed 2^12, where that intermediate overflowed and the error named a downstream layer instead of the pair)
+            if (amax > 0.f && c->amax[tie] > 0.f && std::abs(e - e_tie) > 10) {
                 set_error("%s and %s are concatenated on read and must share one scale, but their ranges differ too much (max |x| %g vs %g): "
                           "this checkpoint cannot run in fp16 hi/lo arithmetic", key.c_str(), tie.c_str(), (double)amax, (double)c->amax[tie]);
                 rc = DISCO_EUNSUPPORTED; return;
@@ -973,7 +979,16 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
 // tensor's max |x|, once more with the power-of-two scale that measurement fixes (Plan::calibrate).  The scales are
 // properties of the checkpoint from then on (deterministic: the inputs are generated here); q-plane clamping at run time is
 // counted (disco_saturation_count) so that inputs far outside the calibrated range are noticed.
+int calibrate_ctx_impl(disco_ctx* c, const float* d_user_gray, int un, int uh, int uw);
 int calibrate_ctx(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, int uh = 0, int uw = 0) {
+    // a pass that fails midway must not leave half of the tensors on new exponents (with `calibrated` still set from an earlier pass,
+    // forwards would then run on a mix of two calibrations): all or nothing
+    const auto sexp0 = c->sexp, nat0 = c->sexp_nat; const auto amax0 = c->amax; const auto tie0 = c->tie;
+    const int rc = calibrate_ctx_impl(c, d_user_gray, un, uh, uw);
+    if (rc) { c->sexp = sexp0; c->sexp_nat = nat0; c->amax = amax0; c->tie = tie0; }
+    return rc;
+}
+int calibrate_ctx_impl(disco_ctx* c, const float* d_user_gray, int un, int uh, int uw) {
     const int n = d_user_gray ? un : 2, H = d_user_gray ? uh : 256, W = d_user_gray ? uw : 256, K = c->opt.n_clusters, L = (H / 16) * (W / 16);
     std::vector<float> g(d_user_gray ? 0 : (size_t)n * H * W);
     if (!d_user_gray) {
@@ -1029,6 +1044,16 @@ int calibrate_ctx(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, 
     }
     return rc;
 }
+
+// disco_set_progress_event arms ONE forward.  Whatever way the next forward entry point is left - argument error, a segnet-only
+// forward (18 conv launches: fewer than most `after` counts), a HIP failure - the event is recorded on the call's stream when there
+// is one and the handle is dropped: it must never fire in an unrelated later forward (by then the caller may have destroyed it).
+struct ProgressDisarm {
+    disco_ctx* c; hipStream_t s;
+    ~ProgressDisarm() {
+        if (c && c->progress_ev) { hipEventRecord(c->progress_ev, s); c->progress_ev = nullptr; }
+    }
+};
 
 int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
     if (!c || !a) { set_error("null argument"); return DISCO_EINVAL; }
@@ -1216,12 +1241,15 @@ int disco_calibrate(disco_ctx* c, const float* d_gray, int n, int h, int w) {
     if (!c || !c->finalized || !d_gray) { set_error("disco_calibrate: bad argument / context not finalized"); return DISCO_EINVAL; }
     if (n < 1 || n > 64 || h < 16 || w < 16 || h % 16 || w % 16 || (h / 16) * (w / 16) < c->opt.n_clusters) { set_error("disco_calibrate: bad size %dx%dx%d", n, h, w); return DISCO_ESHAPE; }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mu);
+    ProgressDisarm disarm{c, nullptr};
     DISCO_HIP_CHECK(hipDeviceSynchronize());      // no forward of this context may be in flight: the scales are about to change
     return calibrate_ctx(c, d_gray, n, h, w);
 }
 
 int disco_saturation_count(disco_ctx* c, void* stream, uint64_t* count) {
     if (!c || !count || !c->finalized) { set_error("disco_saturation_count: bad argument"); return DISCO_EINVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
     unsigned int v = 0;
     DISCO_HIP_CHECK(hipSetDevice(c->device));
     DISCO_HIP_CHECK(hipMemcpyAsync(&v, c->d_sat, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1261,6 +1289,9 @@ int disco_workspace_bytes(disco_ctx* c, int n, int h, int w, int sampled_T, size
 
 int disco_forward_segnet(disco_ctx* c, int n, int h, int w, const float* d_gray, float* d_affinity, void* d_ws, size_t ws_bytes,
                          void* stream) {
+    std::unique_lock<std::mutex> lk;
+    if (c) lk = std::unique_lock<std::mutex>(c->mu);
+    ProgressDisarm disarm{c, (hipStream_t)stream};
     disco_forward_args a{};
     a.n = n; a.h = h; a.w = w; a.d_workspace = d_ws; a.workspace_bytes = ws_bytes; a.stream = stream;
     if (!c || !c->finalized) { set_error("disco_forward_segnet before disco_finalize"); return DISCO_ESTATE; }
@@ -1274,6 +1305,9 @@ int disco_forward_segnet(disco_ctx* c, int n, int h, int w, const float* d_gray,
 }
 
 int disco_forward(disco_ctx* c, const disco_forward_args* a) {
+    std::unique_lock<std::mutex> lk;
+    if (c) lk = std::unique_lock<std::mutex>(c->mu);
+    ProgressDisarm disarm{c, a ? (hipStream_t)a->stream : nullptr};
     if (c && c->opt.segnet_only) { set_error("segnet_only context: use disco_forward_segnet"); return DISCO_ESTATE; }
     int rc = check_forward_args(c, a);
     if (rc) return rc;
@@ -1291,16 +1325,12 @@ int disco_forward(disco_ctx* c, const disco_forward_args* a) {
             return DISCO_EINVAL;
     }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
-    rc = run_plan(c, a, a->workspace_bytes, false, nullptr);
-    if (c->progress_ev) {           // fewer conv launches than asked for (or an error): never leave a waiter without its record
-        hipEventRecord(c->progress_ev, (hipStream_t)a->stream);
-        c->progress_ev = nullptr;
-    }
-    return rc;
+    return run_plan(c, a, a->workspace_bytes, false, nullptr);      // (ProgressDisarm: fewer conv launches than asked for, or an error)
 }
 
 int disco_set_progress_event(disco_ctx* c, void* event, int after_conv_launches) {
     if (!c || after_conv_launches < 0) { set_error("disco_set_progress_event: bad argument"); return DISCO_EINVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
     c->progress_ev = (hipEvent_t)event;
     c->progress_after = after_conv_launches;
     c->progress_seen = 0;
@@ -1309,12 +1339,14 @@ int disco_set_progress_event(disco_ctx* c, void* event, int after_conv_launches)
 
 int disco_set_debug_checksums(disco_ctx* c, void* d_table, int rows, int cols) {
     if (!c || rows < 0 || cols < 0) { set_error("disco_set_debug_checksums: bad argument"); return DISCO_EINVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
     c->d_dbg = (unsigned long long*)d_table; c->dbg_rows = d_table ? rows : 0; c->dbg_cols = cols; c->dbg_seq = 0;
     return DISCO_OK;
 }
 
 int disco_set_debug_dump(disco_ctx* c, void* d_buf, size_t bytes_per_row) {
     if (!c) return DISCO_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
     c->d_dump = (char*)d_buf; c->dump_stride = d_buf ? bytes_per_row : 0;
     return DISCO_OK;
 }
@@ -1326,6 +1358,7 @@ int disco_sync(void* stream) {
 
 int disco_set_profiling(disco_ctx* c, int level) {
     if (!c) return DISCO_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
     c->profiling = level;
     return DISCO_OK;
 }

@@ -275,17 +275,34 @@ void conv_mx_pack_host(const float* h_w, int c_out, int c_in, const int* ci_map,
                     const float ws = std::ldexp(1.f, h_wexp[co]), wls = std::ldexp(1.f, h_wexp[co] + MX_LO_SHIFT);
                     if (q6) {
                         // the lane's 32 bytes = the fp6 slot of its row: field f = channel mx6_field_channel(f) of wl6 (kh = 0) / w6 (kh = 1),
-                        // a little-endian stream of 32 six-bit fields in bytes 0-23
-                        unsigned char slot[32] = {0};
+                        // a little-endian stream of 32 six-bit fields in bytes 0-23, and - the MX format proper, as on the activation side -
+                        // ONE E8M0 SCALE PER (output channel, 32-input-channel block, tap) in byte 24, which the MFMA takes as its weight-side
+                        // scale operand straight out of dword 6 of the fragment.  Round 3 scaled a whole row (9 Cin weights) with one exponent:
+                        // e2m3 has two exponent bits, so a weight below 1/8 of its ROW's maximum fell into subnormals and below 1/60 to zero,
+                        // and with it its w a_lo / w_lo a corrections - harmless on Gaussian rows, half of the 1e-3 budget on heavy-tailed
+                        // ones (Student-t(3): 5.0e-4 against 2.0e-4 block-scaled).  The block's largest |value| goes to (3.75, 7.5].
+                        float v32[32], mx = 0.f;
                         for (int f = 0; f < 32; ++f) {
                             const float w = wat(co, g * 32 + mx6_field_channel(f), tap);
-                            const float wl = w - (float)(f16)w;
-                            const unsigned code = kh == 0 ? fp6_code(wl * wls) : fp6_code(w * ws);
+                            v32[f] = kh == 0 ? w - (float)(f16)w : w;
+                            mx = std::max(mx, std::fabs(v32[f]));
+                        }
+                        int e = 0;
+                        if (mx > 0.f) { std::frexp(mx, &e); e = 3 - e; if (std::ldexp(mx, e) > 7.5f) e -= 1; }
+                        e = std::min(std::max(e, -100), 100);
+                        // A/B switch for the parity experiments only (tools/precision_gpu.py --weights t3): round 3's scaling, one exponent per row
+                        static const bool row_scale = std::getenv("DISCO_MX6_ROW_SCALE") != nullptr;
+                        if (row_scale) e = h_wexp[co] + (kh == 0 ? MX_LO_SHIFT : 0);
+                        unsigned char slot[32] = {0};
+                        for (int f = 0; f < 32; ++f) {
+                            const unsigned code = fp6_code(std::ldexp(v32[f], e));
                             const int bit = 6 * f;
                             const unsigned v = code << (bit & 7);
                             slot[bit >> 3] |= (unsigned char)v;
                             slot[(bit >> 3) + 1] |= (unsigned char)(v >> 8);
                         }
+                        // field 2^(byte - 127) = the value; the al6 planes of the pixel side carry lo 2^11 (MX_LO_SHIFT), which the w6 side takes back
+                        slot[24] = (unsigned char)(127 - e - (kh == 0 ? 0 : MX_LO_SHIFT));
                         for (int j = 0; j < 2; ++j) memcpy(qb + j * WBLK + lane * 16, slot + 16 * j, 16);
                     }
                     for (int j = 0; j < 2; ++j) {

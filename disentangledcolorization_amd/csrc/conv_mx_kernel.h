@@ -56,9 +56,31 @@
 #define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk
 #endif
 
+#ifndef MX_PIPE
+#define MX_PIPE 1       // 1: fragment reads software-pipelined one tap ahead of the MFMAs, the chunk barrier inside the last tap (round 4); 0: round 3's loop
+#endif
+#ifndef MX_TIMELINE
+#define MX_TIMELINE 0   // diagnostic builds (tools/conv_timeline.py): workgroup (0, 0) stamps s_memtime at every phase boundary of waves 0 and NWAVE-1
+#endif
+
 namespace disco {
 
 namespace {
+
+#if MX_TIMELINE
+constexpr int MX_TL_EVENTS = 8192;
+__device__ unsigned long long g_mx_tl[2][MX_TL_EVENTS];      // [first / last wave][event]: (s_memtime << 4) | tag; entry 0 = number of events
+#define MX_TL(tag)                                                                                                      \
+    do {                                                                                                                \
+        if (tl_on) {                                                                                                    \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                 \
+            if (lane == 0 && tl_n < MX_TL_EVENTS) g_mx_tl[tl_w][tl_n] = (t_ << 4) | (unsigned long long)(tag);          \
+            ++tl_n;                                                                                                     \
+        }                                                                                                               \
+    } while (0)
+#else
+#define MX_TL(tag) do { } while (0)
+#endif
 
 constexpr int WBLK = 1024;
 constexpr int W_NB = 9 * 2 * WBLK;          // bytes of one chunk of one 32-cout block: 9 taps x 2 KiB
@@ -150,7 +172,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     constexpr int BUF_BYTES = A_BYTES + W_PIECES * 1024;
     constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;
     constexpr int WPW = (W_PIECES + NWAVE - 1) / NWAVE;
-    constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;
+    // the next chunk's DMA is issued in parts between the taps: over all 9 (round 3), or over the first 7 so that everything has two taps
+    // of time to land before the barrier inside the last one (MX_PIPE)
+    constexpr int NPART = MX_PIPE ? 7 : 9;
+    constexpr int APT = (APW + NPART - 1) / NPART, WPT = (WPW + NPART - 1) / NPART;
     constexpr int PAR_OFF = 2 * BUF_BYTES;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,7 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     // E8M0 scale operands of the fp8 products: weight side per lane (= per output channel row), pixel side uniform per source
     int wsc[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) wsc[j] = X3 ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];       // (wexp: fp8 or fp6 scaling, conv_mx_pack_host)
+    for (int j = 0; j < NTW; ++j) wsc[j] = (X3 || Q6) ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];       // (wexp: fp8 scaling per output channel, conv_mx_pack_host; fp6 weight slots carry a block scale each: below)
     // pixel-side E8M0 scale: 1 (the tensor's scale stays in the accumulators)
     constexpr int asc0 = 127, asc1 = asc0;                // fp8 activation planes: no block scale.  fp6 slots: dword 6 of the fragment (below)
 
@@ -302,11 +327,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         }
     }
 
+#if MX_TIMELINE
+    const bool tl_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == NWAVE - 1);
+    const int tl_w = wave == 0 ? 0 : 1;
+    int tl_n = 1;
+#endif
     issue(n, 0, 0, -1);
     int buf = 0;
     bool dma_waited = false;
 
     for (;;) {
+    MX_TL(1);                            // tile start
     f32x16 acc[MT][NTW];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -329,11 +360,152 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     // KIND 2 (X3): the f16x3 arithmetic of conv_mfma2.hip on this skeleton - planes = hi / lo of 16 channels, weight tile = w_hi / w_lo
     //              fragments (conv3x3_pack_host's image), three K = 16 MFMAs per tap in conv_mfma2's order (w_lo a_hi, w_hi a_lo,
     //              w_hi a_hi), so results are bit-identical to that kernel's
-    auto chunk = [&](auto kind_tag, int ck) {
+#if MX_PIPE
+    // ---- round 4: the same taps in the same order (results bit-identical), issued differently ---------------------------------------
+    // Round 3's loop read a tap's fragments and then issued its MFMAs: the inline-asm pin behind every tap is a scheduling boundary, so
+    // the compiler never hoisted tap t + 1's ds_reads above tap t's MFMAs, and a wave sat out the full LDS latency once per tap with
+    // only its SIMD partner to cover it - 8 MFMAs (256 cycles) of cover in an H chunk, 4 (128 cycles) in a Q chunk, where the pipe
+    // idled 40 % of the time (profiles/r04_conv_timeline.txt) - and after every chunk barrier BOTH waves of a SIMD waited for their
+    // first fragments with the pipe empty.  Now (1) the fragments of tap t + 1 are read BEFORE the MFMAs of tap t are issued (two
+    // fragment sets in registers), and (2) the chunk barrier moved from the top of a chunk into the last tap of its predecessor:
+    //     ... tap 7: read frags(8) | MFMAs(7) ... tap 8: wait for own DMA pieces of chunk k+1 and own reads of chunk k, s_barrier,
+    //     read frags(chunk k+1, tap 0) | MFMAs(8) ... chunk k+1 tap 0: read frags(1) | MFMAs(0) ...
+    // so the barrier skew and the first read latency of a chunk run under the last tap's MFMAs.  The buffer protocol is unchanged: the
+    // barrier still separates every wave's last read of chunk k's buffer from the first DMA write into it (chunk k+2's, issued from
+    // chunk k+1's tap 0 on), and every wave's DMA of chunk k+1 from the first read of it.  Only a tile's first chunk waits at its top.
+    struct Frag { i32x4 a[MT][2]; i32x4 b[NTW][2]; };
+    constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
+    constexpr bool ROWREUSE = COLMAJOR && MT == 2;
+    auto slot_live = [&](int slot) -> bool {
+        const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
+        return !MASKED || ((tmask >> (ky * 3 + kx)) & 1u);
+    };
+    // fragments of tap slot `slot` of a KIND chunk in the LDS buffer at byte offset bufoff; prev: the previous slot's (row reuse)
+    auto load_frags = [&](auto kind_tag, int bufoff, int wo, int slot, Frag& f, const Frag& prev) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_tag)::value;
         constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
+        const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
+        const int tap = ky * 3 + kx;
+        const int c0 = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
+        const int c1 = ISQ ? (c0 ^ 16) : c0 + PLANE_B;           // all other address terms are multiples of 32
+        const char* sW = smem + bufoff + A_BYTES;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (ROWREUSE && ky > 0 && mt == 0) { f.a[0][0] = prev.a[1][0]; f.a[0][1] = prev.a[1][1]; continue; }
+            constexpr int RB = G::PITCH * 32;                           // bytes per tile row
+            const int rowc = (mt * G::ROWS_PER_MB * STRIDE + ky) * RB;   // compile-time constant after unrolling: the ds_read's immediate offset
+            f.a[mt][0] = *reinterpret_cast<const i32x4*>(smem + c0 + rowc);
+            if (!TAIL) f.a[mt][1] = *reinterpret_cast<const i32x4*>(smem + c1 + rowc);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int off = wo + nt * W_NB + tap * 2 * WBLK;
+            f.b[nt][0] = *reinterpret_cast<const i32x4*>(sW + off);
+            if (!TAIL) f.b[nt][1] = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
+        }
+    };
+    Frag pf;                       // tap-0 fragments of the next chunk, read behind the barrier inside the current chunk's last tap
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { pf.a[i][0] = i32x4{0, 0, 0, 0}; pf.a[i][1] = i32x4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { pf.b[i][0] = i32x4{0, 0, 0, 0}; pf.b[i][1] = i32x4{0, 0, 0, 0}; }
+    bool pf_valid = false;         // wave-uniform: false for a tile's first chunk
+    // next_kind: KIND of chunk ck + 1 of this tile, -1: this is the tile's last chunk
+    auto chunk = [&](auto kind_tag, int ck, int next_kind) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
+        using KH_ = std::integral_constant<int, 0>; using KQ_ = std::integral_constant<int, 1>; using K3_ = std::integral_constant<int, 2>; using KT_ = std::integral_constant<int, 3>;
+        MX_TL(2);                        // chunk start
+        if (!pf_valid) {
+            if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MX_TL(3);
+            __builtin_amdgcn_s_barrier();
+        }
+        MX_TL(ISQ ? 5 : 4);              // taps of an H (4) / Q (5) chunk begin
+        const bool more = ck + 1 < nchunks;
+        const int dma_img = more ? n : (next_n < a.n ? next_n : n), dma_ck = more ? ck + 1 : 0;
+        const int bufoff = buf * BUF_BYTES;
+        buf ^= 1;
+        const int asc = (NSRC2 && !X3 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
+        int wo = w_off;
+        asm volatile("" : "+v"(wo));
+        Frag cur;
+        if (pf_valid) cur = pf;
+        else {
+            cur = pf;                    // (defined registers for the halves a TAIL chunk does not load)
+            if (ROWREUSE || slot_live(0)) load_frags(kind_tag, bufoff, wo, 0, cur, cur);
+        }
+#pragma unroll
+        for (int slot = 0; slot < 9; ++slot) {
+            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
+            const int tap = ky * 3 + kx;
+            (void)tap;
+#if !(MX_ABL & 1)
+            if (slot < NPART) issue(dma_img, dma_ck, buf, slot);
+#endif
+            Frag nxt = cur;
+            if (slot < 8) {
+                if (ROWREUSE || slot_live(slot + 1)) load_frags(kind_tag, bufoff, wo, slot + 1, nxt, cur);
+            } else if (next_kind >= 0) {
+                // every DMA piece this wave issued for the next chunk has landed, every fragment read of this chunk has returned
+                MX_TL(10);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                MX_TL(11);
+                const int nb = buf * BUF_BYTES;
+                if (ROWREUSE || slot_live(0)) {
+                    if (next_kind == 1) load_frags(KQ_{}, nb, wo, 0, pf, pf);
+                    else if (next_kind == 2) load_frags(K3_{}, nb, wo, 0, pf, pf);
+                    else if (next_kind == 3) load_frags(KT_{}, nb, wo, 0, pf, pf);
+                    else load_frags(KH_{}, nb, wo, 0, pf, pf);
+                }
+            }
+            if ((slot + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            if (slot_live(slot)) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        if (ISQ) {
+                            const i32x8 bw = {cur.b[nt][0][0], cur.b[nt][0][1], cur.b[nt][0][2], cur.b[nt][0][3], cur.b[nt][1][0], cur.b[nt][1][1], cur.b[nt][1][2], cur.b[nt][1][3]};
+                            const i32x8 ap = {cur.a[mt][0][0], cur.a[mt][0][1], cur.a[mt][0][2], cur.a[mt][0][3], cur.a[mt][1][0], cur.a[mt][1][1], cur.a[mt][1][2], cur.a[mt][1][3]};
+                            // fp6 slots carry their own E8M0 block scale (per pixel - or per output channel and tap - and 32 channels) in byte 24 =
+                            // dword 6 of the fragment, which the MFMA ignores as operand data: both scale operands of a lane come straight out of
+                            // its fragment registers
+                            acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], QFMT, QFMT, 0, Q6 ? cur.b[nt][1][2] : wsc[nt], 0, Q6 ? cur.a[mt][1][2] : asc);
+                        } else if (KIND == 2) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][1]), __builtin_bit_cast(f16x8, cur.a[mt][0]), acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][0]), __builtin_bit_cast(f16x8, cur.a[mt][1]), acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][0]), __builtin_bit_cast(f16x8, cur.a[mt][0]), acc[mt][nt], 0, 0, 0);
+                        } else {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][0]), __builtin_bit_cast(f16x8, cur.a[mt][0]), acc[mt][nt], 0, 0, 0);
+                            if (!TAIL) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][1]), __builtin_bit_cast(f16x8, cur.a[mt][1]), acc[mt][nt], 0, 0, 0);
+                        }
+                    }
+                // pin this tap's MFMAs here: without a use of the accumulators the optimiser sinks the whole (pure) MFMA chain of a
+                // chunk below its last tap, which hoists all 9 taps of fragment reads above it (~200 VGPRs, spills)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        float pin = acc[mt][nt][0];
+                        asm volatile("" : "+v"(pin));
+                        acc[mt][nt][0] = pin;
+                    }
+            }
+            cur = nxt;
+        }
+        pf_valid = next_kind >= 0;
+    };
+#else
+    auto chunk = [&](auto kind_tag, int ck, int /*next_kind*/) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
+        MX_TL(2);                        // chunk start
         if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MX_TL(3);                        // this chunk's DMA has landed (own pieces)
         __builtin_amdgcn_s_barrier();
+        MX_TL(ISQ ? 5 : 4);              // barrier passed: taps of an H (4) / Q (5) chunk begin
         const bool more = ck + 1 < nchunks;
         const int dma_img = more ? n : (next_n < a.n ? next_n : n), dma_ck = more ? ck + 1 : 0;
         const char* sA = smem + buf * BUF_BYTES;
@@ -397,9 +569,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                     if (ISQ) {
                         const i32x8 bw = {rb[nt][0][0], rb[nt][0][1], rb[nt][0][2], rb[nt][0][3], rb[nt][1][0], rb[nt][1][1], rb[nt][1][2], rb[nt][1][3]};
                         const i32x8 ap = {ra[mt][0][0], ra[mt][0][1], ra[mt][0][2], ra[mt][0][3], ra[mt][1][0], ra[mt][1][1], ra[mt][1][2], ra[mt][1][3]};
-                        // fp6 slots carry their own E8M0 block scale (per pixel and 32 channels) in byte 24 = dword 6 of the fragment, which
-                        // the MFMA ignores as operand data: the lane's scale operand comes straight out of its fragment registers
-                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], QFMT, QFMT, 0, wsc[nt], 0, Q6 ? ra[mt][1][2] : asc);
+                        // fp6 slots carry their own E8M0 block scale (per pixel - or per output channel and tap - and 32 channels) in byte 24 =
+                        // dword 6 of the fragment, which the MFMA ignores as operand data: both scale operands of a lane come straight out of
+                        // its fragment registers
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], QFMT, QFMT, 0, Q6 ? rb[nt][1][2] : wsc[nt], 0, Q6 ? ra[mt][1][2] : asc);
                     } else if (KIND == 2) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
@@ -421,25 +594,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 }
         }
     };
+#endif
     using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>; using KT = std::integral_constant<int, 3>;
+    // (the last argument: the KIND of the chunk that follows in this tile, -1 behind the last one)
     if constexpr (X3) {
-        for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck);
+        for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck, ck + 1 < nchunks ? 2 : -1);
     } else if constexpr (XQ) {
         for (int ck = 0; ck < nchunks; ck += 5) {
 #pragma unroll 1
-            for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h);     // H, L, H, L: the same code, other weights
-            chunk(KQ{}, ck + 4);
+            for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h, h < 3 ? 0 : 1);     // H, L, H, L: the same code, other weights
+            chunk(KQ{}, ck + 4, ck + 5 < nchunks ? 0 : -1);
         }
     } else {
         for (int ck = 0; ck + 1 < nchunks; ck += 2) {
-            chunk(KH{}, ck);
-            chunk(KQ{}, ck + 1);
+            chunk(KH{}, ck, 1);
+            chunk(KQ{}, ck + 1, ck + 3 < nchunks ? 0 : ((NSRC2 && AR == 0 && ck + 2 < nchunks) ? 3 : -1));
         }
         if constexpr (NSRC2 && AR == 0) {
-            if (nchunks & 1) chunk(KT{}, nchunks - 1);
+            if (nchunks & 1) chunk(KT{}, nchunks - 1, -1);
         }
     }
 
+    MX_TL(6);                            // taps done
     // ---- epilogue: bias (+res) -> activation -> BN affine -> split into the output planes -> store ------------------------
     // All stores go through ONE buffer descriptor over the output tensor (hi [+ lo] [+ q] planes are one allocation): the
     // per-lane part of an address is a 32-bit pixel offset per M block, everything that depends on the channel group, the
@@ -755,7 +931,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             }
         }
         // ---- phase 2: the next image's first chunk has landed ----
+        MX_TL(7);                        // epilogue math done
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MX_TL(8);                        // ... and the residual loads / next tile's first DMA have landed
         // ---- phase 3: stores ----
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -819,10 +997,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #endif
     }
     dma_waited = true;
-
+    MX_TL(9);                            // stores issued
     n = next_n;
     if (n >= a.n) break;
     }
+#if MX_TIMELINE
+    if (tl_on && lane == 0) g_mx_tl[tl_w][0] = (unsigned long long)tl_n;
+#endif
 #endif
 }
 

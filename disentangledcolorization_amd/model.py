@@ -175,6 +175,7 @@ class AnchorColorProb(nn.Module):
         self._ws_need = {}
         self._keep = None
         self._range_checks_left = {}
+        self._clamped_unreported = 0     # clamps the automatic range checks read off the device counter, owed to saturation_count()
         if init_weights:
             from .synth import synth_state_dict
             super().load_state_dict(synth_state_dict(130, hint2regress=self.hint2regress), strict=True)
@@ -255,13 +256,18 @@ class AnchorColorProb(nn.Module):
             ctx = self._context(g.device)
             _ffi.check(_ffi.lib().disco_calibrate(ctx, _ffi.ptr(g), g.shape[0], g.shape[2], g.shape[3]))
 
-    def saturation_count(self):
-        """fp8 activation elements clamped since the previous call (one device synchronisation on the current stream)."""
-        if self._ctx is None:
-            return 0
+    def _read_clamp_counter(self):
         cnt = C.c_uint64(0)
         _ffi.check(_ffi.lib().disco_saturation_count(self._ctx, _ffi.current_stream(), C.byref(cnt)))
         return int(cnt.value)
+
+    def saturation_count(self):
+        """fp8 activation elements clamped since the previous call (one device synchronisation on the current stream).  The automatic
+        range checks of the first forwards read the same device counter; what they saw is carried over here, not lost."""
+        if self._ctx is None:
+            return 0
+        seen, self._clamped_unreported = self._clamped_unreported, 0
+        return seen + self._read_clamp_counter()
 
     def set_profiling(self, level=1):
         """0 off, 1 per-stage hipEvents, 2 additionally an event pair around every MFMA conv launch."""
@@ -360,7 +366,8 @@ class AnchorColorProb(nn.Module):
         that its handle exists) on its stream behind its `after_conv_launches`-th MFMA conv launch (disco_set_progress_event):
         runner.py staggers its micro-batches with it."""
         dev = torch.device("cuda", torch.cuda.current_device())
-        _ffi.check(_ffi.lib().disco_set_progress_event(self._context(dev), C.c_void_p(event.cuda_event), int(after_conv_launches)))
+        handle = C.c_void_p(None if event is None else event.cuda_event)          # None cancels an armed event
+        _ffi.check(_ffi.lib().disco_set_progress_event(self._context(dev), handle, int(after_conv_launches)))
 
     def max_fallback(self):
         """Upper bound of empty-cluster draws one image can consume (clusterkit.py:176-182: K-1 per pass, 20 passes)."""
@@ -373,7 +380,10 @@ class AnchorColorProb(nn.Module):
         init_idx (n,K) k-means rows / hint_pos (n,K) random-hint tokens; fallback_stream: the values successive
         torch.randint(L,(1,)) calls would return (a prefix of the reference's global draw stream), fallback_bases (n,):
         where in that stream image i's empty-cluster draws start.  Returns (6-tuple, events) with events (n,) int32 =
-        draws each image consumed (None when want_events is False: no host synchronisation then).
+        draws each image consumed (None when want_events is False: no host synchronisation then - EXCEPT in the first
+        `range_checks` (3) forwards of a context, each of which reads the clamp counter once (one synchronisation of the current stream)
+        and may re-calibrate and re-run the batch with a warning; set range_checks = 0 before the first forward for a strictly
+        asynchronous start, e.g. on ranks whose inputs are known to lie in the calibrated range).
         out: optional preallocated (pal, ref, pred, affinity, spix, mask) tensors to write into (sampled_T = 0 only; runner.py hands
         slices of the whole batch's outputs to its micro-batches instead of concatenating their results)."""
         test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
@@ -469,12 +479,12 @@ class AnchorColorProb(nn.Module):
             left = self._range_checks_left.get(id(ctx), self.range_checks)
             if left > 0:
                 self._range_checks_left = {id(ctx): left - 1}
-                clamped = self.saturation_count()
+                clamped = self._read_clamp_counter()
                 if clamped:
                     import warnings
                     warnings.warn("%d fp8 activation values were clamped: this input is outside the ranges the context was calibrated on "
                                   "(two synthetic images at load time); re-calibrating on this batch and running it again" % clamped)
-                    self.calibrate(gray[:64])
+                    self.calibrate(gray[:64])       # (the clamped run is discarded: its count is not owed to saturation_count())
                     return self.forward_once(gray, ab, test_mode, sampled_T, init_idx, hint_pos, fallback_stream, fallback_bases, want_events, out)
         if rep > 1:
             aff_out = aff.expand(rep, -1, -1, -1) if n == 1 else aff.repeat_interleave(rep, 0)

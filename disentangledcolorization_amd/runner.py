@@ -26,8 +26,43 @@ import torch
 import torch.distributed as dist
 
 # micro-batch i + 1 starts behind this many MFMA conv launches of micro-batch i (of 69 per forward: SpixelNet 18, ColorProbNet 27,
-# HourGlass2 24); $DISCO_STAGGER_CONVS overrides (0 = off: the micro-batches start together), profiles/r03_stagger.txt
+# HourGlass2 24); $DISCO_STAGGER_CONVS overrides (0 = off: the micro-batches start together), profiles/r03_stagger_sweep.txt
 STAGGER_CONVS = int(os.environ.get("DISCO_STAGGER_CONVS", "26"))
+
+
+class _HostStream:
+    """Stand-ins for torch.cuda.Stream / Event when the tensors live on the host (the gloo tests and bench.py's fake mode): the
+    pipelined issue order, the result bookkeeping and the asynchronous collectives of _forward_pipelined / colorize are the SAME code
+    on either device - only the stream operations are no-ops (host work is complete when the call returns)."""
+
+    def wait_event(self, ev): pass
+    def wait_stream(self, st): pass
+    def synchronize(self): pass
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+class _HostEvent:
+    def record(self, st=None): pass
+    def synchronize(self): pass
+
+
+class _Sx:
+    """Stream operations for tensors on `dev` (HIP streams, or the host stand-ins above)."""
+
+    def __init__(self, dev):
+        self.dev = torch.device(dev)
+        self.cuda = self.dev.type == "cuda"
+
+    def stream(self): return torch.cuda.Stream(device=self.dev) if self.cuda else _HostStream()
+    def event(self): return torch.cuda.Event() if self.cuda else _HostEvent()
+    def current(self): return torch.cuda.current_stream(self.dev) if self.cuda else _HostStream()
+    def on(self, st): return torch.cuda.stream(st) if self.cuda else st
+
+    def keep_for(self, t, st):
+        """`t` was allocated on another stream than `st`, which reads or writes it: no reuse of its block before st is done."""
+        if self.cuda and t is not None:
+            t.record_stream(st)
 
 
 def shard_bounds(n_global, world, rank):
@@ -115,7 +150,7 @@ class ShardedColorizer:
     def _forward_local(self, gray, ab, sampled_T, idx, pos, fstream, fbases, want):
         n = gray.shape[0]
         self._last_stream = None
-        if (self.pipeline and not want and gray.is_cuda and self.out_capable and self.progress_fn is not None and int(sampled_T) == 0
+        if (self.pipeline and not want and self.out_capable and self.progress_fn is not None and int(sampled_T) == 0
                 and self.micro <= 1 and n > 0):
             return self._forward_pipelined(gray, ab, idx, pos, fstream, fbases)
         # a forward that reports its empty-cluster events synchronises the host before it returns, so micro-batches would
@@ -152,7 +187,12 @@ class ShardedColorizer:
                     self.progress_fn(self._stagger_events[i], self.stagger_convs)
                 args = (gray[lo:hi], ab[lo:hi], sampled_T, None if idx is None else idx[lo:hi],
                         None if pos is None else pos[lo:hi], fstream, None if fbases is None else fbases[lo:hi], want)
-                o, e = self.forward_fn(*args, tuple(t[lo:hi] for t in full)) if full is not None else self.forward_fn(*args)
+                try:
+                    o, e = self.forward_fn(*args, tuple(t[lo:hi] for t in full)) if full is not None else self.forward_fn(*args)
+                except BaseException:
+                    if stagger and i + 1 < m:
+                        self.progress_fn(None, 0)          # a forward that never reached the native call must not leave the event armed
+                    raise
                 parts.append(o); evs.append(e)
         for i in range(m):
             main.wait_stream(self._streams[i])
@@ -164,11 +204,12 @@ class ShardedColorizer:
 
     def _forward_pipelined(self, gray, ab, idx, pos, fstream, fbases):
         dev = gray.device
+        sx = _Sx(dev)
         if self._pipe_streams is None:
-            self._pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-            self._pipe_events = [torch.cuda.Event() for _ in range(2)]
+            self._pipe_streams = [sx.stream() for _ in range(2)]
+            self._pipe_events = [sx.event() for _ in range(2)]
             for ev in self._pipe_events:
-                ev.record(torch.cuda.current_stream(dev))      # (torch creates the hipEvent on the first record)
+                ev.record(sx.current())                        # (torch creates the hipEvent on the first record)
         k = self._pipe_count
         self._pipe_count += 1
         st = self._pipe_streams[k & 1]
@@ -176,8 +217,8 @@ class ShardedColorizer:
         # caching allocator, so an unbounded run-ahead would hold one set of result tensors per enqueued batch)
         if self._pipe_done[k & 1] is not None:
             self._pipe_done[k & 1].synchronize()
-        main = torch.cuda.current_stream(dev)
-        ready = torch.cuda.Event()
+        main = sx.current()
+        ready = sx.event()
         ready.record(main)
         st.wait_event(ready)                                   # the inputs were produced on the caller's stream
         if self._pipe_prev is not None and self.stagger_convs > 0:
@@ -189,11 +230,15 @@ class ShardedColorizer:
         full = (torch.empty(n, self._out_channels[0], h, w, **f32), torch.empty(n, self._out_channels[1], h, w, **f32), torch.empty(n, 2, H, W, **f32),
                 torch.empty(n, 9, H, W, **f32), torch.empty(n, 2, h, w, **f32), torch.empty(n, 1, h, w, **f32))
         for t in full:
-            t.record_stream(st)                                # allocated on the caller's stream, written on st: no reuse before st is done
-        with torch.cuda.stream(st):
+            sx.keep_for(t, st)                                 # allocated on the caller's stream, written on st: no reuse before st is done
+        with sx.on(st):
             self.progress_fn(self._pipe_events[k & 1], max(1, self.stagger_convs))
-            self.forward_fn(gray, ab, 0, idx, pos, fstream, fbases, False, full)
-            done = torch.cuda.Event()
+            try:
+                self.forward_fn(gray, ab, 0, idx, pos, fstream, fbases, False, full)
+            except BaseException:
+                self.progress_fn(None, 0)                  # a forward that never reached the native call must not leave the event armed
+                raise
+            done = sx.event()
             done.record(st)
         self._pipe_done[k & 1] = done
         self._pipe_prev = self._pipe_events[k & 1]
@@ -293,10 +338,13 @@ class ShardedColorizer:
         if not gather or (world == 1 and not force):
             return pred, mask
         if self._last_stream is not None:                    # pipelined forward: pack and gather behind it, on its stream
-            with torch.cuda.stream(self._last_stream):
-                res = self._all_gather_packed(pred, mask, n_global, world, rank, rep, async_gather)
-            for t in res:
-                t.record_stream(torch.cuda.current_stream())   # allocated on the side stream, consumed on the caller's (after wait())
+            sx = _Sx(pred.device)
+            sx.current_outer = sx.current()
+            with sx.on(self._last_stream):
+                # every tensor the collective allocates here (send, recv, results) lives in the SIDE stream's pool but is read on the
+                # caller's stream after wait() - the ragged unpack reads `recv` there: none may be recycled before the caller's stream
+                # is done with it (round 3 kept only the two results: advisor finding)
+                res = self._all_gather_packed(pred, mask, n_global, world, rank, rep, async_gather, keep=lambda t: sx.keep_for(t, sx.current_outer))
             return res
         return self._all_gather_packed(pred, mask, n_global, world, rank, rep, async_gather)
 
@@ -308,12 +356,12 @@ class ShardedColorizer:
                 finish()
         self._pending = []
         if self._pipe_busy:
-            main = torch.cuda.current_stream()
             for st in self._pipe_busy:
-                main.wait_stream(st)
+                if not isinstance(st, _HostStream):
+                    torch.cuda.current_stream(st.device).wait_stream(st)
             self._pipe_busy = []
 
-    def _all_gather_packed(self, pred, mask, n_global, world, rank, rep, async_op=False):
+    def _all_gather_packed(self, pred, mask, n_global, world, rank, rep, async_op=False, keep=None):
         """One collective for both results: per output row [pred (2HW) | hint_mask (hw)].  Equal shards (the bench, any batch
         that divides by the world size): the collective gathers straight into the result - pred_colors and hint_mask are
         returned as strided VIEWS of the receive buffer (row stride 2HW + hw), no unpack pass; call .contiguous() where a
@@ -346,6 +394,9 @@ class ShardedColorizer:
                     mask_g[o: o + counts[r]] = blk[:, np_:].reshape((counts[r],) + ms)
                     o += counts[r]
 
+        if keep is not None:
+            for t in (send, recv, pred_g, mask_g):
+                keep(t)
         work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=async_op)
         if async_op:
             self._pending.append((work, finish))

@@ -158,3 +158,26 @@ def synth_inputs(n: int, h: int = 256, w: int = 256, seed: int = 5, ab_scale: fl
     gray = rs.uniform(-1.0, 1.0, (n, 1, h, w)).astype(np.float32)
     ab = (rs.uniform(-1.0, 1.0, (n, 2, h, w)) * ab_scale).astype(np.float32)
     return torch.from_numpy(gray), torch.from_numpy(ab)
+
+
+def student_t_variant(sd, df: float, seed: int = 7, prefixes=("repnet.", "enhanceNet.")):
+    """The checkpoint `sd` with the 3x3 conv weights under `prefixes` redrawn from a Student-t(df) distribution at the SAME per-tensor
+    standard deviation (heavy tails as trained conv weights have them: a few weights per row far above the rest - what a block-scaled
+    low-precision format has to survive; synth_numpy() draws Gaussians, whose row maximum is ~4 sigma).  Spectral-norm layers get the
+    converged u / v of their new weight_orig.  Everything else (biases, BN tables, token path) is kept.  Test data generation."""
+    import torch
+
+    rs = np.random.RandomState(seed)
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    for key, shape, _, kind in state_dict_spec(any(k == "trg_word_emb.weight" and v.shape[1] == 67 for k, v in sd.items())):
+        if kind not in ("conv_w", "sn_w") or not key.startswith(tuple(prefixes)) or key not in out:
+            continue
+        t = rs.standard_t(df, size=shape)
+        a = (t / t.std() * float(sd[key].double().std())).astype(np.float32)
+        out[key] = torch.from_numpy(a)
+        if kind == "sn_w":
+            u, v = _power_iteration(a.reshape(shape[0], -1), rs)
+            base = key[: -len("weight_orig")]
+            out[base + "weight_u"] = torch.from_numpy(u)
+            out[base + "weight_v"] = torch.from_numpy(v)
+    return out

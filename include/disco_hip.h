@@ -22,9 +22,14 @@
  *     pointer-to-new-memory.
  *   - errors: 0 on success, negative DISCO_E* otherwise; never exit()/throw across the ABI.
  *     disco_last_error() gives a thread-local message for the last failing call.
- *   - threading: launchers are asynchronous on the given hipStream_t (passed as void*) and re-entrant across
- *     streams/devices; the only process-global state is one-time per-device setup (function attributes, the
- *     op-level gamut table: std::call_once / mutex).  One context per device.
+ *   - threading: launchers are asynchronous on the given hipStream_t (passed as void*); the GPU work of successive calls on
+ *     different streams overlaps.  A context holds mutable host state (the pinned staging ring of the index arrays, the one-shot
+ *     progress event, profiling records, calibration tables), so its entry points - disco_forward, disco_forward_segnet,
+ *     disco_calibrate, disco_saturation_count and the disco_set_* calls - serialise on a mutex inside the context: several host
+ *     threads may share a context (their host-side issue takes turns, their streams still overlap on the GPU), but
+ *     disco_set_progress_event + the forward it arms are two calls: arm and launch from ONE thread.  The op-level entry points
+ *     (disco_op_*) touch no context.  The only process-global state is one-time per-device setup (function attributes, the op-level
+ *     gamut table: std::call_once / atomics).  One context per device.
  *     No hidden host synchronisation except in disco_forward's k-means fallback bookkeeping
  *     (documented there) and disco_sync.
  *   - host-side randomness (k-means initial rows, empty-cluster fallback rows, random hints) is
@@ -62,7 +67,8 @@ typedef struct disco_ctx disco_ctx;
 #define DISCO_PREC_F16X3 0 /* fp16 hi/lo split operands, 3 MFMA products, fp32 accumulate */
 /* (1 was DISCO_PREC_F16X1, "fp16 hi operands only", a measurement mode of rounds 1-2 that ran on round 1's conv kernel; removed
  *  with that kernel in ABI version 6: disco_create rejects it) */
-#define DISCO_PREC_MX8 2   /* the default: the enhanceNet (HourGlass2, everything downstream of the anchors) computes
+#define DISCO_PREC_MX8 2   /* the default of rounds 2-3a, still available (DISCO_PREC_MX6 is the default now): the enhanceNet (HourGlass2,
+                              everything downstream of the anchors) computes
                               w a ~= w_h a_h + fp8(w - w_h) fp8(a) + fp8(w) fp8(a - a_h): an fp16 main product plus two fp8
                               (e4m3) correction products in one K=64 MFMA (csrc/conv_mx.hip).  Its activations carry an fp16
                               plane and two fp8 planes with one power-of-two scale per tensor, fixed by a calibration forward
@@ -72,7 +78,8 @@ typedef struct disco_ctx disco_ctx;
 #define DISCO_PREC_MX8_ALL 3 /* every conv stack on the fp8-corrected kernel: ~6% faster again, but the ~3e-5 perturbation it
                               leaves at the encoder output flips k-means anchors in ~1% of images (measurements only) */
 #define DISCO_PREC_MX6 5     /* the default since round 3: as DISCO_PREC_MX8 with the two correction products of the HourGlass2 in MX fp6 (OCP e2m3,
-                              one E8M0 block scale per pixel and 32 channels on the activation side: DISCO_PLANE_Q6) instead of fp8: the K = 64
+                              one E8M0 block scale per pixel and 32 channels on the activation side: DISCO_PLANE_Q6 - and, since round 4, one per
+                              output channel, 32-channel block and tap on the weight side, so heavy-tailed rows keep their corrections) instead of fp8: the K = 64
                               MFMA runs fp6 operands in half the passes.  The first HourGlass2 layer still reads fp8 planes (its producers
                               write those) and writes fp6 ones.  Measured: max |ab - reference| 1.2-1.3e-4 (MX8: 1.0-1.1e-4 on the same
                               inputs), anchors identical (they are decided upstream); 2-3 % faster end to end. */
@@ -157,8 +164,10 @@ int disco_saturation_count(disco_ctx *ctx, void *stream, uint64_t *count);
  * when a scale actually moves.  disco_finalize has already calibrated on two synthetic images; call this when
  * disco_saturation_count reports clamping on your data. */
 int disco_calibrate(disco_ctx *ctx, const float *d_gray, int n, int h, int w);
-/* The calibration pass's per-tensor record (diagnostics; the fp16 range guard: disco_finalize fails with
- * DISCO_EUNSUPPORTED when any tensor's max |x| exceeds 16384): producer key, max |x|, chosen scale exponent. */
+/* The calibration pass's per-tensor record (diagnostics): producer key, max |x| over the calibration images, chosen scale exponent
+ * (every plane of the tensor stores x 2^sexp, the maximum landing in [16, 32)).  disco_finalize fails with DISCO_EUNSUPPORTED only
+ * for a tensor that is not finite, or for two tensors that are concatenated on read whose ranges differ by more than 2^10 (they
+ * must share one exponent); a failing disco_calibrate leaves the previous calibration in place. */
 int disco_calibration_count(disco_ctx *ctx);
 int disco_calibration_entry(disco_ctx *ctx, int i, const char **key, float *amax, int *sexp);
 /* SpixelSeg.forward(gray) -> affinity (n,9,h,w), softmax over the 9 neighbour slots (models/network.py:293-313).
@@ -172,7 +181,9 @@ int disco_sync(void *stream);
  * holds hipEvent timings of named stages on the forward's stream. */
 int disco_set_profiling(disco_ctx *ctx, int level); /* 0 off, 1 stages, 2 stages + every MFMA conv launch */
 /* Pipelining hook (ABI 7): the NEXT disco_forward on this context records `hip_event` (a hipEvent_t the caller owns) on its stream right
- * behind its `after_conv_launches`-th MFMA conv launch (at its end if it has fewer); one shot, NULL cancels.  A caller that runs two
+ * behind its `after_conv_launches`-th MFMA conv launch (at its end if it has fewer); one shot, NULL cancels.  "Next forward" is whatever
+ * forward entry point runs next on the context - disco_forward, disco_forward_segnet, disco_calibrate - and however it ends: on an
+ * argument error the event is recorded on the call's stream (if it has one) and the handle dropped, so it can never fire later.  A caller that runs two
  * micro-batches on two streams lets the second wait for this event of the first: the two forwards then run half a network apart, and the
  * latency-bound token path / k-means of either (a handful of CUs busy) executes under the other's convolutions instead of both idling
  * the GPU at the same time (runner.py; the reference has no counterpart: it runs one batch on one stream). */

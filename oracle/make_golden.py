@@ -27,7 +27,7 @@ def npy(t):
 
 
 def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed=5, full=True, sub=1,
-             feat_stride=8, aff_stride=4, test_mode=True, hint2regress=False, spix_pos=False):
+             feat_stride=8, aff_stride=4, test_mode=True, hint2regress=False, spix_pos=False, inputs=None, extra=None):
     ref_harness.install()
     import clusterkit  # reference module
 
@@ -35,7 +35,7 @@ def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed
         sd = synth.synth_state_dict(SEED, hint2regress=True)
     m = ref_harness.build_reference_model(sd, n_clusters=k, random_hint=random_hint, hint2regress=hint2regress,
                                           spix_pos=spix_pos)
-    gray, ab = synth.synth_inputs(n, h, w, seed=input_seed, ab_scale=0.5)
+    gray, ab = inputs if inputs is not None else synth.synth_inputs(n, h, w, seed=input_seed, ab_scale=0.5)
     cap = {}
     orig_km = clusterkit.batch_kmeans_pytorch
 
@@ -79,6 +79,7 @@ def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed
     else:
         d.update(pal_logit=npy(pal)[:, ::sub], ref_logit=npy(ref)[:, ::sub],
                  pred_colors=npy(pred)[:, :, ::sub, ::sub])
+    d.update(extra or {})
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
     print(name, {kk: getattr(v, "shape", None) for kk, v in d.items()},
           "pred range", float(pred.min()), float(pred.max()))
@@ -200,11 +201,38 @@ def posthoc():
     print("posthoc", {k: v.shape for k, v in d.items()})
 
 
+def photo_case(sd):
+    """Natural-image inputs (round 4): every other fixture feeds uniform noise.  Two of the photographs the reference ships
+    (data/*.jpg, what main/colorizer/inference.py:93-101 colorizes) are decoded here with PIL, brought to 256 x 256 by the oracle's
+    restatement of cv2.resize(INTER_LINEAR) (inference.py:33; cv2 itself is absent offline) and stored as uint8 ARRAYS together with
+    what the real reference model makes of them (inference.py:35-41: /255 -> Lab -> (L-50)/50, ab/110; rgb2lab: the reference's own
+    torch implementation, models/basic.py:395-433, standing in for cv2's float COLOR_RGB2LAB).  Data only: pixels in, tensors out."""
+    from PIL import Image
+    from oracle import disco_ref as R
+
+    names = ["000000001584.jpg", "000000025394.jpg"]
+    rgb8 = []
+    for nm in names:
+        img = np.asarray(Image.open(os.path.join(ref_harness.REF_ROOT, "data", nm)).convert("RGB"))
+        rgb8.append(R.cv2_resize_linear_u8(img, 256, 256))
+    rgb8 = np.stack(rgb8)
+    gs, abs_ = [], []
+    for im in rgb8:
+        g_, ab_, _, _ = R.fetch_from_rgb8(im, org_size=True)
+        gs.append(g_); abs_.append(ab_)
+    gray, ab = torch.cat(gs), torch.cat(abs_)
+    run_case("fwd_photo_256_k8", sd, n=2, h=256, w=256, k=8, input_seed=-1, inputs=(gray, ab),
+             extra=dict(rgb8=rgb8, gray=npy(gray), ab_sub=npy(ab)[:, :, ::4, ::4]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--posthoc-only" in sys.argv:
         return posthoc()
     sd = synth.synth_state_dict(SEED)
+    if "--photo-only" in sys.argv:
+        return photo_case(sd)
+    photo_case(sd)
     # the forward variants beyond inference.py's default flags (SURVEY §8f-3): the validation forward
     # (train_colorizer.py:206), --hint2regress, --spix_pos (inference.py:156,158)
     run_case("fwd_val_128_k8", sd, n=2, h=128, w=128, k=8, input_seed=11, test_mode=False)

@@ -124,6 +124,65 @@ def test_multi_rank_gloo_equals_reference_semantics(n_global, world, random_hint
         assert consumed == want_events
 
 
+def _fake_forward_out(gray, ab, T, idx, pos, fstream, fbases, want, out=None):
+    """_fake_forward with AnchorColorProb.forward_once's out= contract (the pipelined path hands preallocated result tensors in)."""
+    o, ev = _fake_forward(gray, ab, T, idx, pos, fstream, fbases, want)
+    if out is not None:
+        out[2].copy_(o[2]); out[5].copy_(o[5])
+        return out, ev
+    return o, ev
+
+
+def _pipelined_worker(rank, world, port, n_global, q):
+    """bench.py's timed configuration: pipeline = True (successive colorize() calls alternate between two streams - host stand-ins on
+    CPU tensors, the same code otherwise), results written into preallocated tensors, async_gather = True."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gray, ab = _inputs(n_global)
+    lo, hi = shard_bounds(n_global, world, rank)
+    sc = ShardedColorizer(_fake_forward_out, n_clusters=4, max_fallback=16, exact_fallback=False)
+    sc.out_capable, sc.progress_fn, sc.pipeline, sc.stagger_convs = True, (lambda ev, k: None), True, 26
+    entered = []
+    orig = sc._forward_pipelined
+    sc._forward_pipelined = lambda *a: (entered.append(1), orig(*a))[1]
+    results = []
+    for step in range(5):
+        _seed()
+        r = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, 0, gather=True, async_gather=True)
+        if step != 2:              # step 2's result is DROPPED before wait(): its buffers must outlive the collective all the same
+            results.append(r)
+        del r
+    assert len(sc._pending) == 5
+    sc.wait()
+    assert not sc._pending and not sc._pipe_busy
+    assert len(entered) == (5 if hi > lo else 0), "the pipelined path must be the one that ran"
+    q.put((rank, [(p.contiguous().numpy(), m.contiguous().numpy()) for p, m in results]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global,world", [(6, 2), (5, 2), (2, 3)])
+def test_pipelined_async_gather_on_gloo(n_global, world):
+    """The configuration `bench.py --gpus N` times - pipeline = True with the packed all-gather only ENQUEUED behind each forward - had
+    never run with more than one rank (round 3: it required CUDA tensors).  World 2 with equal and ragged shards, world 3 with an
+    empty shard: five batches in flight, one result dropped before wait(); every kept result equals the single-process one."""
+    gray, ab = _inputs(n_global)
+    _seed()
+    sc = ShardedColorizer(_fake_forward, 4, False, max_fallback=16, exact_fallback=False)
+    want_pred, want_mask = sc.colorize(gray, ab, n_global, 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27500 + (os.getpid() * 5 + n_global * 17 + world) % 2000
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, n_global, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs: p.join(timeout=60)
+    for rank, results in got:
+        assert len(results) == 4
+        for pred, mask in results:
+            assert np.array_equal(pred, want_pred.numpy()) and np.array_equal(mask, want_mask.numpy()), rank
+
+
 def test_ranks_with_different_seeds_are_detected():
     """The exchange carries a checksum of the draws: a rank that seeded differently must fail loudly, not diverge."""
     code = r'''
@@ -168,6 +227,8 @@ def test_bench_distributed_scaffolding_on_gloo():
         assert all(not [l for l in o[0].splitlines() if l.startswith("{")] for o in outs[1:]), "only rank 0 prints"
         lines[world] = json.loads(line[0])
     assert lines[1]["n_gpus"] == 1 and lines[2]["n_gpus"] == 2
+    assert lines[2]["world_size_seen_by_backend"] == 2
+    assert "pipelined" in lines[2]["config"]["issue"]         # the default timed loop: pipeline = 1 + async gather, in fake mode too
     assert lines[1]["result_checksum"] == lines[2]["result_checksum"]
     assert lines[2]["config"]["global_batch"] == 6 and lines[2]["value"] > 0
 

@@ -296,6 +296,63 @@ def test_conv3x3_mx6_matches_torch(H, case):
         assert torch.equal(again.buf, first)
 
 
+def test_conv3x3_mx6_heavy_tailed_rows_block_scaled_weights(H):
+    """Round 4: the fp6 WEIGHT operands carry one E8M0 scale per (output channel, 32-input-channel block, tap) - byte 24 of the weight
+    slot, taken by the MFMA as its weight-side scale operand - where round 3 scaled a whole row of 9 Cin weights with one exponent: a
+    row with a single 30x outlier then pushed every other weight of the row below fp6's subnormal step and lost their w a_lo / w_lo a
+    corrections (the error of a plain fp16 product: ~2^-11 of the accumulated mass).  Same tolerance as the Gaussian cases."""
+    gen = g(77)
+    n, cin, cout, h, w = 2, 128, 64, 24, 24
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    for co in range(cout):                               # one 30 sigma weight per row, in a different block / tap each
+        wt[co, (7 * co) % cin, co % 3, (co // 3) % 3] = 30.0 * math.sqrt(2.0 / (9 * cin)) * (1 if co & 1 else -1)
+    b = torch.randn(cout, generator=gen) * 0.1
+    want = _ref(x, wt, b, 1, _ffi.ACT_NONE, 0.0, None, None)
+    scale = max(1.0, want.abs().max().item())
+    out32, _ = H.conv3x3_mx(H.to_act_mx(x, Q6), wt, b, out_f32=True, q6=True)
+    # the part of the output the outliers do not touch must be as accurate as with Gaussian rows
+    err = H.max_err(out32, want)
+    print("mx6 heavy-tailed rows: max err %.3e of range %.2f (plain fp16 operands would leave ~%.1e)" % (err, scale, 2 ** -11 * scale))
+    assert err < TOL6 * scale
+    t = torch.distributions.StudentT(3.0).sample((cout, cin, 3, 3)) * math.sqrt(2.0 / (9 * cin)) / math.sqrt(3.0)
+    want = _ref(x, t, b, 1, _ffi.ACT_NONE, 0.0, None, None)
+    out32, _ = H.conv3x3_mx(H.to_act_mx(x, Q6), t, b, out_f32=True, q6=True)
+    assert H.max_err(out32, want) < TOL6 * max(1.0, want.abs().max().item())
+
+
+def test_mx6_weight_slots_carry_block_scales(H):
+    """The packed image itself: per (32-cout block, chunk, tap) 2 KiB = 64 lanes x 32 bytes in two 1 KiB pieces; a lane's 32 bytes are
+    the slot of row (lane & 31): wl6 (lane < 32) / w6 (lane >= 32), 32 six-bit fields in bytes 0-23 (field f = channel
+    mx6_field_channel(f)), E8M0 in byte 24.  Dequantised, w6 must be w to 3 mantissa bits relative to ITS block's maximum."""
+    gen = g(5)
+    cout, cin = 32, 64
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * 0.05
+    wt[:, :32] *= 2.0 ** -7                               # block 0 of every row at 1/128 of block 1: a row scale would zero it
+    buf, _ = H.pack_conv_mx(wt, 2)
+    raw = buf.cpu().numpy()
+    nck = cin // 16
+    def field_channel(f): return 8 * ((f & 15) >> 2) + 4 * (f >> 4) + (f & 3)
+    def fp6(c):
+        e, m = (c >> 3) & 3, c & 7
+        v = m * 0.125 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 1)
+        return -v if c & 32 else v
+    worst = 0.0
+    for g32 in range(cin // 32):
+        for tap in range(9):
+            base = ((0 * nck + 2 * g32 + 1) * 9 + tap) * 2048
+            for lane in (32, 33, 47, 63):                 # w6 slots of rows 0, 1, 15, 31
+                slot = bytes(raw[base + lane * 16: base + lane * 16 + 16]) + bytes(raw[base + 1024 + lane * 16: base + 1024 + lane * 16 + 16])
+                sc = slot[24]
+                bits = int.from_bytes(slot[:24], "little")
+                row = lane & 31
+                blk = wt[row, g32 * 32:(g32 + 1) * 32, tap // 3, tap % 3]
+                for f in range(32):
+                    got = fp6((bits >> (6 * f)) & 63) * 2.0 ** (sc - 127 + 11)      # the w6 side carries 2^-11 for the al6 planes' 2^11
+                    worst = max(worst, abs(got - blk[field_channel(f)].item()) / blk.abs().max().item())
+    assert worst <= 2 ** -3.9, worst
+
+
 def test_conv3x3_mx6_two_source_fp8_in_fp6_out_and_depth_to_space(H):
     """The two joints of the fp6 HourGlass2: its first layer is a two-source f16+fp8x2 layer (fp8 planes from the upfeat / gray kernels)
     that WRITES fp6 planes; its up-convs are masked 4-phase convs with the depth-to-space epilogue."""

@@ -167,7 +167,12 @@ def _run(golden_dir, synth_sd, q_to_ab, name):
     g = _load(golden_dir, name)
     n, h, w, k, T, rh, iseed, seed = (int(v) for v in g["recipe"])
     test_mode, h2r, spos = (bool(v) for v in g["flags"]) if "flags" in g.files else (True, False, False)
-    gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
+    if "rgb8" in g.files:          # natural-image fixture: the inputs are the stored uint8 pixels through the reference's input path
+        parts = [R.fetch_from_rgb8(im, org_size=True) for im in g["rgb8"]]
+        gray, ab = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+        assert torch.equal(gray, torch.from_numpy(g["gray"])) and torch.equal(ab[:, :, ::4, ::4], torch.from_numpy(g["ab_sub"]))
+    else:
+        gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
     sd = synth.synth_state_dict(seed, hint2regress=True) if h2r else synth_sd
     oracle = R.DiscoOracle(sd, q_to_ab, n_clusters=k, random_hint=bool(rh), hint2regress=h2r, spix_pos=spos)
     np.random.seed(seed); torch.manual_seed(seed); random.seed(seed)
@@ -201,7 +206,9 @@ def _check_forward(g, out, info):
                                   "fwd_randhint_128_k16", "fwd_gt_128_k8", "fwd_n1_512x768_k8",
                                   # validation forward (test_mode=False), --hint2regress, --spix_pos and their mix
                                   "fwd_val_128_k8", "fwd_h2r_128_k8", "fwd_spixpos_128x192_k8",
-                                  "fwd_spixpos_h2r_diverse_128_k16"])
+                                  "fwd_spixpos_h2r_diverse_128_k16",
+                                  # two of the photographs the reference ships (data/*.jpg), 256 x 256 (round 4)
+                                  "fwd_photo_256_k8"])
 def test_forward_matches_reference(golden_dir, synth_sd, q_to_ab, name):
     g, out, info = _run(golden_dir, synth_sd, q_to_ab, name)
     _check_forward(g, out, info)

@@ -39,7 +39,45 @@ def scan(src):
     return src, total, hits
 
 
+def audit_built(lib_path=None):
+    """The same scan on the BUILT library (what ships): its gfx950 code objects are extracted with `llvm-objdump --offloading` into a
+    scratch directory and disassembled - seconds, so __graft_entry__.build() runs it after every build.  Returns (instructions, unsafe)."""
+    import glob
+    import shutil
+    import tempfile
+    objdump = os.path.join(os.path.dirname(os.path.dirname(B.HIPCC)), "lib", "llvm", "bin", "llvm-objdump")
+    d = tempfile.mkdtemp(prefix="disco_audit_")
+    try:
+        tmp = os.path.join(d, "lib.so")
+        shutil.copy(lib_path or B.LIB, tmp)
+        subprocess.run([objdump, "--offloading", tmp], check=True, capture_output=True)
+        objs = glob.glob(tmp + ".*gfx950")
+        if not objs:
+            raise RuntimeError("no gfx950 code object found in %s" % (lib_path or B.LIB))
+        total, hits = 0, []
+        for co in objs:
+            r = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True)
+            kernel = None
+            for line in r.stdout.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+                if m:
+                    kernel = m.group(1)
+                if re.search(r"v_pk_(fma_f32|mul_f32|add_f32|mov_b32)\b", line):
+                    total += 1
+                    if PAT.search(line):
+                        hits.append((kernel, line.split("//")[0].strip()))
+        return total, hits
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
+    if "--built" in sys.argv:
+        total, hits = audit_built()
+        print("%s: %d packed fp32 instructions, %d with op_sel" % (os.path.basename(B.LIB), total, len(hits)))
+        for k, l in hits[:10]:
+            print("    %s: %s" % ((k or "?")[:60], l))
+        return 1 if hits else 0
     srcs = [s for s in B.SOURCES if s.endswith(".hip")]
     with ThreadPoolExecutor(8) as ex:
         res = list(ex.map(scan, srcs))

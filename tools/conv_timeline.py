@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Where does a tile's time go?  s_memtime stamps of workgroup (0, 0) of the f16+fp6x2 conv kernel (GPU box only).
+
+    # build container:  hipcc ... -DMX_TIMELINE=1 -c csrc/conv_mx_ar3.hip -o tools/build/conv_mx_ar3_tl.o ; link -> tools/build/libdisco_tl.so
+    DISCO_HIP_LIB=tools/build/libdisco_tl.so python tools/conv_timeline.py > gpurun_out/r04_conv_timeline.txt
+
+The diagnostic build stamps, for the first and the last wave of that workgroup: tile start, per chunk (DMA landed, barrier passed,
+taps done), epilogue math done, epilogue wait done, stores issued.  Printed per layer shape: cycles per phase averaged over the
+tiles the persistent workgroup walks, next to the MFMA-pipe time the tile needs (2 waves per SIMD x their MFMAs x 32 cycles).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gpu_helpers as H  # noqa: E402
+from disentangledcolorization_amd import _ffi  # noqa: E402
+
+SHAPES = [  # name, cin0, cin1, cout, h_in, stride, up0
+    ("256->256 @64", 256, 0, 256, 64, 1, 0),
+    ("128->128 @128", 128, 0, 128, 128, 1, 0),
+    ("64->64 @256", 64, 0, 64, 256, 1, 0),
+    ("cat 64+64->64 @256", 64, 64, 64, 256, 1, 1),
+]
+EVENTS = 8192
+
+
+def run_shape(L, name, c0, c1, co, hin, stride, up0, n=64):
+    hs = hin // 2 if up0 else hin
+    planes = _ffi.PLANE_Q6
+    x0 = H.to_act_mx(torch.relu(torch.randn(n, c0, hs, hs, device="cuda")), planes=planes, sexp=2)
+    x1 = H.to_act_mx(torch.relu(torch.randn(n, c1, hin, hin, device="cuda")), planes=planes, sexp=2) if c1 else None
+    w = torch.randn(co, c0 + c1, 3, 3) * 0.05
+    packed, wexp = H.pack_conv_mx(w, 2)
+    ho = (hin - 1) // stride + 1
+    out = H.MxAct(n, co, ho, ho, planes, 0)
+    bias = torch.zeros(co, device="cuda")
+    d = _ffi.ConvMxDesc(n, hin, hin, c0, c1, up0, 0, x0.sexp, x1.sexp if x1 else 0, co, stride, _ffi.ACT_RELU, 0.0, planes, 0, 0, 0, 0, 0, 1, 0)
+
+    def run():
+        _ffi.check(L.disco_op_conv3x3_mx(C.byref(d), _ffi.ptr(x0.buf), _ffi.ptr(x1.buf) if x1 else None, _ffi.ptr(packed), _ffi.ptr(wexp),
+                                        _ffi.ptr(bias), None, None, None, _ffi.ptr(out.buf), None, None, H.stream()))
+    for _ in range(20):                      # warm: clocks at their sustained level
+        run()
+    torch.cuda.synchronize()
+    buf = np.zeros((2, EVENTS), np.uint64)
+    assert L.disco_diag_conv_timeline(None, 1) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(); e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    assert L.disco_diag_conv_timeline(buf.ctypes.data_as(C.c_void_p), 0) == 0
+    fl = 2.0 * 9 * (c0 + c1) * co * ho * ho * n
+    nch = (c0 + c1) // 16
+    print("==== %s: %.3f ms (instrumented), %.0f TF alg; %d chunks per tile; MFMA pipe time per tile and SIMD: %d cycles (H chunk 4608, Q chunk 2304)"
+          % (name, ms, fl / ms / 1e9, nch, nch // 2 * 6912))
+    for w in range(2):
+        cnt = int(buf[w, 0])
+        ev = [(int(v) >> 4, int(v) & 15) for v in buf[w, 1:min(cnt, EVENTS)]]
+        tiles = []
+        cur = None
+        for t, tag in ev:
+            if tag == 1:
+                cur = {"start": t, "wait": 0, "barrier": 0, "tapsH": 0, "tapsQ": 0, "nH": 0, "nQ": 0, "last": t, "kind": None}
+                tiles.append(cur)
+                continue
+            if cur is None:
+                continue
+            dt = t - cur["last"]
+            if tag == 2:      # chunk start: time since the previous mark = taps of the previous chunk (or prologue)
+                if cur["kind"] == 4: cur["tapsH"] += dt; cur["nH"] += 1
+                elif cur["kind"] == 5: cur["tapsQ"] += dt; cur["nQ"] += 1
+                else: cur["pro"] = dt
+            elif tag == 10:   # (pipelined loop) taps 0-7 issued; the wait + barrier inside the last tap begins
+                if cur["kind"] == 4: cur["tapsH"] += dt
+                elif cur["kind"] == 5: cur["tapsQ"] += dt
+            elif tag == 11: cur["barrier"] += dt
+            elif tag == 3: cur["wait"] += dt
+            elif tag in (4, 5): cur["barrier"] += dt; cur["kind"] = tag
+            elif tag == 6:
+                if cur["kind"] == 4: cur["tapsH"] += dt; cur["nH"] += 1
+                elif cur["kind"] == 5: cur["tapsQ"] += dt; cur["nQ"] += 1
+            elif tag == 7: cur["epi_math"] = dt
+            elif tag == 8: cur["epi_wait"] = dt
+            elif tag == 9: cur["epi_store"] = dt; cur["total"] = t - cur["start"]
+            cur["last"] = t
+        done = [t for t in tiles if "total" in t]
+        if not done:
+            print("  wave %s: no complete tile recorded (%d events)" % ("first" if w == 0 else "last", cnt)); continue
+        body = done[1:] if len(done) > 2 else done        # the first tile carries the prologue
+        avg = lambda k: sum(t.get(k, 0) for t in body) / len(body)
+        tot = avg("total")
+        print("  wave %-5s %2d tiles | tile %7.0f cyc | taps H %7.0f (%5.0f per chunk)  taps Q %7.0f (%5.0f per chunk) | dma wait %6.0f  barrier %6.0f | epilogue: math %6.0f  wait %6.0f  stores %6.0f"
+              % ("first" if w == 0 else "last", len(done), tot, avg("tapsH"), avg("tapsH") / max(avg("nH"), 1), avg("tapsQ"), avg("tapsQ") / max(avg("nQ"), 1),
+                 avg("wait"), avg("barrier"), avg("epi_math"), avg("epi_wait"), avg("epi_store")))
+        print("             share of the tile: taps %4.1f %%  dma wait %4.1f %%  barrier %4.1f %%  epilogue %4.1f %%   (MFMA pipe need: %4.1f %%)"
+              % (100 * (avg("tapsH") + avg("tapsQ")) / tot, 100 * avg("wait") / tot, 100 * avg("barrier") / tot,
+                 100 * (avg("epi_math") + avg("epi_wait") + avg("epi_store")) / tot, 100 * (nch // 2 * 6912) / tot))
+
+
+def main():
+    L = _ffi.lib()
+    if not hasattr(L, "disco_diag_conv_timeline"):
+        raise SystemExit("this library has no timeline probe: build with -DMX_TIMELINE=1 and point DISCO_HIP_LIB at it")
+    L.disco_diag_conv_timeline.restype = C.c_int
+    L.disco_diag_conv_timeline.argtypes = [C.c_void_p, C.c_int]
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    for s in SHAPES:
+        if only in s[0]:
+            run_shape(L, *s)
+
+
+if __name__ == "__main__":
+    main()

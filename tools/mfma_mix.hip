@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <sys/time.h>
+#include <unistd.h>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -141,6 +143,35 @@ static void run(const char* name, const f16x8* d_ops, const i32x8* d_ops8, float
     }
 }
 
+// --sustain S: each mix for S seconds of back-to-back launches on random operands, with wall-clock stamps for tools/power_per_kernel.py
+// (which samples the socket power meanwhile): "SEG name t0 t1 pipe-units-G/s executed-TFLOP/s clk-GHz"
+static double now_s() { timeval tv; gettimeofday(&tv, nullptr); return tv.tv_sec + tv.tv_usec * 1e-6; }
+template <int MIX, int WPS>
+static void sustain(const char* name, const f16x8* d_ops, const i32x8* d_ops8, float* d_out, unsigned long long* d_clk, int cus, int iters, double seconds) {
+    const int blocks = cus * 4;
+    const double mf16 = MIX == 0 || MIX == 1 ? 12 : (MIX == 6 || MIX == 7 ? 48 : (MIX == 3 || MIX >= 10 ? 0 : (MIX == 5 ? 32 : 16))), m8 = MIX == 2 || MIX == 8 || MIX == 9 ? 8 : (MIX == 3 || MIX >= 10 ? 8 : (MIX == 4 || MIX == 5 ? 4 : 0));
+    // fp6 / fp4 K = 64 instructions take half the passes of fp8 (1 unit instead of 2)
+    const double u8 = (MIX >= 8) ? 1.0 : 2.0;
+    hipDeviceSynchronize();
+    usleep(1500000);                  // idle gap between segments (the power reading settles)
+    const double t0 = now_s();
+    long launches = 0;
+    double clk_sum = 0;
+    while (now_s() - t0 < seconds) {
+        for (int k = 0; k < 4; ++k) hipLaunchKernelGGL((loop_kernel<MIX, WPS>), dim3(blocks), dim3(WPS * 256), 0, 0, d_ops, d_ops8, d_out, d_clk, iters);
+        hipDeviceSynchronize();
+        unsigned long long clk[2]; hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost);
+        clk_sum += clk[1] ? (double)clk[0] / clk[1] * 0.1 : 0.0;
+        launches += 4;
+    }
+    const double t1 = now_s();
+    const double waves = (double)blocks * WPS * 4;
+    const double flop = waves * iters * launches * (mf16 * 2.0 * 32 * 32 * 16 + m8 * 2.0 * 32 * 32 * 64);
+    const double units = waves * iters * launches * (mf16 + u8 * m8);
+    printf("SEG %s|%.4f|%.4f|%.1f|%.1f|%.3f\n", name, t0, t1, units / (t1 - t0) * 1e-9, flop / (t1 - t0) * 1e-12, clk_sum / (launches / 4));
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     int cus = 0; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     // ---------------- layout check ----------------
@@ -178,6 +209,24 @@ int main(int argc, char** argv) {
     std::vector<unsigned char> h8(4 * 64 * 32);
     f16x8* d_ops; i32x8* d_ops8; float* d_out; unsigned long long* d_clk;
     hipMalloc(&d_ops, h.size() * 2); hipMalloc(&d_ops8, h8.size()); hipMalloc(&d_out, 4); hipMalloc(&d_clk, 16);
+    if (argc > 2 && !strcmp(argv[1], "--sustain")) {
+        const double secs = atof(argv[2]);
+        for (size_t i = 0; i < h.size(); ++i) { float v = gauss(); if (i >= 8 * 64 * 8) v *= 4.8e-4f; h[i] = (_Float16)v; }
+        for (auto& v : h8) { v = rand() & 0xff; if ((v & 0x7f) == 0x7f) v &= 0xfe; }
+        hipMemcpy(d_ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(d_ops8, h8.data(), h8.size(), hipMemcpyHostToDevice);
+        sustain<8, 2>("mix: 4 f16 + 2 fp6-K64 (f16+fp6x2), 2 waves/SIMD", d_ops, d_ops8, d_out, d_clk, cus, 4000, secs);
+        sustain<8, 1>("mix: 4 f16 + 2 fp6-K64 (f16+fp6x2), 1 wave/SIMD", d_ops, d_ops8, d_out, d_clk, cus, 4000, secs);
+        sustain<2, 2>("mix: 4 f16 + 2 fp8-K64 (f16+fp8x2), 2 waves/SIMD", d_ops, d_ops8, d_out, d_clk, cus, 4000, secs);
+        sustain<6, 2>("mix: f16x3 chained, 2 waves/SIMD", d_ops, d_ops8, d_out, d_clk, cus, 1500, secs);
+        sustain<7, 2>("mix: plain f16 chained, 2 waves/SIMD", d_ops, d_ops8, d_out, d_clk, cus, 1500, secs);
+        sustain<10, 2>("mix: fp6-K64 only, 2 waves/SIMD", d_ops, d_ops8, d_out, d_clk, cus, 8000, secs);
+        // the same mixes on zeros: what the issue structure alone sustains
+        hipMemset((void*)d_ops, 0, h.size() * 2); hipMemset((void*)d_ops8, 0, h8.size());
+        sustain<8, 2>("mix: 4 f16 + 2 fp6-K64, ZERO operands", d_ops, d_ops8, d_out, d_clk, cus, 4000, secs);
+        sustain<6, 2>("mix: f16x3 chained, ZERO operands", d_ops, d_ops8, d_out, d_clk, cus, 1500, secs);
+        return 0;
+    }
     const int long_iters = argc > 1 ? atoi(argv[1]) : 20000;
     const int ndata = argc > 2 ? atoi(argv[2]) : 2;      // > 2: also the toggle-rate experiments (lo operands with their low mantissa bits cleared)
     for (int data = 0; data < ndata; ++data) {

@@ -29,6 +29,8 @@ def seed(s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--modes", default="mx6,mx8,x2q,f16x3")
+    ap.add_argument("--weights", default="", help="e.g. t4,t3: Student-t redraws of the 3x3 conv weights instead of the usual cases; run once more with "
+                    "DISCO_MX6_ROW_SCALE=1 in the environment for round 3's one-exponent-per-row fp6 weight scaling")
     ap.add_argument("--quick", action="store_true", help="three inputs on the synthetic checkpoint and one stress checkpoint")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
@@ -40,6 +42,15 @@ def main():
               ("repnet_x256", "repnet_x1_256", "sn_sigma_16", "enhance_skip_x256")]
     if args.quick:
         cases = cases[:2] + cases[4:5] + cases[-1:]
+    if args.weights:
+        # heavy-tailed checkpoints (synth.student_t_variant): HourGlass2 alone (what the fp6 weight operands see) and with ColorProbNet
+        cases = []
+        for tag in args.weights.split(","):
+            df = float(tag[1:])
+            for wseed in (7, 8):
+                cases.append(("%s enhanceNet w%d" % (tag, wseed), synth.student_t_variant(base, df, wseed, ("enhanceNet.",)), 19, 2, 128, 128))
+            cases.append(("%s repnet+enhanceNet" % tag, synth.student_t_variant(base, df, 7), 19, 2, 128, 128))
+        cases.append(("gaussian (synth 130)", base, 19, 2, 128, 128))
     worst = {}
     models = {}
 
@@ -54,7 +65,7 @@ def main():
     for name, sd, s, n, h, w in cases:
         gray, ab = synth.synth_inputs(n, h, w, seed=s)
         seed(130); want = R.DiscoOracle(sd, q, n_clusters=8).forward(gray, ab)
-        line = f"{name:22s}"
+        line = f"{name:24s} (|ab_ref| max {want[2].abs().max().item():.2f} std {want[2].std().item():.2f})"
         for mode in args.modes.split(","):
             m = model(mode, sd)
             seed(130); out = m(gray.cuda(), ab.cuda(), True, 0)
