@@ -56,8 +56,8 @@
 #define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk
 #endif
 
-#ifndef MX_PIPE
-#define MX_PIPE 1       // 1: fragment reads software-pipelined one tap ahead of the MFMAs, the chunk barrier inside the last tap (round 4); 0: round 3's loop
+#ifndef MX_EPI_INLINE
+#define MX_EPI_INLINE 1 // 1: an output block's stores are issued right behind its epilogue math (round 4); 0: all math, then all stores (round 3)
 #endif
 #ifndef MX_TIMELINE
 #define MX_TIMELINE 0   // diagnostic builds (tools/conv_timeline.py): workgroup (0, 0) stamps s_memtime at every phase boundary of waves 0 and NWAVE-1
@@ -172,10 +172,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     constexpr int BUF_BYTES = A_BYTES + W_PIECES * 1024;
     constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;
     constexpr int WPW = (W_PIECES + NWAVE - 1) / NWAVE;
-    // the next chunk's DMA is issued in parts between the taps: over all 9 (round 3), or over the first 7 so that everything has two taps
-    // of time to land before the barrier inside the last one (MX_PIPE)
-    constexpr int NPART = MX_PIPE ? 7 : 9;
-    constexpr int APT = (APW + NPART - 1) / NPART, WPT = (WPW + NPART - 1) / NPART;
+    constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;
     constexpr int PAR_OFF = 2 * BUF_BYTES;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -360,145 +357,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     // KIND 2 (X3): the f16x3 arithmetic of conv_mfma2.hip on this skeleton - planes = hi / lo of 16 channels, weight tile = w_hi / w_lo
     //              fragments (conv3x3_pack_host's image), three K = 16 MFMAs per tap in conv_mfma2's order (w_lo a_hi, w_hi a_lo,
     //              w_hi a_hi), so results are bit-identical to that kernel's
-#if MX_PIPE
-    // ---- round 4: the same taps in the same order (results bit-identical), issued differently ---------------------------------------
-    // Round 3's loop read a tap's fragments and then issued its MFMAs: the inline-asm pin behind every tap is a scheduling boundary, so
-    // the compiler never hoisted tap t + 1's ds_reads above tap t's MFMAs, and a wave sat out the full LDS latency once per tap with
-    // only its SIMD partner to cover it - 8 MFMAs (256 cycles) of cover in an H chunk, 4 (128 cycles) in a Q chunk, where the pipe
-    // idled 40 % of the time (profiles/r04_conv_timeline.txt) - and after every chunk barrier BOTH waves of a SIMD waited for their
-    // first fragments with the pipe empty.  Now (1) the fragments of tap t + 1 are read BEFORE the MFMAs of tap t are issued (two
-    // fragment sets in registers), and (2) the chunk barrier moved from the top of a chunk into the last tap of its predecessor:
-    //     ... tap 7: read frags(8) | MFMAs(7) ... tap 8: wait for own DMA pieces of chunk k+1 and own reads of chunk k, s_barrier,
-    //     read frags(chunk k+1, tap 0) | MFMAs(8) ... chunk k+1 tap 0: read frags(1) | MFMAs(0) ...
-    // so the barrier skew and the first read latency of a chunk run under the last tap's MFMAs.  The buffer protocol is unchanged: the
-    // barrier still separates every wave's last read of chunk k's buffer from the first DMA write into it (chunk k+2's, issued from
-    // chunk k+1's tap 0 on), and every wave's DMA of chunk k+1 from the first read of it.  Only a tile's first chunk waits at its top.
-    struct Frag { i32x4 a[MT][2]; i32x4 b[NTW][2]; };
-    constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
-    constexpr bool ROWREUSE = COLMAJOR && MT == 2;
-    auto slot_live = [&](int slot) -> bool {
-        const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
-        return !MASKED || ((tmask >> (ky * 3 + kx)) & 1u);
-    };
-    // fragments of tap slot `slot` of a KIND chunk in the LDS buffer at byte offset bufoff; prev: the previous slot's (row reuse)
-    auto load_frags = [&](auto kind_tag, int bufoff, int wo, int slot, Frag& f, const Frag& prev) __attribute__((always_inline)) {
-        constexpr int KIND = decltype(kind_tag)::value;
-        constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
-        const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
-        const int tap = ky * 3 + kx;
-        const int c0 = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
-        const int c1 = ISQ ? (c0 ^ 16) : c0 + PLANE_B;           // all other address terms are multiples of 32
-        const char* sW = smem + bufoff + A_BYTES;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (ROWREUSE && ky > 0 && mt == 0) { f.a[0][0] = prev.a[1][0]; f.a[0][1] = prev.a[1][1]; continue; }
-            constexpr int RB = G::PITCH * 32;                           // bytes per tile row
-            const int rowc = (mt * G::ROWS_PER_MB * STRIDE + ky) * RB;   // compile-time constant after unrolling: the ds_read's immediate offset
-            f.a[mt][0] = *reinterpret_cast<const i32x4*>(smem + c0 + rowc);
-            if (!TAIL) f.a[mt][1] = *reinterpret_cast<const i32x4*>(smem + c1 + rowc);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int off = wo + nt * W_NB + tap * 2 * WBLK;
-            f.b[nt][0] = *reinterpret_cast<const i32x4*>(sW + off);
-            if (!TAIL) f.b[nt][1] = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
-        }
-    };
-    Frag pf;                       // tap-0 fragments of the next chunk, read behind the barrier inside the current chunk's last tap
-#pragma unroll
-    for (int i = 0; i < MT; ++i) { pf.a[i][0] = i32x4{0, 0, 0, 0}; pf.a[i][1] = i32x4{0, 0, 0, 0}; }
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) { pf.b[i][0] = i32x4{0, 0, 0, 0}; pf.b[i][1] = i32x4{0, 0, 0, 0}; }
-    bool pf_valid = false;         // wave-uniform: false for a tile's first chunk
-    // next_kind: KIND of chunk ck + 1 of this tile, -1: this is the tile's last chunk
-    auto chunk = [&](auto kind_tag, int ck, int next_kind) {
-        constexpr int KIND = decltype(kind_tag)::value;
-        constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
-        using KH_ = std::integral_constant<int, 0>; using KQ_ = std::integral_constant<int, 1>; using K3_ = std::integral_constant<int, 2>; using KT_ = std::integral_constant<int, 3>;
-        MX_TL(2);                        // chunk start
-        if (!pf_valid) {
-            if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            MX_TL(3);
-            __builtin_amdgcn_s_barrier();
-        }
-        MX_TL(ISQ ? 5 : 4);              // taps of an H (4) / Q (5) chunk begin
-        const bool more = ck + 1 < nchunks;
-        const int dma_img = more ? n : (next_n < a.n ? next_n : n), dma_ck = more ? ck + 1 : 0;
-        const int bufoff = buf * BUF_BYTES;
-        buf ^= 1;
-        const int asc = (NSRC2 && !X3 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
-        int wo = w_off;
-        asm volatile("" : "+v"(wo));
-        Frag cur;
-        if (pf_valid) cur = pf;
-        else {
-            cur = pf;                    // (defined registers for the halves a TAIL chunk does not load)
-            if (ROWREUSE || slot_live(0)) load_frags(kind_tag, bufoff, wo, 0, cur, cur);
-        }
-#pragma unroll
-        for (int slot = 0; slot < 9; ++slot) {
-            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
-            const int tap = ky * 3 + kx;
-            (void)tap;
-#if !(MX_ABL & 1)
-            if (slot < NPART) issue(dma_img, dma_ck, buf, slot);
-#endif
-            Frag nxt = cur;
-            if (slot < 8) {
-                if (ROWREUSE || slot_live(slot + 1)) load_frags(kind_tag, bufoff, wo, slot + 1, nxt, cur);
-            } else if (next_kind >= 0) {
-                // every DMA piece this wave issued for the next chunk has landed, every fragment read of this chunk has returned
-                MX_TL(10);
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                MX_TL(11);
-                const int nb = buf * BUF_BYTES;
-                if (ROWREUSE || slot_live(0)) {
-                    if (next_kind == 1) load_frags(KQ_{}, nb, wo, 0, pf, pf);
-                    else if (next_kind == 2) load_frags(K3_{}, nb, wo, 0, pf, pf);
-                    else if (next_kind == 3) load_frags(KT_{}, nb, wo, 0, pf, pf);
-                    else load_frags(KH_{}, nb, wo, 0, pf, pf);
-                }
-            }
-            if ((slot + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-            if (slot_live(slot)) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) {
-                        if (ISQ) {
-                            const i32x8 bw = {cur.b[nt][0][0], cur.b[nt][0][1], cur.b[nt][0][2], cur.b[nt][0][3], cur.b[nt][1][0], cur.b[nt][1][1], cur.b[nt][1][2], cur.b[nt][1][3]};
-                            const i32x8 ap = {cur.a[mt][0][0], cur.a[mt][0][1], cur.a[mt][0][2], cur.a[mt][0][3], cur.a[mt][1][0], cur.a[mt][1][1], cur.a[mt][1][2], cur.a[mt][1][3]};
-                            // fp6 slots carry their own E8M0 block scale (per pixel - or per output channel and tap - and 32 channels) in byte 24 =
-                            // dword 6 of the fragment, which the MFMA ignores as operand data: both scale operands of a lane come straight out of
-                            // its fragment registers
-                            acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], QFMT, QFMT, 0, Q6 ? cur.b[nt][1][2] : wsc[nt], 0, Q6 ? cur.a[mt][1][2] : asc);
-                        } else if (KIND == 2) {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][1]), __builtin_bit_cast(f16x8, cur.a[mt][0]), acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][0]), __builtin_bit_cast(f16x8, cur.a[mt][1]), acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][0]), __builtin_bit_cast(f16x8, cur.a[mt][0]), acc[mt][nt], 0, 0, 0);
-                        } else {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][0]), __builtin_bit_cast(f16x8, cur.a[mt][0]), acc[mt][nt], 0, 0, 0);
-                            if (!TAIL) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.b[nt][1]), __builtin_bit_cast(f16x8, cur.a[mt][1]), acc[mt][nt], 0, 0, 0);
-                        }
-                    }
-                // pin this tap's MFMAs here: without a use of the accumulators the optimiser sinks the whole (pure) MFMA chain of a
-                // chunk below its last tap, which hoists all 9 taps of fragment reads above it (~200 VGPRs, spills)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) {
-                        float pin = acc[mt][nt][0];
-                        asm volatile("" : "+v"(pin));
-                        acc[mt][nt][0] = pin;
-                    }
-            }
-            cur = nxt;
-        }
-        pf_valid = next_kind >= 0;
-    };
-#else
-    auto chunk = [&](auto kind_tag, int ck, int /*next_kind*/) {
+    auto chunk = [&](auto kind_tag, int ck) {
         constexpr int KIND = decltype(kind_tag)::value;
         constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
         MX_TL(2);                        // chunk start
@@ -594,24 +453,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 }
         }
     };
-#endif
     using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>; using KT = std::integral_constant<int, 3>;
-    // (the last argument: the KIND of the chunk that follows in this tile, -1 behind the last one)
     if constexpr (X3) {
-        for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck, ck + 1 < nchunks ? 2 : -1);
+        for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck);
     } else if constexpr (XQ) {
         for (int ck = 0; ck < nchunks; ck += 5) {
 #pragma unroll 1
-            for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h, h < 3 ? 0 : 1);     // H, L, H, L: the same code, other weights
-            chunk(KQ{}, ck + 4, ck + 5 < nchunks ? 0 : -1);
+            for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h);     // H, L, H, L: the same code, other weights
+            chunk(KQ{}, ck + 4);
         }
     } else {
         for (int ck = 0; ck + 1 < nchunks; ck += 2) {
-            chunk(KH{}, ck, 1);
-            chunk(KQ{}, ck + 1, ck + 3 < nchunks ? 0 : ((NSRC2 && AR == 0 && ck + 2 < nchunks) ? 3 : -1));
+            chunk(KH{}, ck);
+            chunk(KQ{}, ck + 1);
         }
         if constexpr (NSRC2 && AR == 0) {
-            if (nchunks & 1) chunk(KT{}, nchunks - 1, -1);
+            if (nchunks & 1) chunk(KT{}, nchunks - 1);
         }
     }
 
@@ -677,6 +534,60 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             const unsigned pi = MODE == 1 ? (unsigned)(2 * oy * ow + 2 * ox) : (unsigned)(oy * ow + ox);
             vo[mt] = pok ? (MODE == 2 ? pi * 4u : pi * 32u) : OOB;
         }
+        // the stores of one 32 x 32 output block (its words were parked in the accumulator registers by the math below)
+        auto store_block = [&](int mt, int nt) __attribute__((always_inline)) {
+            const int cob = (by_e * NT + wn * NTW + nt) * 32;
+            {
+                // (elements are read by value: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+                const f32x16& t = acc[mt][nt];
+                if (MODE != 2) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const bool cok = cob + 16 * q + 8 * kh < a.c_out;
+                        const unsigned vb = (vo[mt] == OOB || !cok) ? OOB : vo[mt];
+                        const i32x4 d4 = {__float_as_int(t[4 * q]), __float_as_int(t[4 * q + 1]), __float_as_int(t[4 * q + 2]), __float_as_int(t[4 * q + 3])};
+                        buffer_store_b128(d4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q]);
+                        if (X3) {       // (the other arithmetics stored their lo words in phase 1)
+                            const i32x4 l4 = {__float_as_int(t[8 + 4 * q]), __float_as_int(t[9 + 4 * q]), __float_as_int(t[10 + 4 * q]), __float_as_int(t[11 + 4 * q])};
+                            buffer_store_b128(l4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u);
+                        }
+                        if (wr_q && q6_out) {
+                            // fp6 slots: this lane owns bytes 12 kh .. 12 kh + 11 of its pixel's slot in either plane (once per 32-channel block)
+                            if (q == 0) {
+                                const unsigned v6 = (vo[mt] == OOB || cob >= a.c_out) ? OOB : vo[mt] + 12u * kh;
+                                buffer_store_b96(i32x3{__float_as_int(t[8]), __float_as_int(t[9]), __float_as_int(t[10])}, ro, v6, so_q[nt][0]);
+                                buffer_store_b96(i32x3{__float_as_int(t[12]), __float_as_int(t[13]), __float_as_int(t[14])}, ro, v6, so_q[nt][0] + ohw * 32u);
+                                // ... and the lower half-wave the two block scales (dword 6 of the slots)
+                                const unsigned v7 = (v6 == OOB || kh) ? OOB : vo[mt] + 24u;
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[11]), ro, v7, so_q[nt][0], 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[15]), ro, v7, so_q[nt][0] + ohw * 32u, 0);
+                            }
+                        } else if (wr_q) {
+                            // q planes: this lane owns bytes 8 kh .. 8 kh + 7 of its pixel's 16-byte half (cb & 16)
+                            const i32x2 q0 = {__float_as_int(t[8 + 2 * q]), __float_as_int(t[9 + 2 * q])};
+                            const i32x2 q1 = {__float_as_int(t[12 + 2 * q]), __float_as_int(t[13 + 2 * q])};
+                            if (!ql_only) __builtin_amdgcn_raw_buffer_store_b64(q0, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q], 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(q1, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q] + (ql_only ? 0u : ohw * 32u), 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if (cob + (e & 3) + 8 * (e >> 2) >= a.c_out) continue;       // no lane has this channel (wave-uniform)
+                        const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;        // differs between the half-waves: per-lane offset
+                        const unsigned vof = (vo[mt] == OOB || co >= a.c_out) ? OOB : vo[mt] + (unsigned)(n * a.c_out + co) * ohw * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[e]), ro, vof, 0, 0);
+                    }
+                }
+            }
+        };
+#if MX_EPI_INLINE
+        // Round 4: the DMA wait comes FIRST (the next tile's first chunk was issued during the last chunk's first taps: long landed), and
+        // every block's stores go out right behind its math, so that the address unit works through them (1 KiB per instruction at
+        // 64 B/clk: ~2 000 cycles per 512 x 64 tile, profiles/r04_conv_timeline_before.txt "stores") while the VALU does the next block -
+        // round 3 parked all four blocks and stored them in a phase of its own, with the waves idle behind the store queue.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         // ---- phase 1: math ----
         // Everything the hot (activation-tensor) modes do per element is branch-free and packed where the ISA has a packed form:
         // v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32 for bias, slope, BN and the hi/lo split, v_cvt_scalef32_pk_fp8_f32 (scale + RNE +
@@ -735,7 +646,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                         for (int p = 0; p < 8; ++p) x[p] = f32x2{tanhf(x[p][0]), tanhf(x[p][1])};
                     } else
 #endif
-                    {
+                    if (slope_e == 0.f) {
+                        // ReLU (most layers): x slope + 0 is +0 for every finite x, so the maximum takes the constant directly - the same
+                        // v_max_f32 on the same operands (bit-identical), without the packed multiply-add and the wait state behind it
+                        float zero = 0.f;
+                        asm volatile("" : "+v"(zero));
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) x[p] = f32x2{vmax_f32(x[p][0], zero), vmax_f32(x[p][1], zero)};
+                    } else {
 #pragma unroll
                         for (int p = 0; p < 8; ++p) {
                             const f32x2 t = __builtin_elementwise_fma(x[p], slope2, zero2);
@@ -758,7 +676,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #pragma unroll
                     for (int p = 0; p < 8; ++p) {
                         const f16x2 h2 = __builtin_convertvector(x[p], f16x2);
-                        lf[p] = x[p] - __builtin_convertvector(h2, f32x2);
+                        // x - float(h) as fma(float(h), -1, x): one v_fma_mix_f32 per element (the f16 -> f32 conversion is an operand
+                        // modifier) where the packed subtraction needed two conversions first; the same single rounding
+                        // (asm: the compiler canonicalises the fma back into two conversions and a packed subtraction)
+                        const unsigned hb = __builtin_bit_cast(unsigned, h2);
+                        float l0, l1;
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x[p][0]));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x[p][1]));
+                        lf[p] = f32x2{l0, l1};
                         hd[p] = __builtin_bit_cast(unsigned, h2);
                     }
                     if (X3 || wr_lo) {
@@ -928,61 +853,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = v[e];
                 }
+#if MX_EPI_INLINE
+                store_block(mt, nt);
+#endif
             }
         }
         // ---- phase 2: the next image's first chunk has landed ----
         MX_TL(7);                        // epilogue math done
+#if !MX_EPI_INLINE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         MX_TL(8);                        // ... and the residual loads / next tile's first DMA have landed
-        // ---- phase 3: stores ----
+        // ---- phase 3: stores (round 3's order: MX_EPI_INLINE 0) ----
+#if !MX_EPI_INLINE
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int cob = (by_e * NT + wn * NTW + nt) * 32;
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                // (elements are read by value: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
-                const f32x16& t = acc[mt][nt];
-                if (MODE != 2) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const bool cok = cob + 16 * q + 8 * kh < a.c_out;
-                        const unsigned vb = (vo[mt] == OOB || !cok) ? OOB : vo[mt];
-                        const i32x4 d4 = {__float_as_int(t[4 * q]), __float_as_int(t[4 * q + 1]), __float_as_int(t[4 * q + 2]), __float_as_int(t[4 * q + 3])};
-                        buffer_store_b128(d4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q]);
-                        if (X3) {       // (the other arithmetics stored their lo words in phase 1)
-                            const i32x4 l4 = {__float_as_int(t[8 + 4 * q]), __float_as_int(t[9 + 4 * q]), __float_as_int(t[10 + 4 * q]), __float_as_int(t[11 + 4 * q])};
-                            buffer_store_b128(l4, ro, vb == OOB ? OOB : vb + 16u * kh, so_hi[nt][q] + (unsigned)a.out_plane * 2u);
-                        }
-                        if (wr_q && q6_out) {
-                            // fp6 slots: this lane owns bytes 12 kh .. 12 kh + 11 of its pixel's slot in either plane (once per 32-channel block)
-                            if (q == 0) {
-                                const unsigned v6 = (vo[mt] == OOB || cob >= a.c_out) ? OOB : vo[mt] + 12u * kh;
-                                buffer_store_b96(i32x3{__float_as_int(t[8]), __float_as_int(t[9]), __float_as_int(t[10])}, ro, v6, so_q[nt][0]);
-                                buffer_store_b96(i32x3{__float_as_int(t[12]), __float_as_int(t[13]), __float_as_int(t[14])}, ro, v6, so_q[nt][0] + ohw * 32u);
-                                // ... and the lower half-wave the two block scales (dword 6 of the slots)
-                                const unsigned v7 = (v6 == OOB || kh) ? OOB : vo[mt] + 24u;
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[11]), ro, v7, so_q[nt][0], 0);
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[15]), ro, v7, so_q[nt][0] + ohw * 32u, 0);
-                            }
-                        } else if (wr_q) {
-                            // q planes: this lane owns bytes 8 kh .. 8 kh + 7 of its pixel's 16-byte half (cb & 16)
-                            const i32x2 q0 = {__float_as_int(t[8 + 2 * q]), __float_as_int(t[9 + 2 * q])};
-                            const i32x2 q1 = {__float_as_int(t[12 + 2 * q]), __float_as_int(t[13 + 2 * q])};
-                            if (!ql_only) __builtin_amdgcn_raw_buffer_store_b64(q0, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q], 0);
-                            __builtin_amdgcn_raw_buffer_store_b64(q1, ro, vb == OOB ? OOB : vb + 8u * kh, so_q[nt][q] + (ql_only ? 0u : ohw * 32u), 0);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        if (cob + (e & 3) + 8 * (e >> 2) >= a.c_out) continue;       // no lane has this channel (wave-uniform)
-                        const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;        // differs between the half-waves: per-lane offset
-                        const unsigned vof = (vo[mt] == OOB || co >= a.c_out) ? OOB : vo[mt] + (unsigned)(n * a.c_out + co) * ohw * 4u;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[e]), ro, vof, 0, 0);
-                    }
-                }
-            }
-        }
+            for (int mt = 0; mt < MT; ++mt) store_block(mt, nt);
+#endif
     };
 #ifdef MX_DEV_MODE       // ISA inspection builds: one epilogue mode only
     epilogue(std::integral_constant<int, MX_DEV_MODE>{});

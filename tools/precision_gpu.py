@@ -33,7 +33,7 @@ def main():
                     "DISCO_MX6_ROW_SCALE=1 in the environment for round 3's one-exponent-per-row fp6 weight scaling")
     ap.add_argument("--quick", action="store_true", help="three inputs on the synthetic checkpoint and one stress checkpoint")
     args = ap.parse_args()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))       # (one thread per core of a 256-core host thrashes: minutes per oracle forward)
     base = synth.synth_state_dict(130)
     q = gamut_points()
     cases = [("synth s%d %dx%d" % (s, h, w), base, s, n, h, w) for s, n, h, w in
