@@ -53,7 +53,8 @@
 #define MX_QFMT 0       // operand format of the K = 64 correction MFMA: 0 = fp8 e4m3.  2 (fp6 e2m3) / 4 (fp4): SPEED EXPERIMENTS ONLY - the data stay fp8 bytes
 #endif
 #ifndef MX_ABL
-#define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk
+#define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk,
+                        // bit 2 = no PIXEL pieces after the first chunk, bit 3 = no WEIGHT pieces after the first chunk
 #endif
 
 #ifndef MX_EPI_INLINE
@@ -280,6 +281,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             if (part >= 0 && i / APT != part) continue;
+#if MX_ABL & 4
+            if (part >= 0) continue;
+#endif
             const int piece = i * NWAVE + wave;
             if (NSRC2 && AR == 0 && tail && piece * 64 >= G::NPIX * 2) continue;       // a piece that lies entirely in plane 1
             if ((i + 1) * NWAVE <= A_PIECES || piece < A_PIECES) {      // only the last round of pieces needs the run-time test
@@ -295,6 +299,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             if (part >= 0 && i / WPT != part) continue;
+#if MX_ABL & 8
+            if (part >= 0) continue;
+#endif
             const int piece = i * NWAVE + wave;
             const int nt = piece / 18, q = piece - nt * 18;
             if (NSRC2 && AR == 0 && tail && (q & 1)) continue;                          // the second plane's weights
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         // the tap ORDER is a property of the tile width alone (never of how the tile is split over waves): every instantiation
         // that can serve a given layer shape accumulates in the same order, so a result does not depend on the batch size
         constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
-        constexpr bool ROWREUSE = COLMAJOR && MT == 2;
+        constexpr bool ROWREUSE = COLMAJOR && MT >= 2;        // M block mt at ky reads tile row mt + ky = what block mt + 1 read at ky - 1
         const int asc = (NSRC2 && !X3 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
         // this chunk's three column addresses inside the current buffer (the only per-chunk address arithmetic)
         const int bufoff = (int)(sA - smem);
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             if (!ROWREUSE && !live) continue;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if (ROWREUSE && ky > 0 && mt == 0) { ra[0][0] = ra[1][0]; ra[0][1] = ra[1][1]; continue; }
+                if (ROWREUSE && ky > 0 && mt + 1 < MT) { ra[mt][0] = ra[mt + 1][0]; ra[mt][1] = ra[mt + 1][1]; continue; }
 #if MX_ABL & 2
                 if (slot > 0) continue;
 #endif

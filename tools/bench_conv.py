@@ -82,7 +82,7 @@ def main():
         if args.only and args.only not in name:
             continue
         n = args.n
-        if args.mx and (c0 % 32 or c1 % 32):
+        if args.mx and (c0 % 32 or c1 % 32 or co < 32):
             continue
         if args.mx in (3, 4) and (c0 % 64 or c1):
             continue
