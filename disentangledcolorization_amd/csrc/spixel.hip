@@ -98,6 +98,26 @@ __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restric
     f32x2_t pw2[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) pw2[s] = pair_of(pw[s]);
+    // Stores (round 4): a thread owns one pixel, and a pixel's 16 channels of a plane are 32 contiguous bytes, so a thread-per-pixel store of
+    // 8 channels is 16 bytes at a 32-byte lane stride - every cache line half written per instruction, the q planes a quarter (round 3:
+    // 3.1 TB/s).  Now a wave collects a whole 16-channel block (32-channel block for the q planes), passes it through 2 KiB of LDS - whose
+    // image IS the memory image of the wave's four 16-pixel row segments - and every store instruction writes whole lines.  Same values.
+    __shared__ __attribute__((aligned(16))) unsigned char s_tr[4][2048];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned char* tr = s_tr[wave];
+    const float sc = ldexpf(1.f, sexp), qls = ldexpf(1.f, MX_LO_SHIFT);
+    // dense store of the 2 KiB in `tr` (4 rows x 16 pixels x 32 bytes) to plane base `dst` (byte address of pixel 0 of the image's block)
+    auto store_rows = [&](unsigned char* dst) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tr + h2 * 1024 + lane * 16);
+            const int row = cy * 16 + wave * 4 + h2 * 2 + (lane >> 5);
+            *reinterpret_cast<uint4*>(dst + ((long)row * W + cx * 16) * 32 + (lane & 31) * 16) = v;
+        }
+    };
+    unsigned char* const base = reinterpret_cast<unsigned char*>(out_act);
+    uint2 qa[4], ql[4];                                                     // a8 / al8 of the current 32-channel block (8 channels per trip)
+    f16x8 lpark;                                                            // lo words of the block's first half
     for (int hb = 0; hb < 2 * nblk; ++hb) {            // 8 channels per trip: 9 x 8 token values in SGPRs
         f32x2_t acc2[4];
 #pragma unroll
@@ -109,7 +129,39 @@ __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restric
             }
         }
         const float acc[8] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
-        store_act8(out_act, out_plane, q_off, sexp, img, hb >> 1, hb & 1, p, HW, nblk, acc, &sat);
+        // the split of store_act8(): xs = x 2^sexp, hi = fp16(xs), lo = fp16(xs - hi), a8 = fp8(xs), al8 = fp8((xs - hi) 2^11)
+        f16x8 h, l;
+        float v[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = acc[j] * sc; h[j] = (f16)v[j]; lo[j] = v[j] - (float)h[j]; l[j] = (f16)lo[j]; }
+        const int blk = hb >> 1, half = hb & 1;
+        // (LDS operations of a wave execute in order: a row image is complete when store_rows reads it, and read before it is rewritten)
+        *reinterpret_cast<f16x8*>(tr + lane * 32 + half * 16) = h;
+        if (half == 0) lpark = l;
+        else {
+            unsigned char* hb_base = base + (((long)img * nblk + blk) * HW) * 32;
+            store_rows(hb_base);
+            if (out_plane) {
+                *reinterpret_cast<f16x8*>(tr + lane * 32) = lpark;
+                *reinterpret_cast<f16x8*>(tr + lane * 32 + 16) = l;
+                store_rows(hb_base + out_plane * 2);
+            }
+        }
+        if (q_off) {
+            uint2 a, b;
+            b.x = pack_fp8x4(lo[0] * qls, lo[1] * qls, lo[2] * qls, lo[3] * qls, &sat); b.y = pack_fp8x4(lo[4] * qls, lo[5] * qls, lo[6] * qls, lo[7] * qls, &sat);
+            a.x = pack_fp8x4(v[0], v[1], v[2], v[3], &sat); a.y = pack_fp8x4(v[4], v[5], v[6], v[7], &sat);
+            qa[hb & 3] = a; ql[hb & 3] = b;
+            if ((hb & 3) == 3) {
+                unsigned char* qb = base + q_off + (((long)img * (nblk >> 1) + (blk >> 1)) * 2) * HW * 32;
+                *reinterpret_cast<uint4*>(tr + lane * 32) = uint4{qa[0].x, qa[0].y, qa[1].x, qa[1].y};
+                *reinterpret_cast<uint4*>(tr + lane * 32 + 16) = uint4{qa[2].x, qa[2].y, qa[3].x, qa[3].y};
+                store_rows(qb);
+                *reinterpret_cast<uint4*>(tr + lane * 32) = uint4{ql[0].x, ql[0].y, ql[1].x, ql[1].y};
+                *reinterpret_cast<uint4*>(tr + lane * 32 + 16) = uint4{ql[2].x, ql[2].y, ql[3].x, ql[3].y};
+                store_rows(qb + HW * 32);
+            }
+        }
     }
     if (sat_out && sat) atomicAdd(sat_out, sat);
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """HBM bytes per conv launch from two rocprofv3 PMC passes (run on the GPU box, see the recipe below) ->
-profiles/r03_pmc_traffic.json, which bench.py reports as roofline.traffic (it carries the hash of the conv sources it was measured
+profiles/r04_pmc_traffic.json, which bench.py reports as roofline.traffic (it carries the hash of the conv sources it was measured
 on; bench.py reports null when the sources have changed since).
 
     cd /tmp && export TMPDIR=/tmp
@@ -54,7 +54,7 @@ def main():
     write, nw, write_l = total(write_dir, "WRITE_SIZE")
     with open(os.path.splitext(out)[0] + "_layers.txt", "w") as fh:
         fh.write("# HBM-side MB per conv launch by position in the forward (reads = FETCH_SIZE x 2 KiB, writes = WRITE_SIZE KiB); the positions are the\n"
-                 "# rows of profiles/r03_final_layers.txt (0-17 SpixelNet, 18-44 ColorProbNet, 45-68 HourGlass2)\n")
+                 "# rows of profiles/r04_final_layers.txt (0-17 SpixelNet, 18-44 ColorProbNet, 45-68 HourGlass2)\n")
         for i in range(PER_FORWARD):
             fh.write("%3d  read %8.1f MB  write %8.1f MB\n" % (i, fetch_l[i] * 2048 / 1e6, write_l[i] * 1024 / 1e6))
     if not nf or nf != nw:

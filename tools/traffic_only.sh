@@ -1,8 +1,8 @@
 #!/bin/bash
-# The two PMC passes behind profiles/r03_pmc_traffic.json alone (run through gpurun from the repo root): re-run after any change to the conv sources.
+# The two PMC passes behind profiles/r04_pmc_traffic.json alone (run through gpurun from the repo root): re-run after any change to the conv sources.
 set -x
 R=$PWD
-O=$R/gpurun_out/r03
+O=$R/gpurun_out/r04
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --pipeline 0 --micro 1 > /dev/null 2> $O/fetch.err
