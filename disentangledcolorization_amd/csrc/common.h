@@ -207,6 +207,8 @@ struct ConvArgs {
     uint32_t src_bytes[2];  // filled by the launcher: bytes addressable through each source's buffer descriptor
     uint32_t w_bytes;       // ... and through the packed-weight descriptor
     int softmax;        // fp32 NCHW output only: softmax over the c_out (<= 32) channels after the epilogue
+    // fused Cin = 1 producer (ConvMxArgs::c1_gray): src[0] then only DESCRIBES the virtual input tensor (c, h, w, sexp; p may be null)
+    const float* c1_gray; const float* c1_w; const float* c1_bias; int c1_act; float c1_slope;
 };
 
 // ---- conv3x3, fp16 main product + two fp8 (e4m3, K = 64) correction products (conv_mx.hip) ----------------------------
@@ -255,6 +257,12 @@ struct ConvMxArgs {
     int q6;                   // 1: the f16 + fp6x2 arithmetic (AR 3): as 0 with fp6 e2m3 correction operands (sources with q_kind 2 planes,
                               // weights packed with variant 2): half the passes of the fp8 K = 64 MFMA
     int out_q_kind;           // layout of the output's q planes (Act::q_kind)
+    // fused Cin = 1 producer (f16x3, stride 1, one source of <= 64 channels that is NOT read: src[0].p may be null): the layer's input is
+    // computed in LDS as act(conv3x3(gray, c1_w) + c1_bias) 2^c1_sexp, conv_c1_kernel's arithmetic (conv_mx_kernel.h, GENC1)
+    const float* c1_gray;     // (n,1,h,w) fp32, or null: an ordinary layer
+    const float* c1_w;        // (c_in, 9)
+    const float* c1_bias;     // (c_in) or null
+    int c1_act; float c1_slope; int c1_sexp;
     int x3;                   // 1: the f16x3 arithmetic on this kernel (launch_conv3x3_x3): sources = hi + lo planes, MxSrc::q_off = byte
                               // distance between them, weights = conv3x3_pack_host's image, no q planes anywhere
 };

@@ -41,18 +41,9 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
     __syncthreads();
     const float* gi = gray + img * hw;
     unsigned sat = 0;
-    // A thread keeps its channel half for all its iterations (the grid stride is even), so the half's 72 weights and 24 epilogue
-    // parameters live in registers: round 3 read them from LDS inside the loop - 72 broadcast ds_reads per 72 FMAs (round 4: 0.17 -> 0.1x ms)
-    const int half = (int)(threadIdx.x & 1);
-    float wr[72], pb[8], ps[8], ph[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wr[j * 9 + k] = sw[(half * 8 + j) * 9 + k];
-        pb[j] = sw[144 + half * 8 + j]; ps[j] = sw[160 + half * 8 + j]; ph[j] = sw[176 + half * 8 + j];
-    }
     for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < 2 * hw; u += (long)gridDim.x * blockDim.x) {
         const long p = u >> 1;
+        const int half = (int)(u & 1);
         const int x = (int)(p % wd), y = (int)(p / wd);
         float in[9];
 #pragma unroll
@@ -65,12 +56,13 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            const int c = half * 8 + j;
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) s = fmaf(in[k], wr[j * 9 + k], s);
-            s += pb[j];
+            for (int k = 0; k < 9; ++k) s = fmaf(in[k], sw[c * 9 + k], s);
+            s += sw[144 + c];
             s = apply_act(s, act, slope);
-            v[j] = real ? s * ps[j] + ph[j] : 0.f;
+            v[j] = real ? s * sw[160 + c] + sw[176 + c] : 0.f;
         }
         store_act8(out, out_plane, q_off, sexp, img, blk, half, p, hw, nblk, v, &sat, q_kind);
     }

@@ -396,7 +396,7 @@ int launch_conv3x3_x3(const ConvArgs& c, hipStream_t s) {
     int csum = 0;
     for (int i = 0; i < c.nsrc; ++i) {
         const ConvSrc& sp = c.src[i];
-        if (sp.c % 16 || sp.c <= 0 || sp.plane <= 0) { set_error("conv3x3_x3: source %d needs hi + lo planes and a multiple of 16 channels (got %d)", i, sp.c); return DISCO_ESHAPE; }
+        if (sp.c % 16 || sp.c <= 0 || (sp.plane <= 0 && !c.c1_gray)) { set_error("conv3x3_x3: source %d needs hi + lo planes and a multiple of 16 channels (got %d)", i, sp.c); return DISCO_ESHAPE; }
         const size_t per = (size_t)c.n * sp.c * sp.h * sp.w * 2;
         const size_t bytes = (size_t)sp.plane * 2 + per;
         if (bytes >= ((size_t)1 << 32)) { set_error("conv3x3: activation tensor of %zu bytes exceeds 32-bit buffer addressing; split the batch", bytes); return DISCO_ESHAPE; }
@@ -414,6 +414,15 @@ int launch_conv3x3_x3(const ConvArgs& c, hipStream_t s) {
     a.bias = c.bias; a.bn_scale = c.bn_scale; a.bn_shift = c.bn_shift;
     a.res = c.res; a.res_plane = c.res_plane; a.res_sexp = c.res_sexp; a.out = c.out; a.out_plane = c.out_plane; a.out_f32 = c.out_f32; a.out_sexp = c.out_sexp;
     a.d2s_c = c.d2s_c; a.act = c.act; a.slope = c.slope; a.softmax = c.softmax; a.x3 = 1;
+    if (c.c1_gray) {
+        // the fused Cin = 1 producer runs on the 32 x 16 x 64 tile only: stride 1, one source of 32..64 channels (>= 2 chunks: the next image's
+        // gray tile is fetched during a tile's first chunk and used in its last), >= 64 output channels, no tap mask, an image at least a tile wide
+        if (c.nsrc != 1 || c.stride != 1 || c.src[0].up || c.c_in < 32 || c.c_in > 64 || c.c_out < 64 || c.tapmask || c.w_out <= 16 || c.h_out <= 8 || !c.c1_w ||
+            c.src[0].h != c.h_in || c.src[0].w != c.w_in || (size_t)c.n * c.h_in * c.w_in * 4 >= ((size_t)1 << 32)) {
+            set_error("conv3x3_x3: this layer shape cannot take the fused Cin = 1 producer"); return DISCO_ESHAPE;
+        }
+        a.c1_gray = c.c1_gray; a.c1_w = c.c1_w; a.c1_bias = c.c1_bias; a.c1_act = c.c1_act; a.c1_slope = c.c1_slope; a.c1_sexp = c.src[0].sexp;
+    }
     {
         const size_t wb = (size_t)cdiv(c.c_out, 32) * (c.c_in / 16) * W_NB;          // = conv3x3_packed_bytes
         if (wb >= ((size_t)1 << 32)) { set_error("conv3x3: packed weights too large"); return DISCO_ESHAPE; }

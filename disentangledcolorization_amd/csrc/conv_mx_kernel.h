@@ -154,7 +154,10 @@ struct GeoMx {
 // AR: 0 = f16 + fp8x2, 1 = f16x2 + fp8 (x2q), 2 = f16x3 (below), 3 = f16 + fp6x2: AR 0 with the two correction operands in fp6 e2m3
 // (Act::q_kind 2 sources, conv_mx_pack_host variant 2): the K = 64 MFMA takes half the passes (tools/fp6_probe.hip pins the operand
 // layout and the conversion; profiles/r03_mfma_mix.txt the rate)
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR>
+// GENC1 (round 4, f16x3 only): the layer's 16-channel chunks are not read from a tensor - they are COMPUTED in LDS from the gray image, as
+// the outputs of the Cin = 1 conv that precedes it in the network (repnet.conv1_2.0 -> conv1_2.2, network.py:152-153): the same fmaf chain,
+// bias, LeakyReLU, scale and hi/lo split as conv_c1_kernel + store_act8 (bit-identical), so that layer's 1.07 GB tensor is never written or read
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR, bool GENC1 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
     constexpr bool XQ = AR == 1, X3 = AR == 2, Q6 = AR == 3;
     constexpr int QFMT = Q6 ? 2 : MX_QFMT;                // operand format code of the K = 64 MFMA: 0 = fp8 e4m3, 2 = fp6 e2m3
@@ -176,6 +179,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;
     constexpr int PAR_OFF = 2 * BUF_BYTES;
 
+    // GENC1: behind the parameters: two gray tiles (the tile's input footprint of the Cin = 1 conv: one pixel more on every side than the
+    // layer's own halo tile) and that conv's weights + biases, 10 floats per channel
+    constexpr int GTW = G::TWI + 2, GTH = G::THI + 2, GT_FLOATS = GTW * GTH;
+    constexpr int GT_PIECES = (GT_FLOATS + 63) / 64;                     // 256-byte LDS-DMA pieces (4 bytes per lane)
+    constexpr int GT_BYTES = GT_PIECES * 256;
+    constexpr int GT_OFF = PAR_OFF + 3 * 32 * NT * 4, C1W_OFF = GT_OFF + 2 * GT_BYTES;
+    constexpr int GPW = (GT_PIECES + NWAVE - 1) / NWAVE;
+    static_assert(!GENC1 || (AR == 2 && STRIDE == 1 && !NSRC2 && !MASKED), "the fused Cin = 1 producer exists for plain f16x3 layers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -212,6 +223,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         s_par[i] = ((src && co < a.c_out) ? src[cpar] : (which == 1 ? 1.f : 0.f)) * pm;
     }
 
+    if (GENC1) {
+        // the producing conv's weights and biases: channel c at floats [10 c, 10 c + 9), bias at 10 c + 9
+        float* s_c1 = reinterpret_cast<float*>(smem + C1W_OFF);
+        for (int i = tid; i < a.c_in * 10; i += NWAVE * 64) {
+            const int c = i / 10, k = i - c * 10;
+            s_c1[i] = k < 9 ? a.c1_w[c * 9 + k] : (a.c1_bias ? a.c1_bias[c] : 0.f);
+        }
+    }
     // E8M0 scale operands of the fp8 products: weight side per lane (= per output channel row), pixel side uniform per source
     int wsc[NTW];
 #pragma unroll
@@ -224,8 +243,73 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
     constexpr int NS = NSRC2 ? 2 : 1;
+    // GENC1: the gray image through its own descriptor; per lane the byte offset of its element(s) of the (TH + 4) x (TW + 4) tile, or OOB
+    // (an out-of-range lane lands as 0 in LDS = the producing conv's zero padding)
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)(GENC1 ? a.c1_gray : nullptr), 0, GENC1 ? (unsigned)a.n * (unsigned)(a.h_in * a.w_in) * 4u : 0u, 0x00020000);
+    unsigned gvoff[GPW];
+    if (GENC1) {
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const int e = (i * NWAVE + wave) * 64 + lane;
+            const int gy = oy0 - 2 + e / GTW, gx = ox0 - 2 + e % GTW;
+            gvoff[i] = (e < GT_FLOATS && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in) ? (unsigned)(gy * a.w_in + gx) * 4u : OOB;
+        }
+    }
+    // LDS-DMA of image `img`'s gray tile into gray buffer gb
+    auto issue_gray = [&](int img, int gb) {
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const int piece = i * NWAVE + wave;
+            if (piece < GT_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (lds_void*)(smem + GT_OFF + gb * GT_BYTES + piece * 256), 4, gvoff[i], (unsigned)img * (unsigned)(a.h_in * a.w_in) * 4u, 0, 0);
+        }
+    };
+    // One wave-iteration of the fused producer: 64 halo pixels x 8 channels (the wave-uniform half j of chunk ck's 16 channels) computed from
+    // gray buffer gb and written as one hi and one lo 16-byte unit per pixel into pixel buffer `abuf` - conv_c1_kernel's arithmetic, to the bit:
+    // s = 0; s = fmaf(in[k], w[k], s) for k = 0..8; s += bias; LeakyReLU; s * 1 + 0 (its BN affine without a BN); then store_act8's split
+    auto gen_c1 = [&](int it, int ck, int gb, int abuf) {
+        const int pg = it >> 1, j = it & 1;
+        const int p = pg * 64 + lane;
+        if (pg * 64 >= G::NPIX) return;                    // (wave-uniform)
+        const int py = p / G::PITCH, q = p - py * G::PITCH;
+        const int gy = oy0 - 1 + py, gx = ox0 - 1 + q;
+        const bool inside = p < G::NPIX && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
+        const float* gt = reinterpret_cast<const float*>(smem + GT_OFF + gb * GT_BYTES);
+        float in[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) in[ky * 3 + kx] = p < G::NPIX ? gt[(py + ky) * GTW + q + kx] : 0.f;
+        const float* wc = reinterpret_cast<const float*>(smem + C1W_OFF) + (ck * 16 + j * 8) * 10;       // (LDS broadcasts; scalar loads of the
+        // same weights from global memory were slower: profiles/r04_fused_first_layer_ab.txt)
+        const float sc = __builtin_ldexpf(1.f, a.c1_sexp);
+        float one = 1.f, zero = 0.f;
+        asm volatile("" : "+v"(one), "+v"(zero));          // the affine (1, 0) as run-time values, as the stand-alone kernel has them
+        f16x8 h, l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sacc = fmaf(in[k], wc[c * 10 + k], sacc);
+            sacc += wc[c * 10 + 9];
+            if (a.c1_act == DISCO_ACT_RELU) sacc = fmaxf(sacc, 0.f);
+            else if (a.c1_act == DISCO_ACT_LRELU) sacc = sacc >= 0.f ? sacc : sacc * a.c1_slope;
+            float v = sacc * one + zero;
+            if (!inside) v = 0.f;                          // this layer's own zero padding
+            const float vs = v * sc;
+            h[c] = (f16)vs;
+            l[c] = (f16)(vs - (float)h[c]);
+        }
+        if (p < G::NPIX) {
+            char* d = smem + abuf * BUF_BYTES + p * 32 + ((j ^ ((q >> 3) & 1)) << 4);
+            *reinterpret_cast<f16x8*>(d) = h;
+            *reinterpret_cast<f16x8*>(d + PLANE_B) = l;
+        }
+    };
+    constexpr int GEN_ITERS = ((G::NPIX + 63) / 64) * 2;                 // wave-iterations per chunk
+    constexpr int GEN_PER_WAVE = (GEN_ITERS + NWAVE - 1) / NWAVE;
     unsigned voff[NS][APW];           // per source: byte offset (plane included) of this lane's 16 bytes inside a chunk, or OOB
-    {
+    if (!GENC1) {
         const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
 #pragma unroll
         for (int si = 0; si < NS; ++si) {
@@ -280,6 +364,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         const bool tail = NSRC2 && AR == 0 && (nchunks & 1) && ck == nchunks - 1;       // 16-channel H-only chunk: plane 0 alone
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
+            if (GENC1) break;                              // the pixel tile is computed (gen_c1), not loaded
             if (part >= 0 && i / APT != part) continue;
 #if MX_ABL & 4
             if (part >= 0) continue;
@@ -336,6 +421,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     const int tl_w = wave == 0 ? 0 : 1;
     int tl_n = 1;
 #endif
+    int gbuf = 0;                        // GENC1: gray buffer of the image being convolved (the other one receives the next image's tile)
+    if (GENC1) {
+        // first tile: its gray tile, then its first chunk computed up front (every later chunk is computed under its predecessor's taps)
+        issue_gray(n, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the gray tile has landed, the weight staging above has been written
+        __builtin_amdgcn_s_barrier();                      // ... and both are visible to every wave
+#pragma unroll
+        for (int k = 0; k < GEN_PER_WAVE; ++k) gen_c1(k * NWAVE + wave, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     issue(n, 0, 0, -1);
     int buf = 0;
     bool dma_waited = false;
@@ -369,6 +464,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
         MX_TL(2);                        // chunk start
         if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (GENC1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's share of the computed pixel tile has been written
         MX_TL(3);                        // this chunk's DMA has landed (own pieces)
         __builtin_amdgcn_s_barrier();
         MX_TL(ISQ ? 5 : 4);              // barrier passed: taps of an H (4) / Q (5) chunk begin
@@ -401,6 +497,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 #if !(MX_ABL & 1)
             issue(dma_img, dma_ck, buf, slot);
 #endif
+            if (GENC1) {
+                // the next chunk's pixel tile, a third per wave in taps 0, 3 and 6; in the tile's first chunk also the NEXT image's gray tile
+                // (into the other gray buffer: complete and visible from the next chunk's barrier on, needed in the tile's last chunk)
+                if (slot == 0 && ck == 0 && next_n < a.n) issue_gray(next_n, gbuf ^ 1);
+                if (slot % 3 == 0 && slot / 3 < GEN_PER_WAVE && (more || next_n < a.n))
+                    gen_c1((slot / 3) * NWAVE + wave, dma_ck, more ? gbuf : (gbuf ^ 1), buf);
+            }
             const bool live = !MASKED || ((tmask >> tap) & 1u);
             if (!ROWREUSE && !live) continue;
 #pragma unroll
@@ -893,6 +996,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     }
     dma_waited = true;
     MX_TL(9);                            // stores issued
+    gbuf ^= 1;
     n = next_n;
     if (n >= a.n) break;
     }
@@ -904,13 +1008,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 
 inline int num_cus_mx() { return num_cus_current(); }
 
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0>
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0, bool GENC1 = false>
 int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
     using G = GeoMx<TW, TH, STRIDE>;
     constexpr int A_BYTES = ((2 * G::NPIX * 2 + 63) / 64) * 1024;
-    constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4;
+    // GENC1: + two gray tiles (256-byte pieces) and 10 floats per input channel of the fused producer (64 channels at most)
+    constexpr int GT_BYTES = (((G::TWI + 2) * (G::THI + 2) + 63) / 64) * 256;
+    constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4 + (GENC1 ? 2 * GT_BYTES + 64 * 10 * 4 : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR>;
+    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR, GENC1>;
     // function attributes are per device and per kernel instantiation (this static lives in the instantiation)
     static std::atomic<int> attr_done[DISCO_MAX_DEVICES];
     DISCO_HIP_CHECK(set_dyn_lds_once(attr_done, reinterpret_cast<const void*>(kern), smem));
@@ -945,6 +1051,9 @@ template <int AR>
 int dispatch_mx_ar(const ConvMxArgs& a, hipStream_t s) {
     const bool wide = a.w_out > 16;
     const bool nt2 = a.c_out > 32;
+    if constexpr (AR == 2) {
+        if (a.c1_gray) return launch_mx4<32, 16, 2, 1, 8, 1, false, false, 2, true>(a, s);       // (launch_conv3x3_x3 has checked the shape)
+    }
     if (a.stride == 1) {
         struct Cand { int tw, th, nt; };
         static const Cand order[6] = {{32, 16, 2}, {32, 16, 1}, {32, 8, 2}, {16, 16, 2}, {32, 8, 1}, {16, 16, 1}};

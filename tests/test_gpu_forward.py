@@ -577,6 +577,39 @@ def test_checkpoints_with_activations_far_from_one(synth_sd, q_to_ab, which):
     assert _err(out[0], want[0]) < LOGIT_TOL * max(1.0, want[0].abs().max().item()) and _err(out[2], want[2]) <= AB_TOL
 
 
+def test_fused_first_layer_is_bit_identical_to_the_two_launch_form():
+    """Round 4: repnet.conv1_2.0 (Cin = 1) is computed inside conv1_2.2's LDS staging when that layer runs on the 32 x 16 x 64 tile with
+    enough tiles to fill the GPU (csrc/conv_mx_kernel.h GENC1; api.cpp run_plan) - the stand-alone kernel's fmaf chain, bias, LeakyReLU,
+    scale and hi/lo split, so every output of the forward must be BIT-identical with the fusion on and off (DISCO_FUSE_C1, read once per
+    process: two subprocesses).  Shapes: full tiles, a partial last tile column (W = 176), one tall image, a batch too small to fuse."""
+    import subprocess, sys
+    code = r'''
+import sys, zlib, numpy as np, torch
+sys.path.insert(0, %r)
+from disentangledcolorization_amd import synth
+from disentangledcolorization_amd.model import AnchorColorProb
+m = AnchorColorProb(n_clusters=8, enhanced=True, init_weights=False)
+m.load_state_dict(synth.synth_state_dict(130))
+m = m.cuda().eval()
+for (n, h, w) in ((8, 128, 128), (6, 96, 176), (1, 512, 256), (1, 64, 64)):
+    gray, ab = synth.synth_inputs(n, h, w, seed=77 + h)
+    np.random.seed(130); torch.manual_seed(130)
+    out = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    crc = 0
+    for t in out:
+        crc = zlib.crc32(t.contiguous().cpu().numpy().tobytes(), crc)
+    print("CRC", n, h, w, "%%08x" %% crc)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DISCO_FUSE_C1=flag), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = [l for l in r.stdout.splitlines() if l.startswith("CRC")]
+        assert len(outs[flag]) == 4
+    assert outs["0"] == outs["1"], (outs["0"], outs["1"])
+
+
 @pytest.mark.parametrize("precision", ["mx6", "mx8"])
 def test_photograph_matches_reference_golden(golden_dir, synth_sd, precision):
     """Natural-image inputs (round 4; every other fixture feeds uniform noise, and the activation ranges are calibrated on synthetic
