@@ -183,6 +183,12 @@ struct disco_ctx {
     std::map<std::string, float> amax;   // calibration: max |x| of every conv output (fp16 range guard, diagnostics)
     unsigned int* d_sat = nullptr;       // mx: q-plane elements that had to be clamped since the last read
     bool calibrated = false;
+    // Channel disparity of the tensors that carry MX fp6 planes (one E8M0 scale per pixel and 32 CHANNELS): per tensor and 32-channel block
+    // the ratio of the largest per-channel max |x| to the lower quartile of the block's live channels, measured in the calibration pass; the largest ratio over all
+    // blocks is `mx6_disparity`.  Beyond MX6_DISPARITY_LIMIT the HourGlass2 is rebuilt on fp8 corrections (e4m3: 4 exponent bits), see disco_finalize.
+    float mx6_disparity = 0.f;
+    std::string mx6_disparity_key;
+    bool enhance_fp8_fallback = false;
     // One host thread at a time inside a context: the forward entry points, calibration and the setters below lock this.  The GPU work
     // of successive calls still overlaps across the streams they were given; what is serialised is the host-side issue (staging ring,
     // one-shot progress event, profiling vectors, calibration tables are plain members).
@@ -298,7 +304,7 @@ int arith_of(const disco_ctx* c, const std::string& key) {
     if (c->opt.precision == DISCO_PREC_MX8_ALL) return ARITH_MX8;
     if (c->opt.precision != DISCO_PREC_MX8 && c->opt.precision != DISCO_PREC_X2Q && c->opt.precision != DISCO_PREC_MX6) return ARITH_F16X3;
     if (key.compare(0, 11, "enhanceNet.") == 0) {
-        if (c->opt.precision == DISCO_PREC_MX8) return ARITH_MX8;
+        if (c->opt.precision == DISCO_PREC_MX8 || c->enhance_fp8_fallback) return ARITH_MX8;
         return key == "enhanceNet.inConv.inConv.0" ? ARITH_MX8 : ARITH_MX6;
     }
     if (c->opt.precision == DISCO_PREC_X2Q && key.compare(0, 7, "repnet.") == 0) return ARITH_X2Q;
@@ -628,6 +634,31 @@ struct Plan {
         }
         c->sexp[key] = e;
         if (t.sexp != e) { t.sexp = e; produce(); }
+        if (t.q_off && t.q_kind == 2 && t.c % 32 == 0 && t.c <= 1024) channel_disparity(key, t);
+    }
+    // MX fp6 planes share one scale per pixel and 32 channels: a channel whose values sit far below its block's largest loses its correction
+    // operands (e2m3: below 1/8 of the block maximum subnormal, below 1/60 zero).  Harmless while the consumer's weights do not make up for the
+    // difference - trained BatchNorm affines can (tools/precision_gpu.py --gamma: 2 decades of per-channel spread cost 6.8e-4, 3 decades the
+    // 1e-3 bar).  Measured here per tensor: per block the largest per-channel max |x| over the live channels' lower quartile; disco_finalize acts on it.
+    void channel_disparity(const std::string& key, const Act& t) {
+        float* d = (float*)raw((size_t)t.c * 4);
+        if (!ok()) return;
+        std::vector<float> h(t.c);
+        if (hipMemsetAsync(d, 0, (size_t)t.c * 4, s) != hipSuccess) { rc = DISCO_EHIP; return; }
+        rc = launch_act_channel_amax(t, d, s);
+        if (ok() && (hipMemcpyAsync(h.data(), d, (size_t)t.c * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = hip_fail(hipGetLastError(), "channel amax");
+        drop(d);
+        if (!ok()) return;
+        for (int b = 0; b + 32 <= t.c; b += 32) {
+            // channels that never fire on the calibration images (ReLU-dead: max 0) carry nothing and are left out; of the live ones the
+            // largest against the lower quartile: a quarter of a block's channels below 1/64 of its maximum is where fp6 starts to cost
+            std::vector<float> v;
+            for (int i = 0; i < 32; ++i) if (h[b + i] > 0.f) v.push_back(h[b + i]);
+            if (v.size() < 16) continue;
+            std::sort(v.begin(), v.end());
+            const float ratio = v.back() / v[v.size() / 4];
+            if (ratio > c->mx6_disparity) { c->mx6_disparity = ratio; c->mx6_disparity_key = key; }
+        }
     }
 
     // MFMA conv: out = bn(act(conv(cat(in0[,in1])) + bias [+ res]));  ofmt: planes of the output tensor (-1: the default)
@@ -1107,6 +1138,56 @@ static bool positive(const char* op, std::initializer_list<long> dims) {
     return true;
 }
 
+// The HourGlass2's layers (network.py:125-144), packed for the arithmetic arith_of() currently assigns them: called once by disco_finalize and
+// once more when the channel-disparity guard moves the stack from fp6 to fp8 corrections (the host weights "enhanceNet.*" stay in c->sd)
+int make_enhance(disco_ctx* c) {
+    int rc;
+    const std::string en = "enhanceNet.";
+    {   // input = cat(gray, 64 token features) in the reference; here source 0 = features, source 1 = 16-ch gray plane
+        // (80 packed channels in every arithmetic: the f16+fp8x2 kernel takes the gray block as its H-only tail chunk with the gray
+        // channel as (g_hi, g_lo, g_hi) against (w_h, w_h, w_l) - launch_gray_tail, conv_mx_pack_host)
+        const int cp = 80;
+        std::vector<int> map(cp, -1);
+        for (int i = 0; i < 64; ++i) map[i] = i + 1;
+        map[64] = 0;
+        if (use_mx(c, en)) { map[65] = 0; map[66] = CONV_MX_LO_OF(0); }
+        if ((rc = make_conv(c, en + "inConv.inConv.0", "", "", &map, cp))) return rc;
+    }
+    if ((rc = make_conv(c, en + "inConv.conv.0", "", en + "inConv.conv.2"))) return rc;
+    for (const char* k : {"down1", "down2"}) {
+        if ((rc = make_conv(c, en + k + ".conv.0", "", "", nullptr, 0, true))) return rc;       // down1 / down2: stride 2
+        if ((rc = make_conv(c, en + k + ".conv.2", "", en + k + ".conv.4"))) return rc;
+    }
+    for (int r = 0; r < 3; ++r)
+        for (const char* k : {"0", "1", "3"})
+            if ((rc = make_conv(c, en + "residual." + std::to_string(r) + ".conv." + k, "", ""))) return rc;
+    for (const char* k : {"up2", "up1"}) {
+        if ((rc = make_conv(c, en + k + ".conv1", "", ""))) return rc;
+        if ((rc = make_conv(c, en + k + ".combine", "", ""))) return rc;
+        if ((rc = make_conv(c, en + k + ".conv2.0", "", ""))) return rc;
+        if ((rc = make_conv(c, en + k + ".conv2.2", "", en + k + ".conv2.4"))) return rc;
+    }
+    if ((rc = make_conv(c, en + "outConv", "", "", nullptr, 0, false, false))) return rc;
+    return DISCO_OK;
+}
+
+// MX fp6 planes tolerate this much spread between the per-channel maxima of a 32-channel block before the
+// HourGlass2 is moved to fp8 corrections (largest over lower quartile of the live channels): tools/precision_gpu.py --gamma (profiles/r04_channel_disparity.txt) measures max|ab| 1.6e-4 at one
+// decade of spread, 2.6e-4 at 1.5, 6.8e-4 at 2 and 1.0e-3 at 3, against 1.1e-4 for fp8 at any of them; with this measure the synthetic checkpoint reads 9, its Student-t variants 10-20, the four spreads 37 / 78 / 159 / 1 153
+constexpr float MX6_DISPARITY_LIMIT = 64.f;
+// after a calibration pass: rebuild the HourGlass2 on fp8 corrections and calibrate again when the measured disparity asks for it
+int enhance_disparity_guard(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, int uh = 0, int uw = 0) {
+    if (c->opt.segnet_only || c->enhance_fp8_fallback || arith_of(c, "enhanceNet.outConv") != ARITH_MX6 || !(c->mx6_disparity > MX6_DISPARITY_LIMIT)) return DISCO_OK;
+    if (!c->sd.count("enhanceNet.outConv.weight")) return DISCO_OK;      // (host weights gone: cannot happen after disco_finalize)
+    c->enhance_fp8_fallback = true;
+    // the old layers' device buffers stay in c->allocs until disco_destroy (a few tens of MB); their exponents are measured again
+    int rc = make_enhance(c);
+    if (rc) return rc;
+    for (auto it = c->sexp.begin(); it != c->sexp.end();) it = it->first.compare(0, 11, "enhanceNet.") == 0 ? c->sexp.erase(it) : std::next(it);
+    for (auto it = c->sexp_nat.begin(); it != c->sexp_nat.end();) it = it->first.compare(0, 11, "enhanceNet.") == 0 ? c->sexp_nat.erase(it) : std::next(it);
+    return calibrate_ctx(c, d_user_gray, un, uh, uw);
+}
+
 extern "C" {
 
 int disco_expected_tensors(void) { return (int)layout().t.size(); }
@@ -1222,32 +1303,7 @@ int disco_finalize(disco_ctx* c) {
     if ((rc = make_conv(c, rp + "conv9_2.0", "", rp + "conv9_2.2"))) return rc;
     if ((rc = make_upconv(c, rp + "conv10up.1"))) return rc;
     if ((rc = make_conv(c, rp + "conv10_2.1", "", ""))) return rc;
-    const std::string en = "enhanceNet.";
-    {   // input = cat(gray, 64 token features) in the reference; here source 0 = features, source 1 = 16-ch gray plane
-        // (80 packed channels in every arithmetic: the f16+fp8x2 kernel takes the gray block as its H-only tail chunk with the gray
-        // channel as (g_hi, g_lo, g_hi) against (w_h, w_h, w_l) - launch_gray_tail, conv_mx_pack_host)
-        const int cp = 80;
-        std::vector<int> map(cp, -1);
-        for (int i = 0; i < 64; ++i) map[i] = i + 1;
-        map[64] = 0;
-        if (use_mx(c, en)) { map[65] = 0; map[66] = CONV_MX_LO_OF(0); }
-        if ((rc = make_conv(c, en + "inConv.inConv.0", "", "", &map, cp))) return rc;
-    }
-    if ((rc = make_conv(c, en + "inConv.conv.0", "", en + "inConv.conv.2"))) return rc;
-    for (const char* k : {"down1", "down2"}) {
-        if ((rc = make_conv(c, en + k + ".conv.0", "", "", nullptr, 0, true))) return rc;       // down1 / down2: stride 2
-        if ((rc = make_conv(c, en + k + ".conv.2", "", en + k + ".conv.4"))) return rc;
-    }
-    for (int r = 0; r < 3; ++r)
-        for (const char* k : {"0", "1", "3"})
-            if ((rc = make_conv(c, en + "residual." + std::to_string(r) + ".conv." + k, "", ""))) return rc;
-    for (const char* k : {"up2", "up1"}) {
-        if ((rc = make_conv(c, en + k + ".conv1", "", ""))) return rc;
-        if ((rc = make_conv(c, en + k + ".combine", "", ""))) return rc;
-        if ((rc = make_conv(c, en + k + ".conv2.0", "", ""))) return rc;
-        if ((rc = make_conv(c, en + k + ".conv2.2", "", en + k + ".conv2.4"))) return rc;
-    }
-    if ((rc = make_conv(c, en + "outConv", "", "", nullptr, 0, false, false))) return rc;
+    if ((rc = make_enhance(c))) return rc;
     if ((rc = make_encoder(c, "wildpath", &c->d_enc[0]))) return rc;
     if ((rc = make_encoder(c, "hintpath", &c->d_enc[1]))) return rc;
     if ((rc = upload_vec(c, T(c, "mid_word_prj.weight").data, &c->d_mid_w))) return rc;
@@ -1257,9 +1313,11 @@ int disco_finalize(disco_ctx* c) {
     for (auto& r : GAMUT_RUNS) for (int b = r[1]; b <= r[2]; b += 10) { q.push_back((float)r[0]); q.push_back((float)b); }
     if (q.size() != 2 * N_VOCAB) { set_error("gamut table size"); return DISCO_ESTATE; }
     if ((rc = upload_vec(c, q, &c->d_q_to_ab))) return rc;
-    c->sd.clear();   // host copies are no longer needed
+    // host copies are no longer needed - except the HourGlass2's, which the channel-disparity guard may have to pack again (28 MB)
+    for (auto it = c->sd.begin(); it != c->sd.end();) it = it->first.compare(0, 11, "enhanceNet.") == 0 ? std::next(it) : c->sd.erase(it);
     c->finalized = true;
-    return calibrate_ctx(c);
+    if ((rc = calibrate_ctx(c))) return rc;
+    return enhance_disparity_guard(c);
 }
 
 int disco_calibrate(disco_ctx* c, const float* d_gray, int n, int h, int w) {
@@ -1269,7 +1327,8 @@ int disco_calibrate(disco_ctx* c, const float* d_gray, int n, int h, int w) {
     std::lock_guard<std::mutex> lk(c->mu);
     ProgressDisarm disarm{c, nullptr};
     DISCO_HIP_CHECK(hipDeviceSynchronize());      // no forward of this context may be in flight: the scales are about to change
-    return calibrate_ctx(c, d_gray, n, h, w);
+    if (int rc = calibrate_ctx(c, d_gray, n, h, w)) return rc;
+    return enhance_disparity_guard(c, d_gray, n, h, w);
 }
 
 int disco_saturation_count(disco_ctx* c, void* stream, uint64_t* count) {
@@ -1285,6 +1344,14 @@ int disco_saturation_count(disco_ctx* c, void* stream, uint64_t* count) {
 }
 
 int disco_calibration_count(disco_ctx* c) { return c ? (int)c->amax.size() : 0; }
+
+int disco_enhance_arithmetic(disco_ctx* c, int* precision, float* channel_disparity) {
+    if (!c || !precision || !channel_disparity) { set_error("null argument"); return DISCO_EINVAL; }
+    const int ar = c->opt.segnet_only ? ARITH_F16X3 : arith_of(c, "enhanceNet.outConv");
+    *precision = ar == ARITH_MX6 ? DISCO_PREC_MX6 : (ar == ARITH_F16X3 ? DISCO_PREC_F16X3 : DISCO_PREC_MX8);
+    *channel_disparity = c->mx6_disparity;
+    return DISCO_OK;
+}
 
 int disco_calibration_entry(disco_ctx* c, int i, const char** key, float* amax, int* sexp) {
     if (!c || i < 0 || i >= (int)c->amax.size() || !key || !amax || !sexp) { set_error("bad calibration index"); return DISCO_EINVAL; }

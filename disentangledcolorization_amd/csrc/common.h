@@ -281,6 +281,7 @@ float fp8_e4m3_to_float(unsigned char v);
 // fp32 NCHW -> act with optional lo / q planes (q: scale exponent sexp); and amax |x| over an act's hi plane
 int launch_nchw_to_act_mx(const float* src, const Act& dst, int c, hipStream_t s);
 int launch_act_amax(const Act& a, float* d_amax, hipStream_t s);
+int launch_act_channel_amax(const Act& a, float* d_out /* a.c floats, zero-initialised */, hipStream_t s);
 int launch_act_q_to_nchw(const Act& a, float* dst, int c, int which, hipStream_t s);   // tests: dequantised q planes
 
 size_t conv3x3_packed_bytes(int c_out, int c_in_pad);

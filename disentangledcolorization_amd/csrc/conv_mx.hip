@@ -159,6 +159,30 @@ int launch_nchw_to_act_mx(const float* src, const Act& dst, int c, hipStream_t s
     return DISCO_OK;
 }
 
+namespace {
+// max |hi| per CHANNEL of an act (calibration: the channel-disparity measure of the MX fp6 planes); out: c floats, zero-initialised
+__global__ void act_channel_amax_kernel(const f16* __restrict__ p, int n, int c, long hw, float* __restrict__ out) {
+    // hi plane [n][c/16][hw][16]: thread t of a workgroup keeps channel (t & 15) of its 16-channel block
+    const int nblk = c >> 4;
+    const int blk = blockIdx.y % nblk;
+    const long img = blockIdx.y / nblk;
+    const f16* base = p + ((img * nblk + blk) * hw) * 16;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw * 16; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf((float)base[i]));
+    // lanes with equal (lane & 15) hold the same channel: fold 64 -> 16
+    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    if ((threadIdx.x & 63) < 16) atomicMax(reinterpret_cast<unsigned int*>(out + blk * 16 + (threadIdx.x & 15)), __float_as_uint(m));
+}
+}  // namespace
+
+int launch_act_channel_amax(const Act& a, float* d_out /* a.c floats, zeroed */, hipStream_t s) {
+    const long hw = (long)a.h * a.w;
+    dim3 grid((unsigned)std::min<long>((hw * 16 + 255) / 256, 32), (unsigned)(a.n * (a.c / 16)));
+    hipLaunchKernelGGL(act_channel_amax_kernel, grid, dim3(256), 0, s, a.p, a.n, a.c, hw, d_out);
+    DISCO_LAUNCH_CHECK("act_channel_amax_kernel");
+    return DISCO_OK;
+}
+
 int launch_act_amax(const Act& a, float* d_amax, hipStream_t s) {
     hipLaunchKernelGGL(act_amax_kernel, dim3(1024), dim3(256), 0, s, a.p, (long)a.elems(), d_amax);
     DISCO_LAUNCH_CHECK("act_amax_kernel");

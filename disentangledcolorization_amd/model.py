@@ -243,7 +243,27 @@ class AnchorColorProb(nn.Module):
             L.disco_destroy(ctx)
             raise
         self._ctx, self._ctx_device = ctx, device
+        self._warn_fp8_fallback()
         return ctx
+
+    def enhance_arithmetic(self):
+        """(name, channel disparity): the arithmetic the HourGlass2 of the current context runs on - "mx6", or "mx8" when the channel-disparity
+        guard of disco_finalize / disco_calibrate moved it to fp8 corrections (include/disco_hip.h: disco_enhance_arithmetic) - and the
+        largest per-block spread of per-channel maxima the calibration passes measured on its MX-fp6 tensors."""
+        if self._ctx is None:
+            return None, 0.0
+        prec, disp = C.c_int(), C.c_float()
+        _ffi.check(_ffi.lib().disco_enhance_arithmetic(self._ctx, C.byref(prec), C.byref(disp)))
+        return {_ffi.PREC_MX6: "mx6", _ffi.PREC_MX8: "mx8", _ffi.PREC_F16X3: "f16x3"}.get(prec.value, str(prec.value)), float(disp.value)
+
+    def _warn_fp8_fallback(self):
+        name, disp = self.enhance_arithmetic()
+        if self.precision in (_ffi.PREC_MX6, _ffi.PREC_X2Q) and name == "mx8" and not getattr(self, "_fallback_warned", False):
+            import warnings
+            self._fallback_warned = True
+            warnings.warn("this checkpoint spreads the channels of a HourGlass2 tensor over a factor %.0f inside one 32-channel block: the MX-fp6 "
+                          "correction operands (one scale per block) would lose accuracy, so the HourGlass2 runs on fp8 corrections instead "
+                          "(precision \"mx8\": same accuracy as on any checkpoint, 2-3 %% slower)" % disp)
 
     def calibrate(self, input_grays):
         """Widen the activation ranges (the per-tensor scale exponents) with those of the caller's own L images (N<=64,1,H,W);
@@ -255,6 +275,7 @@ class AnchorColorProb(nn.Module):
         with torch.cuda.device(g.device):
             ctx = self._context(g.device)
             _ffi.check(_ffi.lib().disco_calibrate(ctx, _ffi.ptr(g), g.shape[0], g.shape[2], g.shape[3]))
+        self._warn_fp8_fallback()
 
     def _read_clamp_counter(self):
         cnt = C.c_uint64(0)

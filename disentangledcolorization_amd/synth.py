@@ -181,3 +181,28 @@ def student_t_variant(sd, df: float, seed: int = 7, prefixes=("repnet.", "enhanc
             out[base + "weight_u"] = torch.from_numpy(u)
             out[base + "weight_v"] = torch.from_numpy(v)
     return out
+
+
+def bn_gamma_spread_variant(sd, decades: float, seed: int = 11):
+    """The checkpoint `sd` with CHANNEL DISPARITY inside the HourGlass2's tensors: four of its BatchNorms (the ones whose outputs feed
+    convolutions only) get their affine scaled per channel by g_c = 10^U(-decades/2, +decades/2), and every consumer's weights of that
+    input channel are divided by g_c - the same function in exact arithmetic (BN is the last op of its block: conv -> ReLU -> BN,
+    network.py:10-28), but tensors whose channels differ by up to `decades` orders of magnitude, as trained BN gammas make them.  What
+    it probes: formats that share one scale over a 32-channel block (the MX fp6 planes) or one exponent per tensor.  Test data generation."""
+    import torch
+
+    rs = np.random.RandomState(seed)
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    plan = [("enhanceNet.inConv.conv.2", 64, [("enhanceNet.down1.conv.0.weight", 0), ("enhanceNet.up1.combine.weight", 64)]),
+            ("enhanceNet.down1.conv.4", 128, [("enhanceNet.down2.conv.0.weight", 0), ("enhanceNet.up2.combine.weight", 128)]),
+            ("enhanceNet.up2.conv2.4", 128, [("enhanceNet.up1.conv1.weight", 0)]),
+            ("enhanceNet.up1.conv2.4", 64, [("enhanceNet.outConv.weight", 0)])]
+    for bn, ch, consumers in plan:
+        g = torch.from_numpy((10.0 ** rs.uniform(-decades / 2, decades / 2, ch)).astype(np.float32))
+        out[bn + ".weight"] = out[bn + ".weight"] * g
+        out[bn + ".bias"] = out[bn + ".bias"] * g
+        for key, off in consumers:
+            w = out[key].clone()
+            w[:, off:off + ch] = w[:, off:off + ch] / g[None, :, None, None]
+            out[key] = w
+    return out

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 7
+#define DISCO_ABI_VERSION 8
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -169,6 +169,13 @@ int disco_calibrate(disco_ctx *ctx, const float *d_gray, int n, int h, int w);
  * for a tensor that is not finite, or for two tensors that are concatenated on read whose ranges differ by more than 2^10 (they
  * must share one exponent); a failing disco_calibrate leaves the previous calibration in place. */
 int disco_calibration_count(disco_ctx *ctx);
+/* ABI 8.  The arithmetic the HourGlass2 of this context actually runs on (DISCO_PREC_MX6, DISCO_PREC_MX8 or DISCO_PREC_F16X3) and the
+ * channel disparity the calibration passes measured on its MX-fp6 tensors: per 32-channel block the largest per-channel max |x| over the
+ * lower quartile of the block's live channels, maximised over blocks and tensors.  MX fp6 planes share one scale per pixel and 32 channels, so a channel far below its
+ * block's largest loses its correction operands; when the disparity exceeds 64 (the synthetic checkpoint reads 9; a checkpoint whose BatchNorm affines spread
+ * the channels of a tensor over ~1.5 decades and more reads 78 and more) disco_finalize / disco_calibrate rebuild the HourGlass2 on fp8 corrections (e4m3: 4 exponent bits) - same
+ * accuracy as DISCO_PREC_MX8, 2-3 % slower - and *precision reports DISCO_PREC_MX8 although the context was created with DISCO_PREC_MX6. */
+int disco_enhance_arithmetic(disco_ctx *ctx, int *precision, float *channel_disparity);
 int disco_calibration_entry(disco_ctx *ctx, int i, const char **key, float *amax, int *sexp);
 /* SpixelSeg.forward(gray) -> affinity (n,9,h,w), softmax over the 9 neighbour slots (models/network.py:293-313).
  * Works on full and segnet_only contexts; workspace as reported by disco_workspace_bytes. */

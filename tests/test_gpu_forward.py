@@ -668,6 +668,40 @@ def test_checkpoints_with_heavy_tailed_weights(synth_sd, q_to_ab, df):
     assert e <= 5e-4
 
 
+@pytest.mark.parametrize("decades", [1.0, 3.0])
+def test_channel_disparity_guard(synth_sd, q_to_ab, decades):
+    """Round 4: MX fp6 planes share one scale per pixel and 32 CHANNELS.  synth.bn_gamma_spread_variant spreads the per-channel scale of four
+    HourGlass2 tensors over `decades` orders of magnitude and divides the consumers' weights accordingly - the same function for the fp32
+    oracle, but inside a block the small channels lose their fp6 correction operands while their (large) weights still matter: measured
+    max|ab| 1.6e-4 / 2.6e-4 / 6.8e-4 / 1.0e-3 at 1 / 1.5 / 2 / 3 decades (profiles/r04_channel_disparity.txt; fp8 corrections: 1.1e-4 at all of
+    them).  disco_finalize measures the disparity in its calibration pass and rebuilds the HourGlass2 on fp8 corrections beyond a measured spread of
+    64 within a block (the plain checkpoint reads 9, one decade 37, three decades 1 153): one decade stays on fp6, three decades fall back (with a warning) and are as accurate as the plain checkpoint."""
+    import warnings
+    sd = synth.bn_gamma_spread_variant(synth_sd, decades)
+    m = AnchorColorProb(n_clusters=8, enhanced=True, init_weights=False)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    gray, ab = synth.synth_inputs(2, 128, 128, seed=19)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        _seed(130); out = m(gray.cuda(), ab.cuda(), True, 0)
+        torch.cuda.synchronize()
+    name, disp = m.enhance_arithmetic()
+    _seed(130); want = R.DiscoOracle(sd, q_to_ab, n_clusters=8).forward(gray, ab)
+    e = _err(out[2], want[2])
+    print(f"BN gamma spread {decades} decades: HourGlass2 on {name} (measured block disparity {disp:.1f}), max|ab - ab_ref| = {e:.3e}")
+    assert torch.equal(out[5].cpu(), want[5]), "anchors"
+    if decades <= 1.0:
+        assert name == "mx6" and disp <= 64 and not [w for w in rec if "fp8 corrections" in str(w.message)]
+        assert e <= 2.5e-4
+    else:
+        assert name == "mx8" and disp > 64 and [w for w in rec if "fp8 corrections" in str(w.message)]
+        assert e <= 2e-4
+    # the plain checkpoint is nowhere near the limit
+    n0, d0 = _model(synth_sd, 8).enhance_arithmetic() if _model(synth_sd, 8)._ctx is not None else ("mx6", 0.0)
+    assert n0 in ("mx6", None) or os.environ.get("DISCO_PRECISION")
+
+
 def test_out_of_range_input_recalibrates_itself(synth_sd, q_to_ab):
     """The scales are fixed at load time on two synthetic images with |L| <= 1.  precision="mx8": an input 400x outside that range
     clamps the fp8 planes of the HourGlass2 (14x headroom): one of the first forwards of a context notices (clamp counter), warns,

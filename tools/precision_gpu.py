@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--modes", default="mx6,mx8,x2q,f16x3")
     ap.add_argument("--weights", default="", help="e.g. t4,t3: Student-t redraws of the 3x3 conv weights instead of the usual cases; run once more with "
                     "DISCO_MX6_ROW_SCALE=1 in the environment for round 3's one-exponent-per-row fp6 weight scaling")
+    ap.add_argument("--gamma", default="", help="e.g. 1,2,3: HourGlass2 BN affines spread per channel over that many decades, compensated in the consumers' weights "
+                    "(synth.bn_gamma_spread_variant): channel disparity inside the block-scaled tensors")
     ap.add_argument("--quick", action="store_true", help="three inputs on the synthetic checkpoint and one stress checkpoint")
     args = ap.parse_args()
     torch.set_num_threads(min(32, os.cpu_count()))       # (one thread per core of a 256-core host thrashes: minutes per oracle forward)
@@ -51,6 +53,10 @@ def main():
                 cases.append(("%s enhanceNet w%d" % (tag, wseed), synth.student_t_variant(base, df, wseed, ("enhanceNet.",)), 19, 2, 128, 128))
             cases.append(("%s repnet+enhanceNet" % tag, synth.student_t_variant(base, df, 7), 19, 2, 128, 128))
         cases.append(("gaussian (synth 130)", base, 19, 2, 128, 128))
+    if args.gamma:
+        cases = [("gaussian (synth 130)", base, 19, 2, 128, 128)]
+        for d in args.gamma.split(","):
+            cases.append(("BN gamma spread %s decades" % d, synth.bn_gamma_spread_variant(base, float(d)), 19, 2, 128, 128))
     worst = {}
     models = {}
 
@@ -73,7 +79,8 @@ def main():
             e = (out[2].cpu().double() - want[2].double()).abs().max().item()
             same = torch.equal(out[5].cpu(), want[5])
             worst[mode] = max(worst.get(mode, 0.0), e)
-            line += f"  {mode} {e:.2e}{'' if same else ' ANCHORS DIFFER'}"
+            ar, disp = m.enhance_arithmetic()
+            line += f"  {mode} {e:.2e}{'' if same else ' ANCHORS DIFFER'}" + (f" [HourGlass2 on {ar}, block disparity {disp:.1f}]" if mode in ("mx6", "x2q") else "")
         print(line, flush=True)
     print("worst: " + "  ".join(f"{k} {v:.2e}" for k, v in worst.items()))
 
