@@ -326,6 +326,7 @@ def main():
             ar, disp = model.enhance_arithmetic()
             out["hourglass2_arithmetic"] = ar
             out["mx6_channel_disparity"] = round(disp, 1)
+            out["mx6_channel_disparity_before_equalisation"] = round(model.equalised_from(), 1)
         if model is not None:
             achieved = conv_fl / (conv_ms * 1e-3) if conv_ms > 0 else 0.0
             out["roofline"] = {

@@ -72,7 +72,7 @@ SIGNATURES = {
     "disco_calibrate": (_I, [_P, _P, _I, _I, _I]),
     "disco_saturation_count": (_I, [_P, _P, C.POINTER(C.c_uint64)]),
     "disco_calibration_count": (_I, [_P]),
-    "disco_enhance_arithmetic": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_float)]),
+    "disco_enhance_arithmetic": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "disco_calibration_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
     "disco_forward_segnet": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "disco_sync": (_I, [_P]),

@@ -189,6 +189,12 @@ struct disco_ctx {
     float mx6_disparity = 0.f;
     std::string mx6_disparity_key;
     bool enhance_fp8_fallback = false;
+    // Cross-layer channel equalisation of the HourGlass2 (plan_equalisation): per conv layer the power-of-two factor every OUTPUT channel is
+    // multiplied by (weight rows + bias, or the BN affine behind the activation) and every INPUT channel's weights are multiplied by (the
+    // inverse of its producer's factor) - the network function is unchanged in exact arithmetic, the tensors in between get level channels
+    std::map<std::string, std::vector<float>> eq_out, eq_in, chan_amax;
+    bool equalised = false;
+    float mx6_disparity_before_eq = 0.f;
     // One host thread at a time inside a context: the forward entry points, calibration and the setters below lock this.  The GPU work
     // of successive calls still overlaps across the streams they were given; what is serialised is the host-side issue (staging ring,
     // one-shot progress event, profiling vectors, calibration tables are plain members).
@@ -353,6 +359,21 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
             bias[o] = bias[o] * sc[o] + sh[o];
         }
     }
+    std::vector<float> post_sc, post_sh;
+    if (!post_bn.empty()) bn_affine(c, post_bn, post_sc, post_sh);
+    {   // channel equalisation (exact: powers of two): input columns, then the output side - through the BN affine when the layer has one
+        // behind its activation (x 2^k commutes with ReLU / LeakyReLU), else through the weight rows and the bias
+        auto ei = c->eq_in.find(key), eo = c->eq_out.find(key);
+        if (ei != c->eq_in.end() && (int)ei->second.size() == ci)
+            for (int o = 0; o < co; ++o)
+                for (int i = 0; i < ci; ++i)
+                    for (int t = 0; t < 9; ++t) w[((size_t)o * ci + i) * 9 + t] *= ei->second[i];
+        if (eo != c->eq_out.end() && (int)eo->second.size() == co)
+            for (int o = 0; o < co; ++o) {
+                if (!post_bn.empty()) { post_sc[o] *= eo->second[o]; post_sh[o] *= eo->second[o]; }
+                else { for (int i = 0; i < ci * 9; ++i) w[(size_t)o * ci * 9 + i] *= eo->second[o]; bias[o] *= eo->second[o]; }
+            }
+    }
     ConvLayer L;
     L.c_in = ci; L.c_out = co; L.c_real = co;
     int rc;
@@ -362,10 +383,8 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
         if ((rc = finish_mx(c, L, w, co, ci, ci_map ? ci_map->data() : nullptr, cpad, act_out, x2q))) return rc;
         if ((rc = upload_padded(c, bias, (size_t)L.c_out_k, 0.f, &L.d_bias))) return rc;
         if (!post_bn.empty()) {
-            std::vector<float> sc, sh;
-            bn_affine(c, post_bn, sc, sh);
-            if ((rc = upload_padded(c, sc, (size_t)L.c_out_k, 1.f, &L.d_bn_scale))) return rc;
-            if ((rc = upload_padded(c, sh, (size_t)L.c_out_k, 0.f, &L.d_bn_shift))) return rc;
+            if ((rc = upload_padded(c, post_sc, (size_t)L.c_out_k, 1.f, &L.d_bn_scale))) return rc;
+            if ((rc = upload_padded(c, post_sh, (size_t)L.c_out_k, 0.f, &L.d_bn_shift))) return rc;
         }
         c->conv[key] = L;
         return DISCO_OK;
@@ -380,10 +399,8 @@ int make_conv(disco_ctx* c, const std::string& key, const std::string& fold_bn, 
     if (rc) return rc;
     if ((rc = upload_vec(c, bias, &L.d_bias))) return rc;
     if (!post_bn.empty()) {
-        std::vector<float> sc, sh;
-        bn_affine(c, post_bn, sc, sh);
-        if ((rc = upload_vec(c, sc, &L.d_bn_scale))) return rc;
-        if ((rc = upload_vec(c, sh, &L.d_bn_shift))) return rc;
+        if ((rc = upload_vec(c, post_sc, &L.d_bn_scale))) return rc;
+        if ((rc = upload_vec(c, post_sh, &L.d_bn_shift))) return rc;
     }
     c->conv[key] = L;
     return DISCO_OK;
@@ -649,6 +666,11 @@ struct Plan {
         if (ok() && (hipMemcpyAsync(h.data(), d, (size_t)t.c * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = hip_fail(hipGetLastError(), "channel amax");
         drop(d);
         if (!ok()) return;
+        {
+            std::vector<float>& acc = c->chan_amax[key];
+            if (acc.size() != h.size()) acc.assign(h.size(), 0.f);
+            for (size_t i = 0; i < h.size(); ++i) acc[i] = std::max(acc[i], std::ldexp(h[i], -t.sexp));       // true values
+        }
         for (int b = 0; b + 32 <= t.c; b += 32) {
             // channels that never fire on the calibration images (ReLU-dead: max 0) carry nothing and are left out; of the live ones the
             // largest against the lower quartile: a quarter of a block's channels below 1/64 of its maximum is where fp6 starts to cost
@@ -1171,21 +1193,106 @@ int make_enhance(disco_ctx* c) {
     return DISCO_OK;
 }
 
+// Cross-layer channel equalisation of the HourGlass2 (round 4).  Every tensor between two of its convs has ONE producer - or, along the residual
+// chain (y = relu(x + F(x)), network.py:45-47), one class of producers that must share their factors - and known consumers, so each channel c of a
+// tensor can be multiplied by s_c = 2^k at its producer(s) and divided at its consumers: exact in fp32 (powers of two), ReLU / LeakyReLU commute
+// with positive factors, and the tensors in between come out with level channels - which is what a format that shares one scale over 32
+// channels of a pixel needs.  s_c lifts every channel's calibration maximum to within a factor 2 of the tensor's largest (never down; at most 2^12).
+struct EqTensor { std::vector<std::string> producers; int channels; std::vector<std::pair<std::string, int>> consumers; };
+const std::vector<EqTensor>& enhance_tensors() {
+    static const std::vector<EqTensor> t = [] {
+        const std::string en = "enhanceNet.";
+        std::vector<EqTensor> v = {
+            {{en + "inConv.inConv.0"}, 64, {{en + "inConv.conv.0", 0}}},
+            {{en + "inConv.conv.0"}, 64, {{en + "down1.conv.0", 0}, {en + "up1.combine", 64}}},
+            {{en + "down1.conv.0"}, 128, {{en + "down1.conv.2", 0}}},
+            {{en + "down1.conv.2"}, 128, {{en + "down2.conv.0", 0}, {en + "up2.combine", 128}}},
+            {{en + "down2.conv.0"}, 256, {{en + "down2.conv.2", 0}}},
+            {{en + "down2.conv.2", en + "residual.0.conv.3", en + "residual.1.conv.3", en + "residual.2.conv.3"}, 256,
+             {{en + "residual.0.conv.0", 0}, {en + "residual.1.conv.0", 0}, {en + "residual.2.conv.0", 0}, {en + "up2.conv1", 0}}},
+            {{en + "up2.conv1"}, 128, {{en + "up2.combine", 0}}},
+            {{en + "up2.combine"}, 128, {{en + "up2.conv2.0", 0}}},
+            {{en + "up2.conv2.0"}, 128, {{en + "up2.conv2.2", 0}}},
+            {{en + "up2.conv2.2"}, 128, {{en + "up1.conv1", 0}}},
+            {{en + "up1.conv1"}, 64, {{en + "up1.combine", 0}}},
+            {{en + "up1.combine"}, 64, {{en + "up1.conv2.0", 0}}},
+            {{en + "up1.conv2.0"}, 64, {{en + "up1.conv2.2", 0}}},
+            {{en + "up1.conv2.2"}, 64, {{en + "outConv", 0}}},
+        };
+        for (int r = 0; r < 3; ++r) {
+            const std::string k = en + "residual." + std::to_string(r) + ".conv.";
+            v.push_back({{k + "0"}, 256, {{k + "1", 0}}});
+            v.push_back({{k + "1"}, 256, {{k + "3", 0}}});
+        }
+        return v;
+    }();
+    return t;
+}
+// fills c->eq_out / c->eq_in from the per-channel maxima of the last calibration pass; false when a tensor has not been measured
+bool plan_equalisation(disco_ctx* c) {
+    std::map<std::string, std::vector<float>> eo, ei;
+    auto widths = [&](const std::string& key) -> int { auto it = c->conv.find(key); return it == c->conv.end() ? 0 : it->second.c_in; };
+    for (const EqTensor& t : enhance_tensors()) {
+        std::vector<float> a(t.channels, 0.f);
+        for (const std::string& p : t.producers) {
+            auto it = c->chan_amax.find(p);
+            if (it == c->chan_amax.end() || (int)it->second.size() < t.channels) return false;
+            for (int i = 0; i < t.channels; ++i) a[i] = std::max(a[i], it->second[i]);
+        }
+        const float top = *std::max_element(a.begin(), a.end());
+        if (!(top > 0.f)) continue;
+        std::vector<float> sc(t.channels, 1.f);
+        for (int i = 0; i < t.channels; ++i)
+            if (a[i] > 0.f) {
+                int k = (int)std::floor(std::log2(top / a[i]));
+                sc[i] = std::ldexp(1.f, std::min(std::max(k, 0), 12));
+            }
+        for (const std::string& p : t.producers) eo[p] = sc;
+        for (const auto& cons : t.consumers) {
+            const int ci = widths(cons.first);
+            if (ci <= 0 || cons.second + t.channels > ci) return false;
+            std::vector<float>& v = ei[cons.first];
+            if (v.empty()) v.assign(ci, 1.f);
+            for (int i = 0; i < t.channels; ++i) v[cons.second + i] = 1.f / sc[i];
+        }
+    }
+    c->eq_out = eo; c->eq_in = ei;
+    return true;
+}
+
 // MX fp6 planes tolerate this much spread between the per-channel maxima of a 32-channel block before the
 // HourGlass2 is moved to fp8 corrections (largest over lower quartile of the live channels): tools/precision_gpu.py --gamma (profiles/r04_channel_disparity.txt) measures max|ab| 1.6e-4 at one
 // decade of spread, 2.6e-4 at 1.5, 6.8e-4 at 2 and 1.0e-3 at 3, against 1.1e-4 for fp8 at any of them; with this measure the synthetic checkpoint reads 9, its Student-t variants 10-20, the four spreads 37 / 78 / 159 / 1 153
 constexpr float MX6_DISPARITY_LIMIT = 64.f;
 // after a calibration pass: rebuild the HourGlass2 on fp8 corrections and calibrate again when the measured disparity asks for it
+// Channels levelled first (keeps fp6) when a block's spread exceeds this; the plain synthetic checkpoint (9) is left as it is
+constexpr float MX6_EQUALISE_ABOVE = 16.f;
 int enhance_disparity_guard(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, int uh = 0, int uw = 0) {
-    if (c->opt.segnet_only || c->enhance_fp8_fallback || arith_of(c, "enhanceNet.outConv") != ARITH_MX6 || !(c->mx6_disparity > MX6_DISPARITY_LIMIT)) return DISCO_OK;
+    if (c->opt.segnet_only || c->enhance_fp8_fallback || arith_of(c, "enhanceNet.outConv") != ARITH_MX6) return DISCO_OK;
     if (!c->sd.count("enhanceNet.outConv.weight")) return DISCO_OK;      // (host weights gone: cannot happen after disco_finalize)
+    auto rebuild = [&]() -> int {
+        // the old layers' device buffers stay in c->allocs until disco_destroy (a few tens of MB); the tensors' exponents and maxima are measured again
+        int rc = make_enhance(c);
+        if (rc) return rc;
+        for (auto* m : {&c->sexp, &c->sexp_nat})
+            for (auto it = m->begin(); it != m->end();) it = it->first.compare(0, 11, "enhanceNet.") == 0 ? m->erase(it) : std::next(it);
+        for (auto it = c->amax.begin(); it != c->amax.end();) it = it->first.compare(0, 11, "enhanceNet.") == 0 ? c->amax.erase(it) : std::next(it);
+        c->chan_amax.clear();
+        c->mx6_disparity = 0.f;
+        return calibrate_ctx(c, d_user_gray, un, uh, uw);
+    };
+    static const bool no_eq = std::getenv("DISCO_NO_EQUALISE") != nullptr;       // (tests of the fp8 fallback)
+    if (!c->equalised && !no_eq && c->mx6_disparity > MX6_EQUALISE_ABOVE && plan_equalisation(c)) {
+        c->equalised = true;
+        c->mx6_disparity_before_eq = c->mx6_disparity;
+        if (int rc = rebuild()) return rc;
+    }
+    if (!(c->mx6_disparity > MX6_DISPARITY_LIMIT)) return DISCO_OK;
     c->enhance_fp8_fallback = true;
-    // the old layers' device buffers stay in c->allocs until disco_destroy (a few tens of MB); their exponents are measured again
-    int rc = make_enhance(c);
-    if (rc) return rc;
-    for (auto it = c->sexp.begin(); it != c->sexp.end();) it = it->first.compare(0, 11, "enhanceNet.") == 0 ? c->sexp.erase(it) : std::next(it);
-    for (auto it = c->sexp_nat.begin(); it != c->sexp_nat.end();) it = it->first.compare(0, 11, "enhanceNet.") == 0 ? c->sexp_nat.erase(it) : std::next(it);
-    return calibrate_ctx(c, d_user_gray, un, uh, uw);
+    const float measured = c->mx6_disparity;          // (no fp6 tensor is left to measure after the rebuild: keep what decided it)
+    const int rc = rebuild();
+    c->mx6_disparity = measured;
+    return rc;
 }
 
 extern "C" {
@@ -1345,8 +1452,9 @@ int disco_saturation_count(disco_ctx* c, void* stream, uint64_t* count) {
 
 int disco_calibration_count(disco_ctx* c) { return c ? (int)c->amax.size() : 0; }
 
-int disco_enhance_arithmetic(disco_ctx* c, int* precision, float* channel_disparity) {
-    if (!c || !precision || !channel_disparity) { set_error("null argument"); return DISCO_EINVAL; }
+int disco_enhance_arithmetic(disco_ctx* c, int* precision, float* channel_disparity, float* disparity_before_equalisation) {
+    if (!c || !precision || !channel_disparity || !disparity_before_equalisation) { set_error("null argument"); return DISCO_EINVAL; }
+    *disparity_before_equalisation = c->equalised ? c->mx6_disparity_before_eq : 0.f;
     const int ar = c->opt.segnet_only ? ARITH_F16X3 : arith_of(c, "enhanceNet.outConv");
     *precision = ar == ARITH_MX6 ? DISCO_PREC_MX6 : (ar == ARITH_F16X3 ? DISCO_PREC_F16X3 : DISCO_PREC_MX8);
     *channel_disparity = c->mx6_disparity;

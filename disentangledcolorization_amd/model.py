@@ -249,12 +249,19 @@ class AnchorColorProb(nn.Module):
     def enhance_arithmetic(self):
         """(name, channel disparity): the arithmetic the HourGlass2 of the current context runs on - "mx6", or "mx8" when the channel-disparity
         guard of disco_finalize / disco_calibrate moved it to fp8 corrections (include/disco_hip.h: disco_enhance_arithmetic) - and the
-        largest per-block spread of per-channel maxima the calibration passes measured on its MX-fp6 tensors."""
+        largest per-block spread of per-channel maxima the last calibration pass measured on its MX-fp6 tensors (after the channel
+        equalisation, if one was applied: `equalised_from()` has the spread before it)."""
         if self._ctx is None:
             return None, 0.0
-        prec, disp = C.c_int(), C.c_float()
-        _ffi.check(_ffi.lib().disco_enhance_arithmetic(self._ctx, C.byref(prec), C.byref(disp)))
+        prec, disp, before = C.c_int(), C.c_float(), C.c_float()
+        _ffi.check(_ffi.lib().disco_enhance_arithmetic(self._ctx, C.byref(prec), C.byref(disp), C.byref(before)))
+        self._eq_before = float(before.value)
         return {_ffi.PREC_MX6: "mx6", _ffi.PREC_MX8: "mx8", _ffi.PREC_F16X3: "f16x3"}.get(prec.value, str(prec.value)), float(disp.value)
+
+    def equalised_from(self):
+        """The channel disparity measured BEFORE the HourGlass2's channels were levelled at load time (0.0: no equalisation was needed)."""
+        self.enhance_arithmetic()
+        return getattr(self, "_eq_before", 0.0)
 
     def _warn_fp8_fallback(self):
         name, disp = self.enhance_arithmetic()

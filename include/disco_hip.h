@@ -169,13 +169,16 @@ int disco_calibrate(disco_ctx *ctx, const float *d_gray, int n, int h, int w);
  * for a tensor that is not finite, or for two tensors that are concatenated on read whose ranges differ by more than 2^10 (they
  * must share one exponent); a failing disco_calibrate leaves the previous calibration in place. */
 int disco_calibration_count(disco_ctx *ctx);
-/* ABI 8.  The arithmetic the HourGlass2 of this context actually runs on (DISCO_PREC_MX6, DISCO_PREC_MX8 or DISCO_PREC_F16X3) and the
- * channel disparity the calibration passes measured on its MX-fp6 tensors: per 32-channel block the largest per-channel max |x| over the
- * lower quartile of the block's live channels, maximised over blocks and tensors.  MX fp6 planes share one scale per pixel and 32 channels, so a channel far below its
- * block's largest loses its correction operands; when the disparity exceeds 64 (the synthetic checkpoint reads 9; a checkpoint whose BatchNorm affines spread
- * the channels of a tensor over ~1.5 decades and more reads 78 and more) disco_finalize / disco_calibrate rebuild the HourGlass2 on fp8 corrections (e4m3: 4 exponent bits) - same
- * accuracy as DISCO_PREC_MX8, 2-3 % slower - and *precision reports DISCO_PREC_MX8 although the context was created with DISCO_PREC_MX6. */
-int disco_enhance_arithmetic(disco_ctx *ctx, int *precision, float *channel_disparity);
+/* ABI 8.  The arithmetic the HourGlass2 of this context actually runs on (DISCO_PREC_MX6, DISCO_PREC_MX8 or DISCO_PREC_F16X3) and the channel
+ * disparity the calibration passes measured on its MX-fp6 tensors: per 32-channel block the largest per-channel max |x| over the lower quartile of
+ * the block's live channels, maximised over blocks and tensors.  MX fp6 planes share one scale per pixel and 32 channels, so a channel far below
+ * its block's largest loses its correction operands - harmful when the consumer's weights make up for the difference, as trained BatchNorm affines
+ * can.  disco_finalize / disco_calibrate therefore (1) above a disparity of 16 level the channels of every tensor inside the HourGlass2 with
+ * power-of-two factors folded into the producers' output channels and the consumers' input channels (exact in fp32: the network function does
+ * not change; *disparity_before_equalisation then holds the first measurement, else 0) and measure again, and (2) if the disparity still exceeds 64,
+ * rebuild the HourGlass2 on fp8 corrections (e4m3: 4 exponent bits; same accuracy as DISCO_PREC_MX8, 2-3 % slower): *precision then reports
+ * DISCO_PREC_MX8 although the context was created with DISCO_PREC_MX6.  The synthetic checkpoint reads 9 and is left alone. */
+int disco_enhance_arithmetic(disco_ctx *ctx, int *precision, float *channel_disparity, float *disparity_before_equalisation);
 int disco_calibration_entry(disco_ctx *ctx, int i, const char **key, float *amax, int *sexp);
 /* SpixelSeg.forward(gray) -> affinity (n,9,h,w), softmax over the 9 neighbour slots (models/network.py:293-313).
  * Works on full and segnet_only contexts; workspace as reported by disco_workspace_bytes. */

@@ -80,7 +80,7 @@ def main():
             same = torch.equal(out[5].cpu(), want[5])
             worst[mode] = max(worst.get(mode, 0.0), e)
             ar, disp = m.enhance_arithmetic()
-            line += f"  {mode} {e:.2e}{'' if same else ' ANCHORS DIFFER'}" + (f" [HourGlass2 on {ar}, block disparity {disp:.1f}]" if mode in ("mx6", "x2q") else "")
+            line += f"  {mode} {e:.2e}{'' if same else ' ANCHORS DIFFER'}" + (f" [HourGlass2 on {ar}, block disparity {disp:.1f}" + (f", levelled from {m.equalised_from():.1f}" if m.equalised_from() else "") + "]" if mode in ("mx6", "x2q") else "")
         print(line, flush=True)
     print("worst: " + "  ".join(f"{k} {v:.2e}" for k, v in worst.items()))
 
