@@ -1197,7 +1197,7 @@ int make_enhance(disco_ctx* c) {
 // chain (y = relu(x + F(x)), network.py:45-47), one class of producers that must share their factors - and known consumers, so each channel c of a
 // tensor can be multiplied by s_c = 2^k at its producer(s) and divided at its consumers: exact in fp32 (powers of two), ReLU / LeakyReLU commute
 // with positive factors, and the tensors in between come out with level channels - which is what a format that shares one scale over 32
-// channels of a pixel needs.  s_c lifts every channel's calibration maximum to within a factor 2 of the tensor's largest (never down; at most 2^12).
+// channels of a pixel needs.  s_c lifts every channel's calibration maximum to within a factor 2 of the tensor's largest (never down; by 2^6 at most).
 struct EqTensor { std::vector<std::string> producers; int channels; std::vector<std::pair<std::string, int>> consumers; };
 const std::vector<EqTensor>& enhance_tensors() {
     static const std::vector<EqTensor> t = [] {
@@ -1245,7 +1245,9 @@ bool plan_equalisation(disco_ctx* c) {
         for (int i = 0; i < t.channels; ++i)
             if (a[i] > 0.f) {
                 int k = (int)std::floor(std::log2(top / a[i]));
-                sc[i] = std::ldexp(1.f, std::min(std::max(k, 0), 12));
+                // (at most 2^6: a channel that is almost silent on the calibration images may be as loud as the others on real ones, and
+                // a factor 2^6 then still leaves 2^5 of the tensor's 2^11 fp16 headroom)
+                sc[i] = std::ldexp(1.f, std::min(std::max(k, 0), 6));
             }
         for (const std::string& p : t.producers) eo[p] = sc;
         for (const auto& cons : t.consumers) {
