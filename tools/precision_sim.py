@@ -121,6 +121,8 @@ class Emu:
             y = cv(ah, wh) + cv(q8_tensor(ah), q8_tensor(wl))
         elif mode == "mx6b":     # both corrections in fp6 e2m3 with MX block scales (per pixel / per cout and tap, 32 channels)
             y = cv(ah, wh) + cv(q6_block(al, 1), q6_block(wh, 1)) + cv(q6_block(ah, 1), q6_block(wl, 1))
+        elif mode == "mx6w1":    # only the weight residual corrected (block-scaled fp6), the activation residual dropped
+            y = cv(ah, wh) + cv(q6_block(ah, 1), q6_block(wl, 1))
         elif mode == "mx6u":     # fp6 with ONE scale per tensor (weights: per cout row)
             y = cv(ah, wh) + cv(q6_tensor(al), q6_block(wh, 1)) + cv(q6_tensor(ah), q6_block(wl, 1))
         elif mode == "mx6uh":    # ... with 2 bits of calibration headroom on the activation side
