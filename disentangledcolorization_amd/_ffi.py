@@ -75,6 +75,9 @@ SIGNATURES = {
     "disco_enhance_arithmetic": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "disco_calibration_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),
     "disco_forward_segnet": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "disco_forward_repnet": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "disco_forward_enhance": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "disco_subnet_workspace_bytes": (_I, [_P, _I, _I, _I, _I, C.POINTER(_SZ)]),
     "disco_sync": (_I, [_P]),
     "disco_set_profiling": (_I, [_P, _I]),
     "disco_set_progress_event": (_I, [_P, _P, _I]),

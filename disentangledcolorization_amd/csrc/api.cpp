@@ -814,6 +814,131 @@ void segnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int 
     P.drop(cc);
 }
 
+// a2 ColorProbNet (network.py:220-236): gray (n,1,H,W) fp32 -> the 64-channel full-resolution feature tensor (fp16 hi + lo planes)
+Act repnet_stage(Plan& P, disco_ctx* c, const float* d_gray, int n, int H, int W) {
+    const std::string rp = "repnet.";
+    P.stage_arith = arith_of(c, rp);
+    // conv1_2.0 (Cin = 1) is not a launch of its own when its consumer runs on the 32 x 16 x 64 tile with enough tiles to fill the GPU: conv1_2.2
+    // then computes its input tiles in LDS from the gray image, with the stand-alone kernel's arithmetic (bit-identical either way), and the
+    // 64-channel full-resolution tensor in between (4 B per element: 1.07 GB at 64 x 256^2) is never written or read.  The calibration pass
+    // and the workspace sizing take the two-launch form (the tensor's exponent is measured on the stand-alone kernel).
+    static const bool fuse_env = [] { const char* e = std::getenv("DISCO_FUSE_C1"); return !e || std::atoi(e) != 0; }();
+    const bool fuse_c1 = fuse_env && !P.dry && !P.calib && P.stage_arith == ARITH_F16X3 && W > 16 && H > 8 &&
+                         (long)((W + 31) / 32) * ((H + 15) / 16) * n >= (long)num_cus_current() * 3 / 4;
+    Act t{}, f{};
+    if (fuse_c1) {
+        Act v{};
+        v.n = n; v.h = H; v.w = W; v.c = 64;
+        if (P.scale_of(rp + "conv1_2.0", &v.sexp)) {
+            const Plan::FusedC1 fc{d_gray, &c->direct.at(rp + "conv1_2.0"), LRELU, 0.2f};
+            P.fuse = &fc;
+            f = P.conv(rp + "conv1_2.2", v, nullptr, 0, 0, 1, LRELU, 0.2f);
+            P.fuse = nullptr;
+        }
+    } else {
+        t = P.c1(rp + "conv1_2.0", d_gray, n, H, W, LRELU, 0.2f);
+        f = P.conv(rp + "conv1_2.2", t, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(t);
+    }
+    Act f3{};
+    const char* blk[6] = {"conv2_3", "conv3_3", "conv4_3", "conv5_3", "conv6_3", "conv7_3"};
+    for (int b = 0; b < 6; ++b) {
+        const std::string k = rp + blk[b];
+        Act x1 = P.conv(k + ".0", f, nullptr, 0, 0, b < 3 ? 2 : 1, LRELU, 0.2f);
+        if (b != 2) P.drop(f);   // b == 2: f is f3_3, kept alive for the conv3short8 shortcut
+        Act x2 = P.conv(k + ".2", x1, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(x1);
+        f = P.conv(k + ".4", x2, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(x2);
+        if (b == 1) f3 = f;
+    }
+    Act sh = P.conv(rp + "conv3short8.0", f3, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, Plan::F_LO);   // residual only
+    P.drop(f3);
+    Act f8 = P.conv(rp + "conv8up.1", f, nullptr, 0, 0, 1, RELU, 0.f, &sh, nullptr, true); P.drop(sh); P.drop(f);
+    t = P.conv(rp + "conv8_3.1", f8, nullptr, 0, 0, 1, RELU, 0.f); P.drop(f8);
+    f8 = P.conv(rp + "conv8_3.3", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
+    t = P.conv(rp + "conv9up.1", f8, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, true); P.drop(f8);
+    Act f9 = P.conv(rp + "conv9_2.0", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
+    t = P.conv(rp + "conv10up.1", f9, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, true); P.drop(f9);
+    Act feats = P.conv(rp + "conv10_2.1", t, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, false, false, Plan::F_LO); P.drop(t);   // pooled, not convolved
+    return feats;
+}
+
+// a13 HourGlass2 (network.py:125-144) from its two input tensors - the 64 feature channels and the 16-channel gray block - to (n,2,H,W) fp32 NCHW;
+// out_act: DISCO_ACT_TANH inside the colorizer (model.py:197), NOACT for the stand-alone network
+void enhance_stage(Plan& P, disco_ctx* c, Act full, Act g16, int out_act, float* d_out) {
+    (void)c;
+    const std::string en = "enhanceNet.";
+    Act t = P.conv(en + "inConv.inConv.0", full, &g16, 0, 0, 1, RELU, 0.f); P.drop(full); P.drop(g16);
+    Act e1 = P.conv(en + "inConv.conv.0", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
+    t = P.conv(en + "down1.conv.0", e1, nullptr, 0, 0, 2, RELU, 0.f);
+    Act e2 = P.conv(en + "down1.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
+    t = P.conv(en + "down2.conv.0", e2, nullptr, 0, 0, 2, RELU, 0.f);
+    const int rfmt = P.mx() ? (Plan::F_LO | P.dfmt()) : Plan::F_LO;      // residual-chain tensors: convolved AND added back
+    Act x = P.conv(en + "down2.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, false, false, rfmt); P.drop(t);
+    for (int r = 0; r < 3; ++r) {
+        const std::string k = en + "residual." + std::to_string(r) + ".conv.";
+        Act t1 = P.conv(k + "0", x, nullptr, 0, 0, 1, NOACT, 0.f);
+        Act t2 = P.conv(k + "1", t1, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t1);
+        Act y = P.conv(k + "3", t2, nullptr, 0, 0, 1, RELU, 0.f, &x, nullptr, false, false, rfmt); P.drop(t2); P.drop(x);
+        x = y;
+    }
+    t = P.conv(en + "up2.conv1", x, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, -1, en + "down1.conv.2"); P.drop(x);      // concatenated with e2
+    Act u = P.conv(en + "up2.combine", t, &e2, 1, 0, 1, RELU, 0.f); P.drop(t); P.drop(e2);
+    t = P.conv(en + "up2.conv2.0", u, nullptr, 0, 0, 1, RELU, 0.f); P.drop(u);
+    u = P.conv(en + "up2.conv2.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
+    t = P.conv(en + "up1.conv1", u, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, -1, en + "inConv.conv.0"); P.drop(u);     // concatenated with e1
+    u = P.conv(en + "up1.combine", t, &e1, 1, 0, 1, RELU, 0.f); P.drop(t); P.drop(e1);
+    t = P.conv(en + "up1.conv2.0", u, nullptr, 0, 0, 1, RELU, 0.f); P.drop(u);
+    u = P.conv(en + "up1.conv2.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
+    P.conv(en + "outConv", u, nullptr, 0, 0, 1, out_act, 0.f, nullptr, d_out);
+    P.drop(u);
+}
+
+// Stand-alone networks (ABI 9; models/network.py:125,147,260 as modules of their own): a context created with disco_options.segnet_only = 1
+// (SpixelNet), 2 (ColorProbNet) or 3 (HourGlass2) holds that network's tensors only and serves one entry point.
+//   1: d_in gray (n,1,H,W)           -> d_out (n,9,H,W)  softmax over the 9 slots (network.py:312)
+//   2: d_in gray (n,1,H,W)           -> d_out (n,64,H,W) features (network.py:234)
+//   3: d_in (n,65,H,W) = cat(gray, 64 features) (model.py:196) -> d_out (n,2,H,W) BEFORE the tanh of model.py:197
+enum { SUBNET_FULL = 0, SUBNET_SEG = 1, SUBNET_REP = 2, SUBNET_ENH = 3 };
+inline const char* subnet_prefix(int which) { return which == SUBNET_SEG ? "segnet.net." : which == SUBNET_REP ? "repnet." : which == SUBNET_ENH ? "enhanceNet." : ""; }
+inline size_t subnet_out_channels(int which) { return which == SUBNET_SEG ? 9 : which == SUBNET_REP ? 64 : 2; }
+void subnet_stage(Plan& P, disco_ctx* c, int which, const float* d_in, int n, int H, int W, float* d_out) {
+    const bool dry = P.dry;
+    hipStream_t s = P.s;
+    switch (which) {
+    case SUBNET_SEG:
+        segnet_stage(P, c, d_in, n, H, W, dry ? nullptr : d_out);
+        return;
+    case SUBNET_REP: {
+        Act feats = repnet_stage(P, c, d_in, n, H, W);
+        if (!dry && P.ok()) P.rc = launch_act_to_nchw(feats.p, (long)feats.plane, d_out, n, 64, H, W, feats.c, s, feats.sexp);
+        P.drop(feats);
+        return;
+    }
+    case SUBNET_ENH: {
+        P.stage_arith = arith_of(c, "enhanceNet.");
+        const long hw = (long)H * W;
+        float* gray = (float*)P.raw((size_t)n * hw * 4);          // channel 0 of every image, contiguous: what the gray-block kernels read
+        if (!dry && P.ok() && hipMemcpy2DAsync(gray, hw * 4, d_in, 65 * hw * 4, hw * 4, n, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            P.rc = hip_fail(hipGetLastError(), "gray channel copy");
+        // the same two input tensors, formats and calibration keys as in the colorizer (run_plan): "upfeat" = the 64 feature channels
+        const int infmt = P.stage_arith == ARITH_MX6 ? (int)Plan::F_Q : P.dfmt();
+        Act full = P.act(n, H, W, 64, infmt);
+        const bool gtail = P.mx();
+        Act g16 = gtail ? P.act(n, H, W, 16, 0) : P.act(n, H, W, P.cpad(16), infmt);
+        if (!dry && P.ok() && P.scale_of("upfeat", &full.sexp) && P.scale_of("gray16", &g16.sexp)) {}
+        unsigned int* sat = P.calib ? nullptr : c->d_sat;
+        auto up = [&]() { P.rc = launch_nchw_to_act_mx(d_in + hw, full, 64, s, 65 * hw, sat); };
+        auto gr = [&]() { P.rc = gtail ? launch_gray_tail(gray, 1, g16, s) : launch_gray16(gray, 1, g16, sat, s); };
+        if (!dry && P.ok()) { up(); P.calibrate("upfeat", full, up); }
+        if (!dry && P.ok()) { gr(); P.calibrate("gray16", g16, gr, "upfeat"); }
+        P.drop(gray);
+        enhance_stage(P, c, full, g16, NOACT, dry ? (float*)16 : d_out);
+        return;
+    }
+    default:
+        set_error("not a stand-alone network context"); P.rc = DISCO_ESTATE;
+    }
+}
+
 int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, size_t* peak, bool calib = false) {
     Plan P(c, a, cap, dry);
     P.calib = calib;
@@ -840,48 +965,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     P.mark("segnet", 2.0 * 2.8962e9 * px / 65536.0);
 
     // ---- a2 ColorProbNet (network.py:220-236) ----------------------------------------------------------------
-    const std::string rp = "repnet.";
-    P.stage_arith = arith_of(c, rp);
-    // conv1_2.0 (Cin = 1) is not a launch of its own when its consumer runs on the 32 x 16 x 64 tile with enough tiles to fill the GPU: conv1_2.2
-    // then computes its input tiles in LDS from the gray image, with the stand-alone kernel's arithmetic (bit-identical either way), and the
-    // 64-channel full-resolution tensor in between (4 B per element: 1.07 GB at 64 x 256^2) is never written or read.  The calibration pass
-    // and the workspace sizing take the two-launch form (the tensor's exponent is measured on the stand-alone kernel).
-    static const bool fuse_env = [] { const char* e = std::getenv("DISCO_FUSE_C1"); return !e || std::atoi(e) != 0; }();
-    const bool fuse_c1 = fuse_env && !dry && !calib && P.stage_arith == ARITH_F16X3 && W > 16 && H > 8 &&
-                         (long)((W + 31) / 32) * ((H + 15) / 16) * n >= (long)num_cus_current() * 3 / 4;
-    Act t{}, f{};
-    if (fuse_c1) {
-        Act v{};
-        v.n = n; v.h = H; v.w = W; v.c = 64;
-        if (P.scale_of(rp + "conv1_2.0", &v.sexp)) {
-            const Plan::FusedC1 fc{a->d_gray, &c->direct.at(rp + "conv1_2.0"), LRELU, 0.2f};
-            P.fuse = &fc;
-            f = P.conv(rp + "conv1_2.2", v, nullptr, 0, 0, 1, LRELU, 0.2f);
-            P.fuse = nullptr;
-        }
-    } else {
-        t = P.c1(rp + "conv1_2.0", a->d_gray, n, H, W, LRELU, 0.2f);
-        f = P.conv(rp + "conv1_2.2", t, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(t);
-    }
-    Act f3{};
-    const char* blk[6] = {"conv2_3", "conv3_3", "conv4_3", "conv5_3", "conv6_3", "conv7_3"};
-    for (int b = 0; b < 6; ++b) {
-        const std::string k = rp + blk[b];
-        Act x1 = P.conv(k + ".0", f, nullptr, 0, 0, b < 3 ? 2 : 1, LRELU, 0.2f);
-        if (b != 2) P.drop(f);   // b == 2: f is f3_3, kept alive for the conv3short8 shortcut
-        Act x2 = P.conv(k + ".2", x1, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(x1);
-        f = P.conv(k + ".4", x2, nullptr, 0, 0, 1, LRELU, 0.2f); P.drop(x2);
-        if (b == 1) f3 = f;
-    }
-    Act sh = P.conv(rp + "conv3short8.0", f3, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, Plan::F_LO);   // residual only
-    P.drop(f3);
-    Act f8 = P.conv(rp + "conv8up.1", f, nullptr, 0, 0, 1, RELU, 0.f, &sh, nullptr, true); P.drop(sh); P.drop(f);
-    t = P.conv(rp + "conv8_3.1", f8, nullptr, 0, 0, 1, RELU, 0.f); P.drop(f8);
-    f8 = P.conv(rp + "conv8_3.3", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
-    t = P.conv(rp + "conv9up.1", f8, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, true); P.drop(f8);
-    Act f9 = P.conv(rp + "conv9_2.0", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
-    t = P.conv(rp + "conv10up.1", f9, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, true); P.drop(f9);
-    Act feats = P.conv(rp + "conv10_2.1", t, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, false, false, Plan::F_LO); P.drop(t);   // pooled, not convolved
+    Act feats = repnet_stage(P, c, a->d_gray, n, H, W);
     P.mark("repnet", 2.0 * 68.8914e9 * px / 65536.0);
 
     // ---- a3-a5 tokens, colours, sizes (model.py:114-121) ------------------------------------------------------
@@ -1011,31 +1095,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     }
     P.drop(dec);
     P.mark("upfeat");
-    const std::string en = "enhanceNet.";
-    t = P.conv(en + "inConv.inConv.0", full, &g16, 0, 0, 1, RELU, 0.f); P.drop(full); P.drop(g16);
-    Act e1 = P.conv(en + "inConv.conv.0", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
-    t = P.conv(en + "down1.conv.0", e1, nullptr, 0, 0, 2, RELU, 0.f);
-    Act e2 = P.conv(en + "down1.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
-    t = P.conv(en + "down2.conv.0", e2, nullptr, 0, 0, 2, RELU, 0.f);
-    const int rfmt = P.mx() ? (Plan::F_LO | P.dfmt()) : Plan::F_LO;      // residual-chain tensors: convolved AND added back
-    Act x = P.conv(en + "down2.conv.2", t, nullptr, 0, 0, 1, RELU, 0.f, nullptr, nullptr, false, false, rfmt); P.drop(t);
-    for (int r = 0; r < 3; ++r) {
-        const std::string k = en + "residual." + std::to_string(r) + ".conv.";
-        Act t1 = P.conv(k + "0", x, nullptr, 0, 0, 1, NOACT, 0.f);
-        Act t2 = P.conv(k + "1", t1, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t1);
-        Act y = P.conv(k + "3", t2, nullptr, 0, 0, 1, RELU, 0.f, &x, nullptr, false, false, rfmt); P.drop(t2); P.drop(x);
-        x = y;
-    }
-    t = P.conv(en + "up2.conv1", x, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, -1, en + "down1.conv.2"); P.drop(x);      // concatenated with e2
-    Act u = P.conv(en + "up2.combine", t, &e2, 1, 0, 1, RELU, 0.f); P.drop(t); P.drop(e2);
-    t = P.conv(en + "up2.conv2.0", u, nullptr, 0, 0, 1, RELU, 0.f); P.drop(u);
-    u = P.conv(en + "up2.conv2.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
-    t = P.conv(en + "up1.conv1", u, nullptr, 0, 0, 1, NOACT, 0.f, nullptr, nullptr, false, false, -1, en + "inConv.conv.0"); P.drop(u);     // concatenated with e1
-    u = P.conv(en + "up1.combine", t, &e1, 1, 0, 1, RELU, 0.f); P.drop(t); P.drop(e1);
-    t = P.conv(en + "up1.conv2.0", u, nullptr, 0, 0, 1, RELU, 0.f); P.drop(u);
-    u = P.conv(en + "up1.conv2.2", t, nullptr, 0, 0, 1, RELU, 0.f); P.drop(t);
-    P.conv(en + "outConv", u, nullptr, 0, 0, 1, DISCO_ACT_TANH, 0.f, nullptr, dry ? (float*)16 : a->d_pred_colors);
-    P.drop(u);
+    enhance_stage(P, c, full, g16, DISCO_ACT_TANH, dry ? (float*)16 : a->d_pred_colors);
     P.mark("enhance", 2.0 * 55.6794e9 * (double)n2 * H * W / 65536.0);
 
     // k-means bookkeeping for the caller (the one documented host synchronisation)
@@ -1084,20 +1144,22 @@ int calibrate_ctx_impl(disco_ctx* c, const float* d_user_gray, int un, int uh, i
     disco_forward_args a{};
     a.n = n; a.h = H; a.w = W; a.sampled_T = 0; a.test_mode = 1;
     a.h_init_idx = idx.data(); a.h_hint_pos = idx.data();
-    const bool seg = c->opt.segnet_only != 0;
+    const int sub = c->opt.segnet_only;
+    const bool seg = sub != SUBNET_FULL;          // a stand-alone network: input -> bufs[0], its one output -> bufs[5]
+    if (sub == SUBNET_ENH && !d_user_gray) { set_error("a stand-alone HourGlass2 context is calibrated on its caller's input (disco_calibrate)"); return DISCO_ESTATE; }
     size_t peak = 0;
     int rc;
-    if (seg) { Plan P(c, &a, (size_t)1 << 46, true); segnet_stage(P, c, nullptr, n, H, W, nullptr); peak = P.arena.peak; rc = P.rc; }
+    if (seg) { Plan P(c, &a, (size_t)1 << 46, true); subnet_stage(P, c, sub, nullptr, n, H, W, nullptr); peak = P.arena.peak; rc = P.rc; }
     else rc = run_plan(c, &a, (size_t)1 << 46, true, &peak);
     if (rc) return rc;
     peak += (size_t)1 << 20;
-    const size_t px = (size_t)n * H * W, lt = (size_t)n * L;
-    const size_t outs[7] = {px * 4, px * 2 * 4, lt * 313 * 4, lt * 313 * 4, px * 2 * 4, px * 9 * 4, lt * 2 * 4 + lt * 4};
+    const size_t px = (size_t)n * H * W, lt = (size_t)n * L, in_ch = sub == SUBNET_ENH ? 65 : 1;
+    const size_t outs[7] = {px * in_ch * 4, px * 2 * 4, lt * 313 * 4, lt * 313 * 4, px * 2 * 4, px * (seg ? subnet_out_channels(sub) : 9) * 4, lt * 2 * 4 + lt * 4};
     void* bufs[8] = {};
     hipError_t e = hipSuccess;
     for (int i = 0; i < 7 && e == hipSuccess; ++i) e = hipMalloc(&bufs[i], outs[i]);
     if (e == hipSuccess) e = hipMalloc(&bufs[7], peak);
-    if (e == hipSuccess) e = d_user_gray ? hipMemcpy(bufs[0], d_user_gray, px * 4, hipMemcpyDeviceToDevice) : hipMemcpy(bufs[0], g.data(), px * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = d_user_gray ? hipMemcpy(bufs[0], d_user_gray, px * in_ch * 4, hipMemcpyDeviceToDevice) : hipMemcpy(bufs[0], g.data(), px * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(bufs[1], 0, px * 2 * 4);
     if (e != hipSuccess) rc = hip_fail(e, "calibration buffers");
     if (!rc) {
@@ -1105,7 +1167,7 @@ int calibrate_ctx_impl(disco_ctx* c, const float* d_user_gray, int un, int uh, i
         a.d_pal_logit = (float*)bufs[2]; a.d_ref_logit = (float*)bufs[3]; a.d_pred_colors = (float*)bufs[4];
         a.d_affinity = (float*)bufs[5]; a.d_spix_colors = (float*)bufs[6]; a.d_hint_mask = (float*)bufs[6] + lt * 2;
         a.d_workspace = bufs[7]; a.workspace_bytes = peak; a.stream = nullptr;
-        if (seg) { Plan P(c, &a, peak, false); P.calib = true; segnet_stage(P, c, a.d_gray, n, H, W, a.d_affinity); rc = P.rc; }
+        if (seg) { Plan P(c, &a, peak, false); P.calib = true; subnet_stage(P, c, sub, a.d_gray, n, H, W, a.d_affinity); rc = P.rc; }
         else rc = run_plan(c, &a, peak, false, nullptr, true);
         if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) rc = hip_fail(hipGetLastError(), "calibration forward");
     }
@@ -1270,7 +1332,7 @@ constexpr float MX6_DISPARITY_LIMIT = 64.f;
 // Channels levelled first (keeps fp6) when a block's spread exceeds this; the plain synthetic checkpoint (9) is left as it is
 constexpr float MX6_EQUALISE_ABOVE = 16.f;
 int enhance_disparity_guard(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, int uh = 0, int uw = 0) {
-    if (c->opt.segnet_only || c->enhance_fp8_fallback || arith_of(c, "enhanceNet.outConv") != ARITH_MX6) return DISCO_OK;
+    if (c->opt.segnet_only == SUBNET_SEG || c->opt.segnet_only == SUBNET_REP || c->enhance_fp8_fallback || arith_of(c, "enhanceNet.outConv") != ARITH_MX6) return DISCO_OK;
     if (!c->sd.count("enhanceNet.outConv.weight")) return DISCO_OK;      // (host weights gone: cannot happen after disco_finalize)
     auto rebuild = [&]() -> int {
         // the old layers' device buffers stay in c->allocs until disco_destroy (a few tens of MB); the tensors' exponents and maxima are measured again
@@ -1323,7 +1385,8 @@ int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
     if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL && opt->precision != DISCO_PREC_X2Q && opt->precision != DISCO_PREC_MX6) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
     if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }
-    if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("segnet_only context takes no colorizer flags"); return DISCO_EINVAL; }
+    if (opt->segnet_only < 0 || opt->segnet_only > 3) { set_error("segnet_only %d: 0 (colorizer), 1 SpixelNet, 2 ColorProbNet, 3 HourGlass2", opt->segnet_only); return DISCO_EINVAL; }
+    if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("a stand-alone network context takes no colorizer flags"); return DISCO_EINVAL; }
     int ndev = 0;
     DISCO_HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) { set_error("device %d of %d", device, ndev); return DISCO_EINVAL; }
@@ -1359,12 +1422,14 @@ int disco_load_tensor(disco_ctx* c, const char* key, const float* h_data, const 
 int disco_finalize(disco_ctx* c) {
     if (!c) { set_error("null context"); return DISCO_EINVAL; }
     if (c->finalized) return DISCO_OK;
-    const bool seg_only = c->opt.segnet_only != 0;
+    const int sub = c->opt.segnet_only;
+    const std::string only = subnet_prefix(sub);            // stand-alone network contexts hold that network's tensors and nothing else
+    auto mine = [&](const std::string& key) { return only.empty() || key.compare(0, only.size(), only) == 0; };
     // strict: same key set and shapes as the reference's load_state_dict(strict=True) (utils_train.py:151)
     size_t n_expected = 0;
     const Layout& lay = layout(c->opt.hint2regress != 0);
     for (const ExpectedTensor& e : lay.t) {
-        if (seg_only && e.key.compare(0, 11, "segnet.net.") != 0) continue;
+        if (!mine(e.key)) continue;
         ++n_expected;
         auto it = c->sd.find(e.key);
         if (it == c->sd.end()) { set_error("missing key in state_dict: %s", e.key.c_str()); return DISCO_ESTATE; }
@@ -1375,13 +1440,16 @@ int disco_finalize(disco_ctx* c) {
         for (auto& kv : c->sd) {
             bool found = false;
             for (const ExpectedTensor& e : lay.t)
-                if (e.key == kv.first && (!seg_only || e.key.compare(0, 11, "segnet.net.") == 0)) { found = true; break; }
+                if (e.key == kv.first && mine(e.key)) { found = true; break; }
             if (!found) { set_error("unexpected key in state_dict: %s", kv.first.c_str()); return DISCO_ESTATE; }
         }
     }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
     int rc;
+    if ((rc = dev_alloc(c, 256, (void**)&c->d_sat))) return rc;
+    DISCO_HIP_CHECK(hipMemset(c->d_sat, 0, 256));
     const std::string sg = "segnet.net.";
+    if (sub == SUBNET_FULL || sub == SUBNET_SEG) {
     if ((rc = make_c1(c, sg + "conv0a.0", sg + "conv0a.1"))) return rc;
     for (const char* k : {"conv0b", "conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "conv3_1",
                           "conv2_1", "conv1_1"})
@@ -1393,10 +1461,10 @@ int disco_finalize(disco_ctx* c) {
     } else if ((rc = make_conv(c, sg + "conv0_1.0", sg + "conv0_1.1", "", nullptr, 0, false))) return rc;
     for (const char* k : {"deconv3", "deconv2", "deconv1", "deconv0"}) if ((rc = make_deconv(c, sg + k + ".0"))) return rc;
     if ((rc = make_conv(c, sg + "pred_mask0", "", "", nullptr, 0, false, false))) return rc;
-    if ((rc = dev_alloc(c, 256, (void**)&c->d_sat))) return rc;
-    DISCO_HIP_CHECK(hipMemset(c->d_sat, 0, 256));
-    if (seg_only) { c->sd.clear(); c->finalized = true; return calibrate_ctx(c); }
+    }
+    if (sub == SUBNET_SEG) { c->sd.clear(); c->finalized = true; return calibrate_ctx(c); }
     const std::string rp = "repnet.";
+    if (sub == SUBNET_FULL || sub == SUBNET_REP) {
     if ((rc = make_c1(c, rp + "conv1_2.0", ""))) return rc;
     if ((rc = make_conv(c, rp + "conv1_2.2", "", rp + "conv1_2.4"))) return rc;
     for (const char* b : {"conv2_3", "conv3_3", "conv4_3", "conv5_3", "conv6_3", "conv7_3"}) {
@@ -1412,7 +1480,11 @@ int disco_finalize(disco_ctx* c) {
     if ((rc = make_conv(c, rp + "conv9_2.0", "", rp + "conv9_2.2"))) return rc;
     if ((rc = make_upconv(c, rp + "conv10up.1"))) return rc;
     if ((rc = make_conv(c, rp + "conv10_2.1", "", ""))) return rc;
+    }
+    if (sub == SUBNET_REP) { c->sd.clear(); c->finalized = true; return calibrate_ctx(c); }
     if ((rc = make_enhance(c))) return rc;
+    // a stand-alone HourGlass2 has no input of its own to measure ranges on: it is calibrated by disco_calibrate on its caller's first batch
+    if (sub == SUBNET_ENH) { c->finalized = true; return DISCO_OK; }
     if ((rc = make_encoder(c, "wildpath", &c->d_enc[0]))) return rc;
     if ((rc = make_encoder(c, "hintpath", &c->d_enc[1]))) return rc;
     if ((rc = upload_vec(c, T(c, "mid_word_prj.weight").data, &c->d_mid_w))) return rc;
@@ -1431,7 +1503,7 @@ int disco_finalize(disco_ctx* c) {
 
 int disco_calibrate(disco_ctx* c, const float* d_gray, int n, int h, int w) {
     if (!c || !c->finalized || !d_gray) { set_error("disco_calibrate: bad argument / context not finalized"); return DISCO_EINVAL; }
-    if (n < 1 || n > 64 || h < 16 || w < 16 || h % 16 || w % 16 || (h / 16) * (w / 16) < c->opt.n_clusters) { set_error("disco_calibrate: bad size %dx%dx%d", n, h, w); return DISCO_ESHAPE; }
+    if (n < 1 || n > 64 || h < 16 || w < 16 || h % 16 || w % 16 || (!c->opt.segnet_only && (h / 16) * (w / 16) < c->opt.n_clusters)) { set_error("disco_calibrate: bad size %dx%dx%d", n, h, w); return DISCO_ESHAPE; }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mu);
     ProgressDisarm disarm{c, nullptr};
@@ -1457,7 +1529,7 @@ int disco_calibration_count(disco_ctx* c) { return c ? (int)c->amax.size() : 0; 
 int disco_enhance_arithmetic(disco_ctx* c, int* precision, float* channel_disparity, float* disparity_before_equalisation) {
     if (!c || !precision || !channel_disparity || !disparity_before_equalisation) { set_error("null argument"); return DISCO_EINVAL; }
     *disparity_before_equalisation = c->equalised ? c->mx6_disparity_before_eq : 0.f;
-    const int ar = c->opt.segnet_only ? ARITH_F16X3 : arith_of(c, "enhanceNet.outConv");
+    const int ar = (c->opt.segnet_only == SUBNET_SEG || c->opt.segnet_only == SUBNET_REP) ? ARITH_F16X3 : arith_of(c, "enhanceNet.outConv");
     *precision = ar == ARITH_MX6 ? DISCO_PREC_MX6 : (ar == ARITH_F16X3 ? DISCO_PREC_F16X3 : DISCO_PREC_MX8);
     *channel_disparity = c->mx6_disparity;
     return DISCO_OK;
@@ -1482,27 +1554,50 @@ int disco_workspace_bytes(disco_ctx* c, int n, int h, int w, int sampled_T, size
     size_t peak = 0;
     if (c->opt.segnet_only) {
         Plan P(c, &a, (size_t)1 << 46, true);
-        segnet_stage(P, c, nullptr, n, h, w, nullptr);
+        subnet_stage(P, c, c->opt.segnet_only, nullptr, n, h, w, nullptr);
         peak = P.arena.peak; rc = P.rc;
     } else rc = run_plan(c, &a, (size_t)1 << 46, true, &peak);
     *bytes = peak + 4096;
     return rc;
 }
 
-int disco_forward_segnet(disco_ctx* c, int n, int h, int w, const float* d_gray, float* d_affinity, void* d_ws, size_t ws_bytes,
-                         void* stream) {
+// one network of the colorizer on its own: on a full context or on the stand-alone context of that network
+static int forward_subnet(disco_ctx* c, int which, const char* entry, int n, int h, int w, const float* d_in, float* d_out, void* d_ws, size_t ws_bytes,
+                          void* stream) {
     std::unique_lock<std::mutex> lk;
     if (c) lk = std::unique_lock<std::mutex>(c->mu);
     ProgressDisarm disarm{c, (hipStream_t)stream};
     disco_forward_args a{};
     a.n = n; a.h = h; a.w = w; a.d_workspace = d_ws; a.workspace_bytes = ws_bytes; a.stream = stream;
-    if (!c || !c->finalized) { set_error("disco_forward_segnet before disco_finalize"); return DISCO_ESTATE; }
+    if (!c || !c->finalized) { set_error("%s before disco_finalize", entry); return DISCO_ESTATE; }
+    if (c->opt.segnet_only && c->opt.segnet_only != which) { set_error("%s on the stand-alone context of another network", entry); return DISCO_ESTATE; }
     if (n < 1 || h < 16 || w < 16 || h % 16 || w % 16) { set_error("bad input size %dx%dx%d (multiples of 16)", n, h, w); return DISCO_ESHAPE; }
-    if (!d_gray || !d_affinity || !d_ws) { set_error("null tensor pointer"); return DISCO_EINVAL; }
+    if (!d_in || !d_out || !d_ws) { set_error("null tensor pointer"); return DISCO_EINVAL; }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
-    if (!c->calibrated) { set_error("context used before its calibration pass"); return DISCO_ESTATE; }
+    if (!c->calibrated) { set_error(c->opt.segnet_only == SUBNET_ENH ? "stand-alone HourGlass2 context: disco_calibrate on a first batch of its input comes first" : "context used before its calibration pass"); return DISCO_ESTATE; }
     Plan P(c, &a, ws_bytes, false);
-    segnet_stage(P, c, d_gray, n, h, w, d_affinity);
+    subnet_stage(P, c, which, d_in, n, h, w, d_out);
+    return P.rc;
+}
+
+int disco_forward_segnet(disco_ctx* c, int n, int h, int w, const float* d_gray, float* d_affinity, void* d_ws, size_t ws_bytes, void* stream) {
+    return forward_subnet(c, SUBNET_SEG, "disco_forward_segnet", n, h, w, d_gray, d_affinity, d_ws, ws_bytes, stream);
+}
+int disco_forward_repnet(disco_ctx* c, int n, int h, int w, const float* d_gray, float* d_feats, void* d_ws, size_t ws_bytes, void* stream) {
+    return forward_subnet(c, SUBNET_REP, "disco_forward_repnet", n, h, w, d_gray, d_feats, d_ws, ws_bytes, stream);
+}
+int disco_forward_enhance(disco_ctx* c, int n, int h, int w, const float* d_input, float* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+    return forward_subnet(c, SUBNET_ENH, "disco_forward_enhance", n, h, w, d_input, d_out, d_ws, ws_bytes, stream);
+}
+int disco_subnet_workspace_bytes(disco_ctx* c, int which, int n, int h, int w, size_t* bytes) {
+    if (!c || !bytes || !c->finalized) { set_error("disco_subnet_workspace_bytes: bad argument / context not finalized"); return DISCO_EINVAL; }
+    if (which < SUBNET_SEG || which > SUBNET_ENH || (c->opt.segnet_only && c->opt.segnet_only != which)) { set_error("network %d is not in this context", which); return DISCO_EINVAL; }
+    if (n < 1 || h < 16 || w < 16 || h % 16 || w % 16) { set_error("bad input size %dx%dx%d (multiples of 16)", n, h, w); return DISCO_ESHAPE; }
+    disco_forward_args a{};
+    a.n = n; a.h = h; a.w = w;
+    Plan P(c, &a, (size_t)1 << 46, true);
+    subnet_stage(P, c, which, nullptr, n, h, w, nullptr);
+    *bytes = P.arena.peak + 4096;
     return P.rc;
 }
 
@@ -1510,7 +1605,7 @@ int disco_forward(disco_ctx* c, const disco_forward_args* a) {
     std::unique_lock<std::mutex> lk;
     if (c) lk = std::unique_lock<std::mutex>(c->mu);
     ProgressDisarm disarm{c, a ? (hipStream_t)a->stream : nullptr};
-    if (c && c->opt.segnet_only) { set_error("segnet_only context: use disco_forward_segnet"); return DISCO_ESTATE; }
+    if (c && c->opt.segnet_only) { set_error("stand-alone network context: use disco_forward_segnet / _repnet / _enhance"); return DISCO_ESTATE; }
     int rc = check_forward_args(c, a);
     if (rc) return rc;
     if (!a->d_gray || !a->d_ab || !a->d_pal_logit || !a->d_ref_logit || !a->d_pred_colors || !a->d_affinity ||

