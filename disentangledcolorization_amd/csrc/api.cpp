@@ -2,6 +2,7 @@
 // spectral-norm / batch-norm folding, weight packing, and the forward plan of
 // AnchorColorProb.forward(test_mode=True) (models/model.py:103-199) as a sequence of HIP launches.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -578,6 +579,19 @@ struct Plan {
         ++dbg_col;
     }
     void mark(const char* name, double flops = 0.0) {
+        // DISCO_HOST_TIMING=1 (diagnostic): host time between the stage marks of every forward, printed at the "enhance" mark
+        static const bool host_timing = std::getenv("DISCO_HOST_TIMING") != nullptr;
+        if (host_timing && !dry && !calib) {
+            static thread_local std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> ht;
+            ht.emplace_back(name, std::chrono::steady_clock::now());
+            if (std::string(name) == "enhance") {
+                std::string line = "[host us]";
+                for (size_t i = 1; i < ht.size(); ++i)
+                    line += " " + std::string(ht[i].first) + " " + std::to_string(std::chrono::duration_cast<std::chrono::microseconds>(ht[i].second - ht[i - 1].second).count());
+                std::fprintf(stderr, "%s\n", line.c_str());
+                ht.clear();
+            }
+        }
         if (dry || !c->profiling || !ok()) return;
         hipEvent_t ev;
         if (hipEventCreate(&ev) != hipSuccess) return;
