@@ -179,3 +179,31 @@ def test_no_packed_fp32_instruction_with_op_sel():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "unsafe instructions: 0" in r.stdout
+
+
+def test_network_dropins_without_a_gpu(synth_sd):
+    """disentangledcolorization_amd/network.py (models/network.py:125,147,260 as modules of their own): the three state_dicts are the
+    colorizer's subsets with the prefix removed, strict loading works on the host, unsupported configurations raise, and a CPU tensor
+    is refused (no CPU fallback)."""
+    import pytest
+    import torch
+    import torch.nn as nn
+    from disentangledcolorization_amd import _ffi, network
+
+    for cls, pre, count in ((network.SpixelNet, "segnet.net.", 94), (network.ColorProbNet, "repnet.", 141), (network.HourGlass2, "enhanceNet.", 79)):
+        m = cls()
+        want = {k[len(pre):]: v for k, v in synth_sd.items() if k.startswith(pre)}
+        assert len(want) == count and list(m.state_dict().keys()) == list(want.keys())
+        m.load_state_dict(want)                                          # strict
+        assert all(torch.equal(m.state_dict()[k], v) for k, v in want.items())
+        with pytest.raises(RuntimeError):
+            cls().load_state_dict({k: v for k, v in list(want.items())[1:]})
+        with pytest.raises(_ffi.DiscoError):
+            m(torch.zeros(1, 65 if cls is network.HourGlass2 else 1, 32, 32))
+        with pytest.raises(NotImplementedError):
+            m.train()
+        assert m.eval() is m
+    for bad in (lambda: network.SpixelNet(inChannel=3), lambda: network.ColorProbNet(outChannel=2),
+                lambda: network.HourGlass2(inChannel=3, outChannel=1), lambda: network.HourGlass2(normLayer=nn.InstanceNorm2d)):
+        with pytest.raises(NotImplementedError):
+            bad()
