@@ -859,3 +859,46 @@ def test_pipelined_batches_equal_the_plain_runs(synth_sd):
         for i, res in enumerate(got):
             if res is not None:
                 assert torch.equal(res[0], want[i % 3][0]) and torch.equal(res[1], want[i % 3][1]), (rnd, i)
+
+
+def test_two_host_threads_share_one_context(synth_sd):
+    """include/disco_hip.h, threading: a context's entry points serialise on a mutex inside the context, so several host threads may share one
+    (their host-side issue takes turns, their streams overlap on the GPU).  Two threads, each on its own stream, run 25 forwards of their own
+    batch through the same model / context (ctypes drops the GIL inside the C call, so they do contend); every result is bit-identical to
+    the one a single thread computes."""
+    import threading
+
+    m = _model(synth_sd, 8)
+    saved, m.range_checks = m.range_checks, 0
+    try:
+        batches = []
+        for i in range(2):
+            gray, ab = synth.synth_inputs(3, 128, 128, seed=60 + i)
+            idx = np.stack([np.random.RandomState(70 + 10 * i + j).choice(64, 8, replace=False) for j in range(3)]).astype(np.int32)
+            batches.append((gray.cuda(), ab.cuda(), idx))
+        want = [tuple(t.clone() for t in m.forward_once(g, a, True, 0, idx, None, None, None, False)[0]) for g, a, idx in batches]
+        torch.cuda.synchronize()
+        got, errors = [None, None], []
+
+        def worker(i):
+            try:
+                g, a, idx = batches[i]
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    for _ in range(25):
+                        out = m.forward_once(g, a, True, 0, idx, None, None, None, False)[0]
+                    s.synchronize()
+                got[i] = out
+            except Exception as e:      # noqa: BLE001  (reported below, in the main thread)
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in threads: t.start()
+        for t in threads: t.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for i in range(2):
+            for k in range(6):
+                assert torch.equal(got[i][k], want[i][k]), (i, k)
+    finally:
+        m.range_checks = saved
