@@ -209,6 +209,9 @@ struct disco_ctx {
     Staging stg[4];
     int stg_next = 0;
     int profiling = 0;
+    // small batches (run_plan): SpixelNet runs on this stream next to ColorProbNet on the caller's - neither fills the GPU on its own
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // disco_set_progress_event: recorded on the next forward's stream behind its `progress_after`-th MFMA conv launch (one shot)
     hipEvent_t progress_ev = nullptr;
     int progress_after = 0, progress_seen = 0;
@@ -975,11 +978,46 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     }
     P.mark("start");
 
-    segnet_stage(P, c, a->d_gray, n, H, W, dry ? nullptr : a->d_affinity);
+    // Small batches (up to 8 x 256^2 worth of pixels): neither conv stack fills 256 CUs on its own (one 256^2 image is 128 full-resolution
+    // tiles, the 512-channel layers run 64 workgroups), and SpixelNet and ColorProbNet depend on nothing but the gray image.  SpixelNet then
+    // runs on a side stream of the context, in a block of the workspace reserved for it (sized by shape alone, so the sizing pass and the
+    // forward agree), and the caller's stream waits for it in front of the pooling kernel.  Same kernels, same results.  Not while a
+    // progress event is armed (it counts conv launches in issue order), not under profiling (stage times), not in the calibration pass.
+    static const bool fork_env = [] { const char* e = std::getenv("DISCO_FORK_SEGNET"); return !e || std::atoi(e) != 0; }();
+    const bool fork_shape = fork_env && (long)n * H * W <= 8L * 256 * 256;
+    void* seg_ws = nullptr;
+    size_t seg_bytes = 0;
+    if (fork_shape) {
+        Plan S(c, a, (size_t)1 << 46, true);
+        segnet_stage(S, c, nullptr, n, H, W, nullptr);
+        seg_bytes = S.arena.peak + 4096;
+        if (S.rc) P.rc = S.rc;
+        seg_ws = P.raw(seg_bytes);
+    }
+    bool forked = false;
+    if (fork_shape && !dry && !calib && P.ok() && !c->progress_ev && !c->profiling && P.dbg_row < 0) {
+        if (!c->side) {
+            if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); }
+        }
+        if (c->side && hipEventRecord(c->ev_fork, s) == hipSuccess && hipStreamWaitEvent(c->side, c->ev_fork, 0) == hipSuccess) {
+            disco_forward_args a2 = *a;
+            a2.d_workspace = seg_ws; a2.workspace_bytes = seg_bytes; a2.stream = c->side;
+            Plan S(c, &a2, seg_bytes, false);
+            segnet_stage(S, c, a->d_gray, n, H, W, a->d_affinity);
+            if (S.rc) P.rc = S.rc;
+            if (hipEventRecord(c->ev_join, c->side) != hipSuccess && P.ok()) P.rc = DISCO_EHIP;
+            forked = true;
+        }
+    }
+    if (!forked) segnet_stage(P, c, a->d_gray, n, H, W, dry ? nullptr : a->d_affinity);
     P.mark("segnet", 2.0 * 2.8962e9 * px / 65536.0);
 
     // ---- a2 ColorProbNet (network.py:220-236) ----------------------------------------------------------------
     Act feats = repnet_stage(P, c, a->d_gray, n, H, W);
+    if (forked && P.ok() && hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) P.rc = DISCO_EHIP;
+    if (forked && !P.ok()) (void)hipStreamSynchronize(c->side);      // an error return must not leave the side stream writing into the caller's buffers
+    if (seg_ws) P.drop(seg_ws);
     P.mark("repnet", 2.0 * 68.8914e9 * px / 65536.0);
 
     // ---- a3-a5 tokens, colours, sizes (model.py:114-121) ------------------------------------------------------
@@ -1418,6 +1456,9 @@ int disco_destroy(disco_ctx* c) {
     for (auto& e : c->prof) hipEventDestroy(e.ev);
     for (auto& e : c->conv_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
     for (auto& g : c->stg) { if (g.ev) hipEventDestroy(g.ev); if (g.h) hipHostFree(g.h); }
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     for (void* p : c->allocs) hipFree(p);
     delete c;
     return DISCO_OK;

@@ -30,6 +30,9 @@
  *     disco_set_progress_event + the forward it arms are two calls: arm and launch from ONE thread.  The op-level entry points
  *     (disco_op_*) touch no context.  The only process-global state is one-time per-device setup (function attributes, the op-level
  *     gamut table: std::call_once / atomics).  One context per device.
+ *     Small batches (n h w <= 8 x 256 x 256): disco_forward issues SpixelNet on a side stream owned by the context, forked from and joined
+ *     back into the caller's stream with events - every result is complete on the caller's stream as always, inputs may be reused once
+ *     that stream has passed the forward (DISCO_FORK_SEGNET=0 in the environment keeps everything on the caller's stream).
  *     No hidden host synchronisation except in disco_forward's k-means fallback bookkeeping
  *     (documented there) and disco_sync.
  *   - host-side randomness (k-means initial rows, empty-cluster fallback rows, random hints) is

@@ -902,3 +902,23 @@ def test_two_host_threads_share_one_context(synth_sd):
                 assert torch.equal(got[i][k], want[i][k]), (i, k)
     finally:
         m.range_checks = saved
+
+
+def test_small_batches_fork_spixelnet_onto_a_side_stream(synth_sd):
+    """Up to 8 x 256^2 pixels per forward, disco_forward runs SpixelNet on a side stream of the context next to ColorProbNet (neither fills the
+    GPU at that size; csrc/api.cpp run_plan).  Same kernels, same results: the two images of a forked forward equal, bit for bit, their rows
+    in a 40-image forward (above the threshold: single stream), also when the small forwards are issued back to back."""
+    m = _model(synth_sd, 8)
+    saved, m.range_checks = m.range_checks, 0
+    try:
+        gray, ab = synth.synth_inputs(40, 128, 128, seed=81)
+        idx = np.stack([np.random.RandomState(90 + j).choice(64, 8, replace=False) for j in range(40)]).astype(np.int32)
+        gray, ab = gray.cuda(), ab.cuda()
+        big = m.forward_once(gray, ab, True, 0, idx, None, None, None, False)[0]
+        smalls = [m.forward_once(gray[i:i + 2].contiguous(), ab[i:i + 2].contiguous(), True, 0, idx[i:i + 2], None, None, None, False)[0] for i in (0, 2, 4, 6, 0, 2)]
+        torch.cuda.synchronize()
+        for j, i in enumerate((0, 2, 4, 6, 0, 2)):
+            for k in range(6):
+                assert torch.equal(smalls[j][k], big[k][i:i + 2]), (i, k)
+    finally:
+        m.range_checks = saved
