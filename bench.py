@@ -139,6 +139,21 @@ def measure_alt(precision, sd, gray, ab, n_global, args, sync):
             "note": "ColorProbNet on f16x2+fp8; passes the same parity suite; anchors differ from the fp32 reference in 0.66 % of 1 960 images (default: 0.10 %)"}
 
 
+def single_image_latency(model, gray1, ab1, sync, reps=30):
+    """Median wall time of one synchronised forward of ONE 256x256 image (issue + GPU + sync), after 5 warm-ups."""
+    import numpy as np
+    idx = np.stack([np.random.RandomState(7).choice((gray1.shape[2] // 16) * (gray1.shape[3] // 16), model.hint_num, replace=False)]).astype(np.int32)
+    ts = []
+    for it in range(5 + reps):
+        sync()
+        t0 = time.perf_counter()
+        model.forward_once(gray1, ab1, True, 0, idx, None, None, None, False)
+        sync()
+        if it >= 5:
+            ts.append(time.perf_counter() - t0)
+    return round(sorted(ts)[len(ts) // 2] * 1e3, 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,6 +358,9 @@ def main():
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
             }
             out["stage_ms_per_step"] = {k: round(v / prof_steps, 3) for k, v in stage_ms.items()}        # of the profiled single-stream forwards
+            if world == 1:
+                # the reference's own call pattern is one image per forward (main/colorizer/inference.py:93-109): its latency, NOT `value`
+                out["single_image_latency_ms"] = single_image_latency(model, gray[:1].contiguous(), ab[:1].contiguous(), sync)
             if world == 1 and args.alt and not args.no_alt and args.precision == "mx6":
                 # the opt-in arithmetic on the same inputs, timed the same way (NOT `value`: DESIGN.md section 2 says why it is opt-in)
                 out["opt_in_precision"] = measure_alt("x2q", sd, gray, ab, n_global, args, sync)
