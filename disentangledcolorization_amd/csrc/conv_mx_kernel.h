@@ -79,6 +79,15 @@ __device__ unsigned long long g_mx_tl[2][MX_TL_EVENTS];      // [first / last wa
             ++tl_n;                                                                                                     \
         }                                                                                                               \
     } while (0)
+// read back / clear the phase stamps of workgroup (0, 0) of this translation unit's instantiations
+#define MX_TIMELINE_EXPORT(NAME)                                                                                                     \
+    extern "C" int NAME(unsigned long long* h_dst /* [2][8192] */, int clear) {                                                      \
+        if (clear) {                                                                                                                 \
+            static unsigned long long zeros[2][disco::MX_TL_EVENTS];                                                                 \
+            return hipMemcpyToSymbol(HIP_SYMBOL(disco::g_mx_tl), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;                        \
+        }                                                                                                                            \
+        return hipMemcpyFromSymbol(h_dst, HIP_SYMBOL(disco::g_mx_tl), sizeof(unsigned long long) * 2 * disco::MX_TL_EVENTS) == hipSuccess ? 0 : -1; \
+    }
 #else
 #define MX_TL(tag) do { } while (0)
 #endif
@@ -157,7 +166,11 @@ struct GeoMx {
 // GENC1 (round 4, f16x3 only): the layer's 16-channel chunks are not read from a tensor - they are COMPUTED in LDS from the gray image, as
 // the outputs of the Cin = 1 conv that precedes it in the network (repnet.conv1_2.0 -> conv1_2.2, network.py:152-153): the same fmaf chain,
 // bias, LeakyReLU, scale and hi/lo split as conv_c1_kernel + store_act8 (bit-identical), so that layer's 1.07 GB tensor is never written or read
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR, bool GENC1 = false>
+// NB: LDS buffers.  2 = the throughput loop (a chunk's DMA issued in ninths between its predecessor's taps).  3 = the LATENCY loop (round 5),
+// for launches that cannot fill the GPU (one image, the deep layers of small batches): a chunk's whole DMA goes out in one burst TWO chunks
+// ahead, right behind the barrier that frees its buffer; fragment reads run one tap ahead of the MFMAs; the chunk barrier sits inside the
+// last tap of the preceding chunk.  Same chunks, same taps, same MFMAs in the same order per accumulator: results are bit-identical to NB = 2.
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR, bool GENC1 = false, int NB = 2>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
     constexpr bool XQ = AR == 1, X3 = AR == 2, Q6 = AR == 3;
     constexpr int QFMT = Q6 ? 2 : MX_QFMT;                // operand format code of the K = 64 MFMA: 0 = fp8 e4m3, 2 = fp6 e2m3
@@ -177,7 +190,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;
     constexpr int WPW = (W_PIECES + NWAVE - 1) / NWAVE;
     constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;
-    constexpr int PAR_OFF = 2 * BUF_BYTES;
+    constexpr int PAR_OFF = NB * BUF_BYTES;
+    static_assert(NB == 2 || NB == 3, "two or three LDS buffers");
+    constexpr int DUMP_OFF = PAR_OFF + 3 * 32 * NT * 4;       // NB = 3: 1 KiB that absorbs the out-of-range DMA pieces (every wave issues the same number)
+    constexpr int DMA_PER_CHUNK = APW + WPW;                  // NB = 3: LDS-DMA instructions per wave and chunk, exactly (the s_waitcnt immediate)
+    static_assert(DMA_PER_CHUNK <= 60, "vmcnt is a 6-bit counter");
+    static_assert(NB == 2 || (MT == 1 && NTW == 1 && !GENC1 && !(NSRC2 && AR == 0) && AR != 1), "the latency loop serves one 32 x 32 block per wave, plain chunk sequences");
 
     // GENC1: behind the parameters: two gray tiles (the tile's input footprint of the Cin = 1 conv: one pixel more on every side than the
     // layer's own halo tile) and that conv's weights + biases, 10 floats per channel
@@ -192,13 +210,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
+#if MX_TIMELINE
+    const bool tl_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == NWAVE - 1);
+    const int tl_w = wave == 0 ? 0 : 1;
+    int tl_n = 1;
+    MX_TL(12);                           // kernel entry
+#endif
     const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
     const int nchunks = XQ ? (a.c_in >> 6) * 5 : a.c_in >> 4;    // two chunks (H, Q) per 32 input channels; XQ: H L H L Q per 64; X3: one per 16
 
     int bid = blockIdx.x;
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int by = bid / tiles_y;
+    int tx, ty, by;
+    if constexpr (NB == 3) {
+        // output-channel block fastest: workgroup ids go round the 8 XCDs, so an XCD (its own 4 MB L2) serves few channel blocks for ALL pixel
+        // tiles - each weight tile comes out of HBM / Infinity Cache once per XCD and is an L2 hit for the other pixel tiles (512 -> 512 @32^2 on
+        // 32 x 4 tiles: 2 blocks = 1.2 MB of weights per XCD instead of all 9.4 MB streaming through every L2)
+        const int nby = (a.c_out + 32 * NT - 1) / (32 * NT);
+        by = bid % nby; bid /= nby;
+        tx = bid % tiles_x; ty = bid / tiles_x;
+    } else {
+        tx = bid % tiles_x; bid /= tiles_x;
+        ty = bid % tiles_y;
+        by = bid / tiles_y;
+    }
     const int ox0 = tx * TW, oy0 = ty * TH;
     const int img_step = gridDim.y;
     int n = blockIdx.y;
@@ -213,15 +247,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     }
 
     float* s_par = reinterpret_cast<float*>(smem + PAR_OFF);
-    for (int i = tid; i < 3 * 32 * NT; i += NWAVE * 64) {
-        const int which = i / (32 * NT), c = i - which * (32 * NT);
-        const int co = by * NT * 32 + c;
-        const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;
-        const float* src = which == 0 ? a.bias : (which == 1 ? a.bn_scale : a.bn_shift);
-        // exact power-of-two factors carry the parameters into the domains the epilogue works in (ConvMxArgs::acc_mul ...)
-        const float pm = which == 0 ? a.bias_mul : (which == 1 ? a.bns_mul : a.bnh_mul);
-        s_par[i] = ((src && co < a.c_out) ? src[cpar] : (which == 1 ? 1.f : 0.f)) * pm;
-    }
+    auto stage_params = [&]() {
+        for (int i = tid; i < 3 * 32 * NT; i += NWAVE * 64) {
+            const int which = i / (32 * NT), c = i - which * (32 * NT);
+            const int co = by * NT * 32 + c;
+            const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;
+            const float* src = which == 0 ? a.bias : (which == 1 ? a.bn_scale : a.bn_shift);
+            // exact power-of-two factors carry the parameters into the domains the epilogue works in (ConvMxArgs::acc_mul ...)
+            const float pm = which == 0 ? a.bias_mul : (which == 1 ? a.bns_mul : a.bnh_mul);
+            s_par[i] = ((src && co < a.c_out) ? src[cpar] : (which == 1 ? 1.f : 0.f)) * pm;
+        }
+    };
+    if constexpr (NB == 2) stage_params();       // (the latency loop stages them behind its first DMA bursts: their load latency runs under the DMA's)
 
     if (GENC1) {
         // the producing conv's weights and biases: channel c at floats [10 c, 10 c + 9), bias at 10 c + 9
@@ -362,6 +399,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         char* dA = smem + buf * BUF_BYTES;
         char* dW = dA + A_BYTES;
         const bool tail = NSRC2 && AR == 0 && (nchunks & 1) && ck == nchunks - 1;       // 16-channel H-only chunk: plane 0 alone
+        if constexpr (NB == 3) {
+            // the latency loop: every wave issues exactly DMA_PER_CHUNK instructions per chunk (its s_waitcnt counts them), one (or two) per
+            // tap of the chunk computed meanwhile; a piece beyond the tile reads out of range (zeros, no memory traffic) into the dump area;
+            // masked taps' weights are fetched like the others
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                if (part >= 0 && (i * 9) / DMA_PER_CHUNK != part) continue;
+                const int piece = i * NWAVE + wave;
+                const bool ok = (i + 1) * NWAVE <= A_PIECES || piece < A_PIECES;
+                char* dst = ok ? dA + piece * 1024 : smem + DUMP_OFF;
+                unsigned v0 = voff[0][i], v1 = voff[NS - 1][i];
+                if (NSRC2) asm("" : "+v"(v0), "+v"(v1));
+                const unsigned vsel = s1 ? v1 : v0;
+                if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)dst, 16, vsel, soff, 0, MX_PIX_AUX);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)dst, 16, vsel, soff, 0, MX_PIX_AUX);
+            }
+#pragma unroll
+            for (int i = 0; i < WPW; ++i) {
+                if (part >= 0 && ((APW + i) * 9) / DMA_PER_CHUNK != part) continue;
+                const int piece = i * NWAVE + wave;
+                const bool ok = (i + 1) * NWAVE <= W_PIECES || piece < W_PIECES;
+                const int nt = piece / 18, q = piece - nt * 18;
+                char* dst = ok ? dW + piece * 1024 : smem + DUMP_OFF;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, ok ? (unsigned)lane * 16u : OOB,
+                                                         ok ? w_tile_b + (unsigned)nt * w_nt_b + (unsigned)ck * W_NB + q * 1024 : 0u, 0, MX_W_AUX);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             if (GENC1) break;                              // the pixel tile is computed (gen_c1), not loaded
@@ -416,11 +481,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         }
     }
 
-#if MX_TIMELINE
-    const bool tl_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == NWAVE - 1);
-    const int tl_w = wave == 0 ? 0 : 1;
-    int tl_n = 1;
-#endif
     int gbuf = 0;                        // GENC1: gray buffer of the image being convolved (the other one receives the next image's tile)
     if (GENC1) {
         // first tile: its gray tile, then its first chunk computed up front (every later chunk is computed under its predecessor's taps)
@@ -431,9 +491,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         for (int k = 0; k < GEN_PER_WAVE; ++k) gen_c1(k * NWAVE + wave, 0, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    issue(n, 0, 0, -1);
+    MX_TL(13);                           // parameters staged, offsets computed: the first chunk's DMA goes out
     int buf = 0;
     bool dma_waited = false;
+    // NB = 3 (the latency loop): the stream of chunks this workgroup walks - (image, chunk) pairs across image boundaries - is issued two
+    // ahead of the one being computed.  l_img / l_ck: the next chunk to issue, l_ibuf: the buffer it goes to, l_cbuf: the buffer being
+    // computed from, l_ahead: "a chunk was issued behind the one the next wait is for" (then the wait leaves DMA_PER_CHUNK instructions
+    // outstanding: LDS-DMA pieces land in issue order)
+    int l_cbuf = 0, l_ibuf = 0, l_img = n, l_ck = 0;
+    bool l_ahead = false, l_first = true;
+    auto issue_next = [&]() -> bool {              // (the prologue's two chunks, each in one burst)
+        if (l_img >= a.n) return false;
+        issue(l_img, l_ck, l_ibuf, -1);
+        l_ibuf = l_ibuf == NB - 1 ? 0 : l_ibuf + 1;
+        if (++l_ck == nchunks) { l_ck = 0; l_img += img_step; }
+        return true;
+    };
+    auto wait_dma = [&](bool ahead) {
+        if (ahead) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_CHUNK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if constexpr (NB == 3) { issue_next(); l_ahead = issue_next(); stage_params(); }
+    else issue(n, 0, 0, -1);
 
     for (;;) {
     MX_TL(1);                            // tile start
@@ -564,7 +643,147 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         }
     };
     using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>; using KT = std::integral_constant<int, 3>;
-    if constexpr (X3) {
+    if constexpr (NB == 3) {
+        // ---- the latency loop (see the template parameter NB) ---------------------------------------------------------------------
+        //     chunk s, tap t < 8:  read frags(t + 1) | MFMAs(t)
+        //     chunk s, tap 8:      wait for chunk s + 1 (own pieces; chunk s + 2's may stay in flight), own reads of chunk s returned,
+        //                          s_barrier; issue chunk s + 3 into chunk s's buffer; read frags(chunk s + 1, tap 0) | MFMAs(8)
+        // Buffer protocol: the barrier B(s+1) inside tap 8 of chunk s separates every wave's last read of chunk s's buffer from the first DMA
+        // write into it (chunk s + 3's, issued right behind the barrier) and every wave's DMA pieces of chunk s + 1 from the first read of
+        // them.  A tile's first chunk has its barrier at the top (the previous tile's epilogue lies in between and has waited for everything
+        // in flight).  The barrier skew and a chunk's first LDS latency run under the previous tap's MFMAs.
+        struct Frag { i32x4 a0, a1, b0, b1; };
+        constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;      // (the tap order of the tile width: as in the throughput loop)
+        auto slot_tap = [](int slot) { const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3; return ky * 3 + kx; };
+        auto slot_live = [&](int slot) -> bool { return !MASKED || ((tmask >> slot_tap(slot)) & 1u); };
+        auto load_frags = [&](auto kind_tag, int cb, int slot, Frag& f) __attribute__((always_inline)) {
+            constexpr bool ISQ = decltype(kind_tag)::value == 1;
+            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
+            const int tap = ky * 3 + kx;
+            int bufoff = cb * BUF_BYTES;
+            asm("" : "+s"(bufoff));                                  // an opaque scalar, added per read (no table of 9 addresses in registers)
+            const int c0 = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
+            const int c1 = ISQ ? (c0 ^ 16) : c0 + PLANE_B;
+            constexpr int RB = G::PITCH * 32;
+            const int rowc = ky * RB;                                  // (MT = 1: the wave's one M block; compile-time: the ds_read's immediate)
+            f.a0 = *reinterpret_cast<const i32x4*>(smem + c0 + rowc);
+            f.a1 = *reinterpret_cast<const i32x4*>(smem + c1 + rowc);
+            const char* sW = smem + bufoff + A_BYTES;
+            const int off = w_off + tap * 2 * WBLK;
+            f.b0 = *reinterpret_cast<const i32x4*>(sW + off);
+            f.b1 = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
+        };
+        // Taps go in GROUPS of three: the fragments of a group are read (12 ds_read_b128) while the previous group's MFMAs - 9 / 6 / 3 of
+        // them, back to back on the wave's one accumulator - run.  A wave alone on its SIMD pays for every instruction that stands between two
+        // MFMAs of one accumulator chain (MI355X_MICROARCH.md: +43 cycles for the first issue slot in such a gap, ~6 for each further one), so
+        // the chain is broken three times per chunk, not nine.
+        struct Grp { Frag t[3]; };
+        Grp pf;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pf.t[i] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+        auto load_group = [&](auto kind_tag, int cb, int g, Grp& f) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (slot_live(3 * g + i)) load_frags(kind_tag, cb, 3 * g + i, f.t[i]);
+        };
+        // FIRST / LAST: the tile's first / last chunk, as compile-time flags - with run-time branches the compiler's wait-count pass merges
+        // the paths and makes a group's MFMA run wait for LDS reads it does not use
+        auto chunk_lat = [&](auto kind_tag, auto next_tag, auto first_tag, auto last_tag) {
+            constexpr int KIND = decltype(kind_tag)::value;
+            constexpr bool ISQ = KIND == 1;
+            constexpr bool pf_valid = !decltype(first_tag)::value, last = decltype(last_tag)::value;
+            MX_TL(2);
+            Grp cur = pf;
+            if constexpr (!pf_valid) {
+                if (l_first) { wait_dma(l_ahead); l_first = false; }      // (later tiles: their predecessor's epilogue has waited for everything in flight)
+                MX_TL(3);
+                __builtin_amdgcn_s_barrier();
+                load_group(kind_tag, l_cbuf, 0, cur);
+            }
+            MX_TL(ISQ ? 5 : 4);
+            // the chunk two ahead of this one goes out during this chunk's taps (its buffer - the previous chunk's - was freed by the barrier
+            // this chunk started behind), three ninths per group
+            const bool iss = l_img < a.n;
+            const int i_img = l_img, i_ck = l_ck, i_buf = l_ibuf;
+            if (iss) {
+                l_ibuf = l_ibuf == NB - 1 ? 0 : l_ibuf + 1;
+                if (++l_ck == nchunks) { l_ck = 0; l_img += img_step; }
+            }
+            const int nbuf = l_cbuf == NB - 1 ? 0 : l_cbuf + 1;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                Grp nxt = cur;
+                if (g < 2) load_group(kind_tag, l_cbuf, g + 1, nxt);
+                else if constexpr (!last) {
+                    // every DMA piece this wave issued for the next chunk has landed (the pieces of the chunk behind it, issued during this one's
+                    // taps, may stay in flight), every fragment read of this chunk has returned
+                    MX_TL(10);
+                    wait_dma(iss);
+                    // (the builtin, not an asm: the compiler's wait-count pass then KNOWS that this chunk's reads have returned; behind an opaque
+                    // asm it believed them outstanding next to the 12 new ones - more than the 4-bit counter can express - and made the
+                    // MFMA run below wait for the new reads)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
+                    __builtin_amdgcn_s_barrier();
+                    MX_TL(11);
+                    load_group(next_tag, nbuf, 0, pf);
+                }
+                if (iss) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) issue(i_img, i_ck, i_buf, 3 * g + i);
+                }
+                // this group's fragments have returned (the next group's 12 reads may stay in flight): ONE wait in front of the run, none inside
+                // it - an s_waitcnt between two MFMAs of the chain is an issue slot like any other
+                if (g < 2) __builtin_amdgcn_s_waitcnt(0xcc7f);        // lgkmcnt(12)
+                else if constexpr (last) __builtin_amdgcn_s_waitcnt(0xc07f);
+                // (the scheduler otherwise sinks the reads into the MFMA run)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NWAVE >= 8) {      // two waves per SIMD: alternate their priority group by group
+                    if ((g + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (!slot_live(3 * g + i)) continue;
+                    const Frag& f = cur.t[i];
+                    if (ISQ) {
+                        const i32x8 bw = {f.b0[0], f.b0[1], f.b0[2], f.b0[3], f.b1[0], f.b1[1], f.b1[2], f.b1[3]};
+                        const i32x8 ap = {f.a0[0], f.a0[1], f.a0[2], f.a0[3], f.a1[0], f.a1[1], f.a1[2], f.a1[3]};
+                        acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[0][0], QFMT, QFMT, 0, Q6 ? f.b1[2] : wsc[0], 0, Q6 ? f.a1[2] : asc0);
+                    } else if (KIND == 2) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b1), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a1), acc[0][0], 0, 0, 0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
+                    } else {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b1), __builtin_bit_cast(f16x8, f.a1), acc[0][0], 0, 0, 0);
+                    }
+                }
+                {
+                    float pin = acc[0][0][0];                  // (pins this group's MFMAs here: see the throughput loop)
+                    asm volatile("" : "+v"(pin));
+                    acc[0][0][0] = pin;
+                }
+                cur = nxt;
+            }
+            l_cbuf = nbuf;
+        };
+        using Yes = std::true_type; using No = std::false_type;
+        if constexpr (X3) {
+            if (nchunks == 1) chunk_lat(K3{}, K3{}, Yes{}, Yes{});
+            else {
+                chunk_lat(K3{}, K3{}, Yes{}, No{});
+                for (int ck = 1; ck + 1 < nchunks; ++ck) chunk_lat(K3{}, K3{}, No{}, No{});
+                chunk_lat(K3{}, K3{}, No{}, Yes{});
+            }
+        } else {
+            // (H, Q) pairs: nchunks is even
+            chunk_lat(KH{}, KQ{}, Yes{}, No{});
+            for (int ck = 2; ck < nchunks; ck += 2) {
+                chunk_lat(KQ{}, KH{}, No{}, No{});
+                chunk_lat(KH{}, KQ{}, No{}, No{});
+            }
+            chunk_lat(KQ{}, KH{}, No{}, Yes{});
+        }
+    } else if constexpr (X3) {
         for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck);
     } else if constexpr (XQ) {
         for (int ck = 0; ck < nchunks; ck += 5) {
@@ -1016,15 +1235,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 
 inline int num_cus_mx() { return num_cus_current(); }
 
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0, bool GENC1 = false>
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0, bool GENC1 = false, int NB = 2>
 int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
     using G = GeoMx<TW, TH, STRIDE>;
     constexpr int A_BYTES = ((2 * G::NPIX * 2 + 63) / 64) * 1024;
     // GENC1: + two gray tiles (256-byte pieces) and 10 floats per input channel of the fused producer (64 channels at most)
     constexpr int GT_BYTES = (((G::TWI + 2) * (G::THI + 2) + 63) / 64) * 256;
-    constexpr int smem = 2 * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4 + (GENC1 ? 2 * GT_BYTES + 64 * 10 * 4 : 0);
+    // NB = 3: + the 1 KiB dump area of the out-of-range DMA pieces
+    constexpr int smem = NB * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4 + (GENC1 ? 2 * GT_BYTES + 64 * 10 * 4 : 0) + (NB == 3 ? 1024 : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR, GENC1>;
+    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR, GENC1, NB>;
     // function attributes are per device and per kernel instantiation (this static lives in the instantiation)
     static std::atomic<int> attr_done[DISCO_MAX_DEVICES];
     DISCO_HIP_CHECK(set_dyn_lds_once(attr_done, reinterpret_cast<const void*>(kern), smem));
@@ -1043,13 +1263,21 @@ int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
     DISCO_LAUNCH_CHECK("conv3x3_mx_kernel");
     return DISCO_OK;
 }
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, int AR>
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, int AR, int NB = 2>
 int launch_mx2(const ConvMxArgs& a, hipStream_t s) {
     if constexpr (AR == 1) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, 1>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, 1>(a, s);
     else {
-        if (a.nsrc > 1) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, true, AR>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, true, AR>(a, s);
-        return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, AR>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, AR>(a, s);
+        if constexpr (!(AR == 0 && NB == 3)) {       // (the f16+fp8x2 two-source layer ends in a tail chunk: throughput loop only; the dispatcher does not come here with it)
+            if (a.nsrc > 1) return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, true, AR, false, NB>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, true, AR, false, NB>(a, s);
+        }
+        return a.tapmask ? launch_mx4<TW, TH, NT, STRIDE, WM, WN, true, false, AR, false, NB>(a, s) : launch_mx4<TW, TH, NT, STRIDE, WM, WN, false, false, AR, false, NB>(a, s);
     }
+}
+
+// DISCO_CONV_LAT=0: the latency loop off (A/B runs: small grids then take round 4's tiles and loop; results are bit-identical either way)
+inline bool conv_lat_enabled() {
+    static const bool on = [] { const char* e = std::getenv("DISCO_CONV_LAT"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 }  // namespace
@@ -1063,11 +1291,16 @@ int dispatch_mx_ar(const ConvMxArgs& a, hipStream_t s) {
         if (a.c1_gray) return launch_mx4<32, 16, 2, 1, 8, 1, false, false, 2, true>(a, s);       // (launch_conv3x3_x3 has checked the shape)
     }
     if (a.stride == 1) {
+        // Candidates in order of efficiency at full load; the first that fills 3/4 of the CUs is taken, else the one with most workgroups.
+        // The last three run the LATENCY loop (NB = 3; round 5): they are only reached when the launch cannot fill the GPU with the big tiles.
+        // Every candidate a layer can take accumulates in the same order (the tap order is tied to the tile WIDTH; a 16-wide tile is only
+        // offered to images at most 16 wide), so an image's result does not depend on the batch it is part of.
         struct Cand { int tw, th, nt; };
-        static const Cand order[6] = {{32, 16, 2}, {32, 16, 1}, {32, 8, 2}, {16, 16, 2}, {32, 8, 1}, {16, 16, 1}};
+        static const Cand order[7] = {{32, 16, 2}, {32, 16, 1}, {32, 8, 2}, {16, 16, 2}, {32, 8, 1}, {16, 16, 1}, {32, 4, 1}};
+        const bool lat = AR != 1 && !(AR == 0 && a.nsrc > 1) && conv_lat_enabled();
         const long fill = (long)num_cus_mx() * 3 / 4;
         int pick = -1; long best = -1;
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < (lat ? 7 : 6); ++i) {
             const Cand& c = order[i];
             if ((c.nt == 2 && !nt2) || (c.tw == 32 && !wide) || (c.tw == 32 && c.th == 16 && a.h_out <= 8)) continue;
             const long w = (long)cdiv(a.w_out, c.tw) * cdiv(a.h_out, c.th) * cdiv(a.c_out, 32 * c.nt) * a.n;
@@ -1079,8 +1312,15 @@ int dispatch_mx_ar(const ConvMxArgs& a, hipStream_t s) {
             case 1: return launch_mx2<32, 16, 1, 1, 8, 1, AR>(a, s);
             case 2: return launch_mx2<32, 8, 2, 1, 4, 2, AR>(a, s);
             case 3: return launch_mx2<16, 16, 2, 1, 4, 2, AR>(a, s);
-            case 4: return launch_mx2<32, 8, 1, 1, 8, 1, AR>(a, s);
-            default: return launch_mx2<16, 16, 1, 1, 8, 1, AR>(a, s);
+            case 4:
+                if constexpr (AR != 1) { if (lat) return launch_mx2<32, 8, 1, 1, 8, 1, AR, 3>(a, s); }
+                return launch_mx2<32, 8, 1, 1, 8, 1, AR>(a, s);
+            case 6:
+                if constexpr (AR != 1) return launch_mx2<32, 4, 1, 1, 4, 1, AR, 3>(a, s);
+                [[fallthrough]];
+            default:
+                if constexpr (AR != 1) { if (lat) return launch_mx2<16, 16, 1, 1, 8, 1, AR, 3>(a, s); }
+                return launch_mx2<16, 16, 1, 1, 8, 1, AR>(a, s);
         }
     }
     if (wide) return nt2 ? launch_mx2<32, 4, 2, 2, 4, 2, AR>(a, s) : launch_mx2<32, 4, 1, 2, 4, 1, AR>(a, s);

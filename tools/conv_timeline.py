@@ -31,6 +31,22 @@ SHAPES = [  # name, cin0, cin1, cout, h_in, stride, up0
 EVENTS = 8192
 
 
+def run_shape_x3(L, name, c0, c1, co, hin, stride, up0, n=64):
+    """The f16x3 arithmetic (ColorProbNet / SpixelNet): plain hi + lo act tensors through disco_op_conv3x3."""
+    hs = hin // 2 if up0 else hin
+    src0 = torch.relu(torch.randn(2, n, hs, hs, c0, device="cuda")).half()
+    w = torch.randn(co, c0, 3, 3) * 0.05
+    packed = H.pack_conv(w)
+    ho = (hin - 1) // stride + 1
+    out = torch.empty(2, n, ho, ho, co, device="cuda", dtype=torch.float16)
+    bias = torch.zeros(co, device="cuda")
+    d = _ffi.ConvDesc(n, hin, hin, c0, 0, up0, 0, co, stride, _ffi.ACT_RELU, 0.0, 0)
+
+    def run():
+        _ffi.check(L.disco_op_conv3x3(C.byref(d), _ffi.ptr(src0), None, _ffi.ptr(packed), _ffi.ptr(bias), None, None, None, _ffi.ptr(out), H.stream()))
+    return measure(L, L.disco_diag_conv_timeline_x3, run, name, c0, co, ho, n, (c0 // 16) * 27 * 2 * 32)
+
+
 def run_shape(L, name, c0, c1, co, hin, stride, up0, n=64):
     hs = hin // 2 if up0 else hin
     planes = _ffi.PLANE_Q6
@@ -48,20 +64,36 @@ def run_shape(L, name, c0, c1, co, hin, stride, up0, n=64):
     def run():
         _ffi.check(L.disco_op_conv3x3_mx(C.byref(d), _ffi.ptr(x0.buf), _ffi.ptr(x1.buf) if x1 else None, _ffi.ptr(packed), _ffi.ptr(wexp),
                                         _ffi.ptr(bias), None, None, None, _ffi.ptr(out if f32 else out.buf), None, None, H.stream()))
+    return measure(L, L.disco_diag_conv_timeline, run, name, c0 + c1, co, ho, n, (c0 + c1) // 32 * 6912)
+
+
+def measure(L, diag, run, name, cin, co, ho, n, pipe_cycles):
     for _ in range(20):                      # warm: clocks at their sustained level
         run()
     torch.cuda.synchronize()
     buf = np.zeros((2, EVENTS), np.uint64)
-    assert L.disco_diag_conv_timeline(None, 1) == 0
+    assert diag(None, 1) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    assert L.disco_diag_conv_timeline(buf.ctypes.data_as(C.c_void_p), 0) == 0
-    fl = 2.0 * 9 * (c0 + c1) * co * ho * ho * n
-    nch = (c0 + c1) // 16
-    print("==== %s: %.3f ms (instrumented), %.0f TF alg; %d chunks per tile; MFMA pipe time per tile and SIMD: %d cycles (H chunk 4608, Q chunk 2304)"
-          % (name, ms, fl / ms / 1e9, nch, nch // 2 * 6912))
+    assert diag(buf.ctypes.data_as(C.c_void_p), 0) == 0
+    fl = 2.0 * 9 * cin * co * ho * ho * n
+    nch = cin // 16
+    print("==== %s, n = %d: %.4f ms (instrumented), %.0f TF alg; %d chunks per tile; MFMA pipe time per tile and SIMD at 2 waves per SIMD on the 8-wave tiles: %d cycles"
+          % (name, n, ms, fl / ms / 1e9, nch, pipe_cycles))
+    if RAW:
+        # every stamp of the first tile of the last wave: tag, cycles since the previous stamp (s_memtime runs at 100 MHz x ... see the header: the
+        # unit is the constant-rate counter, NOT shader clocks; the tile total against the launch time above gives the conversion)
+        cnt = int(buf[1, 0])
+        ev = [(int(v) >> 4, int(v) & 15) for v in buf[1, 1:min(cnt, EVENTS)]]
+        names = {1: "tile", 2: "chunk", 3: "dma-landed", 4: "barrier(H)", 5: "barrier(Q)", 6: "taps-done", 7: "epi-math", 8: "epi-wait", 9: "stores", 10: "tap8", 11: "barrier-in-tap8", 12: "entry", 13: "prologue"}
+        line = []
+        for i in range(1, len(ev)):
+            line.append("%s+%d" % (names.get(ev[i][1], str(ev[i][1])), ev[i][0] - ev[i - 1][0]))
+            if ev[i][1] == 9:
+                break
+        print("  raw (last wave, first tile): total %d ticks | %s" % (ev[min(len(line), len(ev) - 1)][0] - ev[0][0], " ".join(line)))
     for w in range(2):
         cnt = int(buf[w, 0])
         ev = [(int(v) >> 4, int(v) & 15) for v in buf[w, 1:min(cnt, EVENTS)]]
@@ -106,16 +138,35 @@ def run_shape(L, name, c0, c1, co, hin, stride, up0, n=64):
                  100 * (avg("epi_math") + avg("epi_wait") + avg("epi_store")) / tot, 100 * (nch // 2 * 6912) / tot))
 
 
+RAW = False
+X3_SHAPES = [("f16x3 512->512 @32", 512, 0, 512, 32, 1, 0), ("f16x3 256->256 @64", 256, 0, 256, 64, 1, 0), ("f16x3 128->128 @128", 128, 0, 128, 128, 1, 0)]
+
+
 def main():
+    global RAW
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("only", nargs="?", default="")
+    ap.add_argument("--n", type=int, default=64)
+    ap.add_argument("--raw", action="store_true", help="also print every stamp of the first tile (small n: where does a launch's latency go?)")
+    ap.add_argument("--x3", action="store_true", help="the f16x3 shapes (needs conv_mx_ar2.hip built with -DMX_TIMELINE=1 as well)")
+    args = ap.parse_args()
+    RAW = args.raw
     L = _ffi.lib()
     if not hasattr(L, "disco_diag_conv_timeline"):
         raise SystemExit("this library has no timeline probe: build with -DMX_TIMELINE=1 and point DISCO_HIP_LIB at it")
-    L.disco_diag_conv_timeline.restype = C.c_int
-    L.disco_diag_conv_timeline.argtypes = [C.c_void_p, C.c_int]
-    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    for f in ("disco_diag_conv_timeline", "disco_diag_conv_timeline_x3"):
+        if hasattr(L, f):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+    if args.x3:
+        for s in X3_SHAPES:
+            if args.only in s[0]:
+                run_shape_x3(L, *s, n=args.n)
+        return
     for s in SHAPES:
-        if only in s[0]:
-            run_shape(L, *s)
+        if args.only in s[0]:
+            run_shape(L, *s, n=args.n)
 
 
 if __name__ == "__main__":
