@@ -171,13 +171,20 @@ struct GeoMx {
 // ahead, right behind the barrier that frees its buffer; fragment reads run one tap ahead of the MFMAs; the chunk barrier sits inside the
 // last tap of the preceding chunk.  Same chunks, same taps, same MFMAs in the same order per accumulator: results are bit-identical to NB = 2.
 template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR, bool GENC1 = false, int NB = 2>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
+__global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
     constexpr bool XQ = AR == 1, X3 = AR == 2, Q6 = AR == 3;
     constexpr int QFMT = Q6 ? 2 : MX_QFMT;                // operand format code of the K = 64 MFMA: 0 = fp8 e4m3, 2 = fp6 e2m3
     static_assert(!(XQ && NSRC2), "the f16x2+fp8 arithmetic takes one source");
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = GeoMx<TW, TH, STRIDE>;
     constexpr int NWAVE = WM * WN;
+    // The latency loop is wave-specialised: NWAVE CONSUMER waves (fragment reads, MFMAs, epilogue) and NPROD = 4 PRODUCER waves, one per SIMD,
+    // which do nothing but issue the LDS-DMA and wait for it.  A consumer alone on its SIMD pays for every instruction between two MFMAs of
+    // its accumulator chain, and an LDS-DMA piece costs 60-180 issue cycles there (measured: three pieces per tap group were ~270 of a
+    // group's ~560 cycles); in a wave of its own the issue runs next to the consumer's MFMAs.
+    constexpr int NPROD = NB == 3 ? 4 : 0;
+    constexpr int NDW = NPROD ? NPROD : NWAVE;                // waves that issue DMA
+    constexpr int NTHR = (NWAVE + NPROD) * 64;
     constexpr int MT = G::MB / WM;
     constexpr int NTW = NT / WN;
     static_assert(G::MB % WM == 0 && NT % WN == 0, "tile split");
@@ -187,8 +194,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     constexpr int A_BYTES = A_PIECES * 1024;
     constexpr int W_PIECES = NT * 18;
     constexpr int BUF_BYTES = A_BYTES + W_PIECES * 1024;
-    constexpr int APW = (A_PIECES + NWAVE - 1) / NWAVE;
-    constexpr int WPW = (W_PIECES + NWAVE - 1) / NWAVE;
+    constexpr int APW = (A_PIECES + NDW - 1) / NDW;
+    constexpr int WPW = (W_PIECES + NDW - 1) / NDW;
     constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;
     constexpr int PAR_OFF = NB * BUF_BYTES;
     static_assert(NB == 2 || NB == 3, "two or three LDS buffers");
@@ -207,11 +214,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     static_assert(!GENC1 || (AR == 2 && STRIDE == 1 && !NSRC2 && !MASKED), "the fused Cin = 1 producer exists for plain f16x3 layers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    if constexpr (NB == 3) {
+        // Touch every 64-byte line of the kernel-argument segment NOW, in one burst of scalar loads: the compiler reads the arguments where it
+        // needs them, in five or six dependent batches, and each batch is a cold miss of its own (the segment is written per launch: nothing of
+        // it is cached) - ~3 000 cycles before the first DMA piece could leave (s_memtime stamps of a producer wave, profiles/r05_latency_loop.txt).
+        // After this, they hit the scalar cache.
+        typedef const __attribute__((address_space(4))) unsigned KWord;
+        KWord* ka = (KWord*)__builtin_amdgcn_kernarg_segment_ptr();
+        constexpr int LINES = (int)((sizeof(ConvMxArgs) + 63) / 64);
+        unsigned t[LINES];
+#pragma unroll
+        for (int i = 0; i < LINES; ++i) t[i] = ka[16 * i];
+#pragma unroll
+        for (int i = 0; i < LINES; ++i) asm volatile("" :: "s"(t[i]));
+    }
+
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
+    const bool producer = NPROD > 0 && wave >= NWAVE;             // (wave-uniform)
+    const int dwv = NPROD ? wave - NWAVE : wave;                  // this wave's index among the DMA-issuing waves (consumers of the latency loop: unused)
+    const int wm = producer ? 0 : wave % WM, wn = producer ? 0 : wave / WM;
 #if MX_TIMELINE
-    const bool tl_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == NWAVE - 1);
+    // (the latency loop: the second trace is the first PRODUCER wave's)
+    const bool tl_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == (NB == 3 ? NWAVE : NWAVE - 1));
     const int tl_w = wave == 0 ? 0 : 1;
     int tl_n = 1;
     MX_TL(12);                           // kernel entry
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
 
     float* s_par = reinterpret_cast<float*>(smem + PAR_OFF);
     auto stage_params = [&]() {
-        for (int i = tid; i < 3 * 32 * NT; i += NWAVE * 64) {
+        for (int i = tid; i < 3 * 32 * NT; i += NWAVE * 64) {          // (the latency loop's consumers: tid < NWAVE * 64)
             const int which = i / (32 * NT), c = i - which * (32 * NT);
             const int co = by * NT * 32 + c;
             const int cpar = a.d2s_c > 0 ? co % a.d2s_c : co;
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     // E8M0 scale operands of the fp8 products: weight side per lane (= per output channel row), pixel side uniform per source
     int wsc[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) wsc[j] = (X3 || Q6) ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];       // (wexp: fp8 scaling per output channel, conv_mx_pack_host; fp6 weight slots carry a block scale each: below)
+    for (int j = 0; j < NTW; ++j) wsc[j] = (X3 || Q6 || producer) ? 0 : 127 - MX_LO_SHIFT - a.wexp[(by * NT + wn * NTW + j) * 32 + (lane & 31)];       // (wexp: fp8 scaling per output channel, conv_mx_pack_host; fp6 weight slots carry a block scale each: below)
     // pixel-side E8M0 scale: 1 (the tensor's scale stays in the accumulators)
     constexpr int asc0 = 127, asc1 = asc0;                // fp8 activation planes: no block scale.  fp6 slots: dword 6 of the fragment (below)
 
@@ -346,14 +371,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     constexpr int GEN_ITERS = ((G::NPIX + 63) / 64) * 2;                 // wave-iterations per chunk
     constexpr int GEN_PER_WAVE = (GEN_ITERS + NWAVE - 1) / NWAVE;
     unsigned voff[NS][APW];           // per source: byte offset (plane included) of this lane's 16 bytes inside a chunk, or OOB
-    if (!GENC1) {
+    auto compute_voff = [&]() {
+        if (GENC1) return;
         const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1;
+        // (the geometry in scalar registers up front, the range test without short-circuit branches: the compiler otherwise re-reads the
+        // argument segment inside a branch per entry and test - a dozen dependent scalar-load round trips on the way to the first pixel piece)
+        int h_in = a.h_in, w_in = a.w_in;
+        asm volatile("" : "+s"(h_in), "+s"(w_in));
 #pragma unroll
         for (int si = 0; si < NS; ++si) {
-            const MxSrc& sp = a.src[si];
+            int sp_h = a.src[si].h, sp_w = a.src[si].w, sp_up = a.src[si].up;
+            unsigned sp_qoff = a.src[si].q_off;
+            asm volatile("" : "+s"(sp_h), "+s"(sp_w), "+s"(sp_up), "+s"(sp_qoff));
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
-                const int u = (i * NWAVE + wave) * 64 + lane;
+                const int u = (i * NDW + dwv) * 64 + lane;
                 const int plane = u / (G::NPIX * 2);
                 const int rem = u - plane * (G::NPIX * 2);
                 const int p = rem >> 1, j = rem & 1;
@@ -362,17 +394,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                 int px;
                 bool slot_ok = u < A_UNITS;
                 if (STRIDE == 1) px = q;
-                else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok && px < G::TWI; }
+                else { const int par = q / G::HALF; px = (q - par * G::HALF) * 2 + par; slot_ok = slot_ok & (px < G::TWI); }
                 const int gy = iy0 + py, gx = ix0 + px;
-                const bool in = slot_ok && gy >= 0 && gy < a.h_in && gx >= 0 && gx < a.w_in;
+                const bool in = slot_ok & (gy >= 0) & (gy < h_in) & (gx >= 0) & (gx < w_in);
                 // both chunk kinds keep their second plane h*w*32 bytes after the first (the next 16-channel block of the hi
                 // plane / the al8 plane of the q block), so one offset serves both
                 // (X3: the second plane is the tensor's lo plane, q_off bytes after the hi plane)
-                if (X3) voff[si][i] = in ? (unsigned)plane * sp.q_off + (unsigned)((gy >> sp.up) * sp.w + (gx >> sp.up)) * 32u + kh * 16u : OOB;
-                else voff[si][i] = in ? (unsigned)((plane * sp.h + (gy >> sp.up)) * sp.w + (gx >> sp.up)) * 32u + kh * 16u : OOB;
+                const unsigned o3 = (unsigned)plane * sp_qoff + (unsigned)((gy >> sp_up) * sp_w + (gx >> sp_up)) * 32u + kh * 16u;
+                const unsigned o0 = (unsigned)((plane * sp_h + (gy >> sp_up)) * sp_w + (gx >> sp_up)) * 32u + kh * 16u;
+                voff[si][i] = in ? (X3 ? o3 : o0) : OOB;
             }
         }
-    }
+    };
+    if constexpr (NB == 2) compute_voff();       // (the latency loop's producers compute them behind their first weight pieces)
     const int c_src0 = a.src[0].c;
     const unsigned img_b0 = (unsigned)(a.src[0].c * a.src[0].h * a.src[0].w) * 2u, blk_b0 = (unsigned)(a.src[0].h * a.src[0].w) * 32u;
     const unsigned img_b1 = (unsigned)(a.src[NS - 1].c * a.src[NS - 1].h * a.src[NS - 1].w) * 2u, blk_b1 = (unsigned)(a.src[NS - 1].h * a.src[NS - 1].w) * 32u;
@@ -400,14 +434,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
         char* dW = dA + A_BYTES;
         const bool tail = NSRC2 && AR == 0 && (nchunks & 1) && ck == nchunks - 1;       // 16-channel H-only chunk: plane 0 alone
         if constexpr (NB == 3) {
-            // the latency loop: every wave issues exactly DMA_PER_CHUNK instructions per chunk (its s_waitcnt counts them), one (or two) per
-            // tap of the chunk computed meanwhile; a piece beyond the tile reads out of range (zeros, no memory traffic) into the dump area;
-            // masked taps' weights are fetched like the others
+            // the latency loop: every producer wave issues exactly DMA_PER_CHUNK instructions per chunk (its s_waitcnt counts them); a piece
+            // beyond the tile reads out of range (zeros, no memory traffic) into the dump area; masked taps' weights are fetched like the others
+            // (part -1: the whole chunk; -2: its weight pieces only, -3: its pixel pieces only - the first chunk of the stream goes out in that order,
+            // with the per-lane pixel offsets computed in between)
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
-                if (part >= 0 && (i * 9) / DMA_PER_CHUNK != part) continue;
-                const int piece = i * NWAVE + wave;
-                const bool ok = (i + 1) * NWAVE <= A_PIECES || piece < A_PIECES;
+                if (part == -2) break;
+                const int piece = i * NDW + dwv;
+                const bool ok = (i + 1) * NDW <= A_PIECES || piece < A_PIECES;
                 char* dst = ok ? dA + piece * 1024 : smem + DUMP_OFF;
                 unsigned v0 = voff[0][i], v1 = voff[NS - 1][i];
                 if (NSRC2) asm("" : "+v"(v0), "+v"(v1));
@@ -417,9 +452,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             }
 #pragma unroll
             for (int i = 0; i < WPW; ++i) {
-                if (part >= 0 && ((APW + i) * 9) / DMA_PER_CHUNK != part) continue;
-                const int piece = i * NWAVE + wave;
-                const bool ok = (i + 1) * NWAVE <= W_PIECES || piece < W_PIECES;
+                if (part == -3) break;
+                const int piece = i * NDW + dwv;
+                const bool ok = (i + 1) * NDW <= W_PIECES || piece < W_PIECES;
                 const int nt = piece / 18, q = piece - nt * 18;
                 char* dst = ok ? dW + piece * 1024 : smem + DUMP_OFF;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, ok ? (unsigned)lane * 16u : OOB,
@@ -494,25 +529,55 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
     MX_TL(13);                           // parameters staged, offsets computed: the first chunk's DMA goes out
     int buf = 0;
     bool dma_waited = false;
-    // NB = 3 (the latency loop): the stream of chunks this workgroup walks - (image, chunk) pairs across image boundaries - is issued two
-    // ahead of the one being computed.  l_img / l_ck: the next chunk to issue, l_ibuf: the buffer it goes to, l_cbuf: the buffer being
-    // computed from, l_ahead: "a chunk was issued behind the one the next wait is for" (then the wait leaves DMA_PER_CHUNK instructions
-    // outstanding: LDS-DMA pieces land in issue order)
-    int l_cbuf = 0, l_ibuf = 0, l_img = n, l_ck = 0;
-    bool l_ahead = false, l_first = true;
-    auto issue_next = [&]() -> bool {              // (the prologue's two chunks, each in one burst)
-        if (l_img >= a.n) return false;
-        issue(l_img, l_ck, l_ibuf, -1);
-        l_ibuf = l_ibuf == NB - 1 ? 0 : l_ibuf + 1;
-        if (++l_ck == nchunks) { l_ck = 0; l_img += img_step; }
-        return true;
-    };
-    auto wait_dma = [&](bool ahead) {
-        if (ahead) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_CHUNK) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    if constexpr (NB == 3) { issue_next(); l_ahead = issue_next(); stage_params(); }
-    else issue(n, 0, 0, -1);
+    int l_cbuf = 0;                      // NB = 3: the LDS buffer the consumers compute from
+    if constexpr (NB == 3) {
+        // ---- the latency loop's PRODUCER waves -------------------------------------------------------------------------------------
+        // The stream of chunks this workgroup walks - (image, chunk) pairs across image boundaries - is issued two ahead of the one being
+        // computed, each chunk in one burst into the buffer that barrier B(s) has just freed:
+        //     for every chunk s of the stream:  wait until chunk s has landed (chunk s + 1, issued behind it, may stay in flight: LDS-DMA
+        //     pieces land in issue order and every wave issues exactly DMA_PER_CHUNK of them per chunk); s_barrier B(s) - the consumers
+        //     arrive there with their reads of chunk s - 1 returned; issue chunk s + 2 into chunk s - 1's buffer.
+        // One barrier per chunk, shared with the consumers (below); while the consumers run a tile's epilogue the producers sit in the next
+        // tile's first barrier with its first two chunks in flight.
+        if (producer) {
+            int l_ibuf = 0, l_img = n, l_ck = 0;
+            auto issue_next = [&]() -> bool {
+                if (l_img >= a.n) return false;
+                issue(l_img, l_ck, l_ibuf, -1);
+                l_ibuf = l_ibuf == NB - 1 ? 0 : l_ibuf + 1;
+                if (++l_ck == nchunks) { l_ck = 0; l_img += img_step; }
+                return true;
+            };
+            MX_TL(13);
+            issue(n, 0, 0, -2);                                   // the first chunk's weights: nothing to compute for them
+            MX_TL(14);
+            compute_voff();
+            MX_TL(15);
+            issue(n, 0, 0, -3);
+            l_ibuf = 1;
+            if (++l_ck == nchunks) { l_ck = 0; l_img += img_step; }
+            MX_TL(14);
+            bool ahead = issue_next();
+            MX_TL(15);
+            for (int img = n; img < a.n; img += img_step)
+                for (int ck = 0; ck < nchunks; ++ck) {
+                    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_CHUNK) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    MX_TL(3);
+                    __builtin_amdgcn_s_barrier();
+                    MX_TL(4);
+                    ahead = issue_next();
+                    MX_TL(2);
+                }
+#if MX_TIMELINE
+            if (tl_on && lane == 0) g_mx_tl[tl_w][0] = (unsigned long long)tl_n;
+#endif
+            return;
+        }
+        stage_params();                                           // (the consumers: the producers have nothing in flight but DMA pieces, which is what their s_waitcnt counts)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the staged parameters are written
+        __builtin_amdgcn_s_setprio(2);                            // the consumers' MFMAs before the producers' address arithmetic
+    } else issue(n, 0, 0, -1);
 
     for (;;) {
     MX_TL(1);                            // tile start
@@ -695,30 +760,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
             MX_TL(2);
             Grp cur = pf;
             if constexpr (!pf_valid) {
-                if (l_first) { wait_dma(l_ahead); l_first = false; }      // (later tiles: their predecessor's epilogue has waited for everything in flight)
                 MX_TL(3);
-                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();                     // B(s) of the tile's first chunk: the producers have seen it land
                 load_group(kind_tag, l_cbuf, 0, cur);
             }
             MX_TL(ISQ ? 5 : 4);
-            // the chunk two ahead of this one goes out during this chunk's taps (its buffer - the previous chunk's - was freed by the barrier
-            // this chunk started behind), three ninths per group
-            const bool iss = l_img < a.n;
-            const int i_img = l_img, i_ck = l_ck, i_buf = l_ibuf;
-            if (iss) {
-                l_ibuf = l_ibuf == NB - 1 ? 0 : l_ibuf + 1;
-                if (++l_ck == nchunks) { l_ck = 0; l_img += img_step; }
-            }
             const int nbuf = l_cbuf == NB - 1 ? 0 : l_cbuf + 1;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 Grp nxt = cur;
                 if (g < 2) load_group(kind_tag, l_cbuf, g + 1, nxt);
                 else if constexpr (!last) {
-                    // every DMA piece this wave issued for the next chunk has landed (the pieces of the chunk behind it, issued during this one's
-                    // taps, may stay in flight), every fragment read of this chunk has returned
+                    // B(s + 1): every fragment read of this chunk has returned (its buffer is the producers' from here on); behind it the next
+                    // chunk is complete in LDS
                     MX_TL(10);
-                    wait_dma(iss);
                     // (the builtin, not an asm: the compiler's wait-count pass then KNOWS that this chunk's reads have returned; behind an opaque
                     // asm it believed them outstanding next to the 12 new ones - more than the 4-bit counter can express - and made the
                     // MFMA run below wait for the new reads)
@@ -727,19 +782,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_mx_kernel(const ConvM
                     MX_TL(11);
                     load_group(next_tag, nbuf, 0, pf);
                 }
-                if (iss) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) issue(i_img, i_ck, i_buf, 3 * g + i);
-                }
                 // this group's fragments have returned (the next group's 12 reads may stay in flight): ONE wait in front of the run, none inside
                 // it - an s_waitcnt between two MFMAs of the chain is an issue slot like any other
                 if (g < 2) __builtin_amdgcn_s_waitcnt(0xcc7f);        // lgkmcnt(12)
                 else if constexpr (last) __builtin_amdgcn_s_waitcnt(0xc07f);
                 // (the scheduler otherwise sinks the reads into the MFMA run)
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (NWAVE >= 8) {      // two waves per SIMD: alternate their priority group by group
-                    if ((g + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-                }
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (!slot_live(3 * g + i)) continue;
@@ -1259,7 +1307,7 @@ int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
         }
     }
     dim3 grid(combos, groups);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3((WM * WN + (NB == 3 ? 4 : 0)) * 64), smem, s, a);
     DISCO_LAUNCH_CHECK("conv3x3_mx_kernel");
     return DISCO_OK;
 }
@@ -1292,7 +1340,8 @@ int dispatch_mx_ar(const ConvMxArgs& a, hipStream_t s) {
     }
     if (a.stride == 1) {
         // Candidates in order of efficiency at full load; the first that fills 3/4 of the CUs is taken, else the one with most workgroups.
-        // The last three run the LATENCY loop (NB = 3; round 5): they are only reached when the launch cannot fill the GPU with the big tiles.
+        // The last one runs the LATENCY loop (NB = 3; round 5): it is only reached when the launch cannot fill the GPU with the bigger tiles
+        // (the latency loop on the 8-consumer-wave tiles was measured and lost to the throughput loop: profiles/r05_latency_loop_ab.txt).
         // Every candidate a layer can take accumulates in the same order (the tap order is tied to the tile WIDTH; a 16-wide tile is only
         // offered to images at most 16 wide), so an image's result does not depend on the batch it is part of.
         struct Cand { int tw, th, nt; };
@@ -1312,15 +1361,11 @@ int dispatch_mx_ar(const ConvMxArgs& a, hipStream_t s) {
             case 1: return launch_mx2<32, 16, 1, 1, 8, 1, AR>(a, s);
             case 2: return launch_mx2<32, 8, 2, 1, 4, 2, AR>(a, s);
             case 3: return launch_mx2<16, 16, 2, 1, 4, 2, AR>(a, s);
-            case 4:
-                if constexpr (AR != 1) { if (lat) return launch_mx2<32, 8, 1, 1, 8, 1, AR, 3>(a, s); }
-                return launch_mx2<32, 8, 1, 1, 8, 1, AR>(a, s);
+            case 4: return launch_mx2<32, 8, 1, 1, 8, 1, AR>(a, s);
             case 6:
                 if constexpr (AR != 1) return launch_mx2<32, 4, 1, 1, 4, 1, AR, 3>(a, s);
                 [[fallthrough]];
-            default:
-                if constexpr (AR != 1) { if (lat) return launch_mx2<16, 16, 1, 1, 8, 1, AR, 3>(a, s); }
-                return launch_mx2<16, 16, 1, 1, 8, 1, AR>(a, s);
+            default: return launch_mx2<16, 16, 1, 1, 8, 1, AR>(a, s);
         }
     }
     if (wide) return nt2 ? launch_mx2<32, 4, 2, 2, 4, 2, AR>(a, s) : launch_mx2<32, 4, 1, 2, 4, 1, AR>(a, s);

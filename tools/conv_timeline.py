@@ -87,7 +87,7 @@ def measure(L, diag, run, name, cin, co, ho, n, pipe_cycles):
         # unit is the constant-rate counter, NOT shader clocks; the tile total against the launch time above gives the conversion)
         cnt = int(buf[1, 0])
         ev = [(int(v) >> 4, int(v) & 15) for v in buf[1, 1:min(cnt, EVENTS)]]
-        names = {1: "tile", 2: "chunk", 3: "dma-landed", 4: "barrier(H)", 5: "barrier(Q)", 6: "taps-done", 7: "epi-math", 8: "epi-wait", 9: "stores", 10: "tap8", 11: "barrier-in-tap8", 12: "entry", 13: "prologue"}
+        names = {1: "tile", 2: "chunk", 3: "dma-landed", 4: "barrier(H)", 5: "barrier(Q)", 6: "taps-done", 7: "epi-math", 8: "epi-wait", 9: "stores", 10: "tap8", 11: "barrier-in-tap8", 12: "entry", 13: "prologue", 14: "p14", 15: "p15"}
         line = []
         for i in range(1, len(ev)):
             line.append("%s+%d" % (names.get(ev[i][1], str(ev[i][1])), ev[i][0] - ev[i - 1][0]))

@@ -69,5 +69,5 @@ for s, e, k in g:
     k = k.replace("disco::", "").replace("(anonymous namespace)::", "").replace("_GLOBAL__N_1", "")
     k = (k[:k.index(">(") + 1] if ">(" in k else k.split("(")[0])[-90:]
     a = acc.setdefault(k, [0, 0]); a[0] += 1; a[1] += e - s
-for k, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:25]:
+for k, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:45]:
     print("  %4d x %8.1f us  = %8.1f us   %s" % (c, t / c / 1e3, t / 1e3, k))
