@@ -214,7 +214,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     static_assert(!GENC1 || (AR == 2 && STRIDE == 1 && !NSRC2 && !MASKED), "the fused Cin = 1 producer exists for plain f16x3 layers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    if constexpr (NB == 3) {
+    {
         // Touch every 64-byte line of the kernel-argument segment NOW, in one burst of scalar loads: the compiler reads the arguments where it
         // needs them, in five or six dependent batches, and each batch is a cold miss of its own (the segment is written per launch: nothing of
         // it is cached) - ~3 000 cycles before the first DMA piece could leave (s_memtime stamps of a producer wave, profiles/r05_latency_loop.txt).

@@ -12,6 +12,7 @@
 //   select_colors_kernel  softmax(313) -> stable top-10 -> T-th distinct colour (anchor_gen.py:54-90) + label
 //   nearest_bin_kernel    argmax of encode_ab2ind = nearest gamut bin (basic.py:177-194, model.py:166)
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include <mutex>
 #include "common.h"
@@ -657,6 +658,168 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
     if (tid == 0 && info) { info[img * 2] = passes; info[img * 2 + 1] = s_events; }
 }
 
+// ---- k-means + anchors for up to 256 points of 64 features: the latency path (round 5) -----------------------------------------------
+// A 256 x 256 image has 16 x 16 tokens, and its k-means is a chain of ~5 Lloyd passes on ONE workgroup: what counts is the length of
+// a pass, not its work.  kmeans_anchor_kernel spends ~30 us per pass at this size (ten barriers of 1024 threads, a counting sort, member
+// sums as chains of dependent LDS reads); this kernel runs a pass behind two barriers:
+//   assign   4 threads per point (a quarter of the centres each), the point's 64 features in REGISTERS for the whole kernel, the centres
+//            as ds_read_b128 broadcasts; the quarters of a point are neighbouring lanes and merge by shuffles under the order
+//            (distance, centre index) = the first minimum over all centres
+//   update   one WAVE per cluster, lane = feature: the members as ballot masks of the assignments (wave-uniform), their rows read eight
+//            at a time and added in ascending point order; the centre's shift as a chain over v_readlane'd lanes - no member list, no
+//            sort, no cross-wave reduction; new centres go to the other of two centre buffers (no copy pass)
+//   stop     every thread sums the K shifts itself (same order), so the decision needs no third barrier
+// The arithmetic is kmeans_anchor_kernel's, expression by expression (fmaf distance chain over ascending features, first minimum, member
+// sums in ascending point order divided by the count, shift = sum_j sqrt(sum_c d^2) in ascending order), so assignments, pass counts and
+// empty-cluster events are bit-identical to it (tests/test_gpu_ops.py::test_kmeans_small_kernel_equals_the_general_one).
+constexpr int KS_PITCH = 65;       // point rows in LDS (floats): odd, conflict-free both by row and by column
+constexpr int KS_CP = 68;          // centre rows: 16-byte aligned, consecutive rows on different banks
+constexpr int KS_MAXL = 256;
+__global__ __launch_bounds__(1024) void kmeans_small_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
+                                                            const int32_t* __restrict__ init_idx, const int32_t* __restrict__ fallback,
+                                                            int max_fallback, int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
+                                                            int32_t* info, int L, int K) {
+    extern __shared__ float dyn[];          // [L][KS_PITCH] points
+    __shared__ __attribute__((aligned(16))) float cen[2][KMAX * KS_CP];
+    __shared__ int asg[KS_MAXL];
+    __shared__ float hm_l[KS_MAXL];
+    __shared__ int cnt[KMAX];
+    __shared__ float shift_part[KMAX];
+    __shared__ int s_anchor[KMAX];
+    __shared__ int s_events, s_any_empty;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* X = x + (size_t)img * L * 64;
+    float* xs = dyn;
+    for (int u = tid; u < L * 64; u += 1024) xs[(u >> 6) * KS_PITCH + (u & 63)] = X[u];
+    for (int u = tid; u < K * 64; u += 1024) cen[0][(u >> 6) * KS_CP + (u & 63)] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
+    if (tid == 0) { s_events = 0; s_any_empty = 0; }
+    __syncthreads();
+    const int t = tid >> 2, q = tid & 3;          // point, quarter of the centres
+    float row[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) row[c] = t < L ? xs[t * KS_PITCH + c] : 0.f;
+    const int KQ = (K + 3) >> 2;
+    int cur = 0, passes = 0;
+    while (true) {
+        // ---- assign ----
+        {
+            float best = INFINITY; int bi = 0x7fffffff;
+            for (int j = q * KQ; j < min(K, (q + 1) * KQ); ++j) {
+                const float4* cp = reinterpret_cast<const float4*>(cen[cur] + j * KS_CP);
+                float d = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < 16; ++c4) {
+                    const float4 cv = cp[c4];
+                    float df = row[4 * c4] - cv.x; d = fmaf(df, df, d);
+                    df = row[4 * c4 + 1] - cv.y; d = fmaf(df, df, d);
+                    df = row[4 * c4 + 2] - cv.z; d = fmaf(df, df, d);
+                    df = row[4 * c4 + 3] - cv.w; d = fmaf(df, df, d);
+                }
+                if (d < best) { best = d; bi = j; }
+            }
+#pragma unroll
+            for (int sft = 1; sft < 4; sft <<= 1) {
+                const float od = __shfl_xor(best, sft); const int oj = __shfl_xor(bi, sft);
+                if (od < best || (od == best && oj < bi)) { best = od; bi = oj; }
+            }
+            if (q == 0 && t < L) asg[t] = bi;
+        }
+        __syncthreads();
+        // ---- update: wave = cluster, lane = feature ----
+        const int nxt = cur ^ 1;
+        // the centre's shift contribution sqrt(sum_c (new - old)^2), the sum as the chain q += d d over ascending features
+        auto shift_of = [&](float dlane) -> float {
+            float qv = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) { const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dlane), c)); qv += dc * dc; }
+            return sqrtf(qv);
+        };
+        for (int j = wave; j < K; j += 16) {
+            unsigned long long mk[4]; int m = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int tt = b * 64 + lane;
+                const int av = tt < L ? asg[tt] : -1;
+                mk[b] = __ballot(av == j);
+                m += __popcll(mk[b]);
+            }
+            if (m > 0) {
+                float sum = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    unsigned long long mask = mk[b];
+                    while (mask) {                           // eight members' rows in flight, added in ascending point order
+                        float v[8]; bool ok[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            ok[u] = mask != 0ull;
+                            const int tt = b * 64 + (ok[u] ? __builtin_ctzll(mask) : 0);
+                            mask &= mask - 1ull;
+                            v[u] = xs[tt * KS_PITCH + lane];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (ok[u]) sum += v[u];
+                    }
+                }
+                sum = sum / (float)m;
+                cen[nxt][j * KS_CP + lane] = sum;
+                const float sh = shift_of(sum - cen[cur][j * KS_CP + lane]);
+                if (lane == 0) { shift_part[j] = sh; cnt[j] = m; }
+            } else if (lane == 0) { cnt[j] = 0; s_any_empty = 1; }
+        }
+        __syncthreads();
+        if (s_any_empty) {
+            // empty clusters take a fallback row, in cluster order (sequential bookkeeping by one thread); rare
+            if (tid == 0) {
+                for (int j = 0; j < K; ++j)
+                    if (cnt[j] == 0) {
+                        const int e = s_events++;
+                        const int r = (fallback && e < max_fallback) ? fallback[(size_t)img * max_fallback + e] : 0;
+                        cnt[j] = -(r + 1);
+                    }
+            }
+            __syncthreads();
+            for (int j = wave; j < K; j += 16)
+                if (cnt[j] < 0) {
+                    const float sum = X[(size_t)(-cnt[j] - 1) * 64 + lane];
+                    cen[nxt][j * KS_CP + lane] = sum;
+                    const float sh = shift_of(sum - cen[cur][j * KS_CP + lane]);
+                    if (lane == 0) shift_part[j] = sh;
+                }
+            __syncthreads();
+            if (tid == 0) s_any_empty = 0;
+        }
+        ++passes;
+        float sh = 0.f;
+        for (int j = 0; j < K; ++j) sh += shift_part[j];
+        cur = nxt;
+        if ((sh * sh < 1e-4f) || passes >= 20) break;
+    }
+    // anchors: per cluster the first argmax of [assign==j] + sizes*0.01 (exact fp32 ops, no fma); one wave per cluster
+    const float* sz = sizes + (size_t)img * L;
+    for (int j = wave; j < K; j += 16) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int tt = lane; tt < L; tt += 64) {
+            const float sc = add_rn(asg[tt] == j ? 1.f : 0.f, mul_rn(sz[tt], 0.01f));
+            if (sc > bv) { bv = sc; bi = tt; }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { anchor_out[img * K + j] = bi; s_anchor[j] = bi; }
+    }
+    for (int tt = tid; tt < L; tt += 1024) { assign_out[(size_t)img * L + tt] = asg[tt]; hm_l[tt] = 0.f; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int j = 0; j < K; ++j) hm_l[s_anchor[j]] += 1.f;       // sequential: two clusters may share an anchor
+        if (info) { info[img * 2] = passes; info[img * 2 + 1] = s_events; }
+    }
+    __syncthreads();
+    for (int tt = tid; tt < L; tt += 1024) hint_mask[(size_t)img * L + tt] = hm_l[tt];
+}
+
 // ---- k-means + anchors, fallback for more than KM_LIST_TOKENS points: one workgroup (256 threads) per image --------
 // The token matrix (L x 64 fp32) is staged once in LDS (row pitch 65 floats: conflict-free row-per-thread reads)
 // when it fits (L <= KM_LDS_TOKENS); larger images (no_resize path) read it from L2 with unconditional,
@@ -1044,6 +1207,15 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
     const size_t tile = (size_t)256 * (d + 1) * sizeof(float);
     const size_t glist_smem = tile + (size_t)nseg * k * sizeof(int) + best;
     int rc = DISCO_OK;
+    // DISCO_KMEANS_V1=1: the general kernel at every size (A/B runs; results are bit-identical)
+    static const bool small_ok = [] { const char* e = std::getenv("DISCO_KMEANS_V1"); return !(e && e[0] == '1'); }();
+    if (small_ok && l <= KS_MAXL && d == 64 && !channel_major) {
+        const size_t smem = (size_t)l * KS_PITCH * sizeof(float);
+        static std::atomic<int> small_done[DISCO_MAX_DEVICES];
+        DISCO_HIP_CHECK(set_dyn_lds_once(small_done, reinterpret_cast<const void*>(kmeans_small_kernel), MAX_SMEM));
+        hipLaunchKernelGGL(kmeans_small_kernel, dim3(n), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
+                           hint_mask, info, l, k);
+    } else
     if (l <= KM_LDS_TOKENS) rc = launch(kmeans_anchor_kernel<true, false>, 0, (size_t)l * (d + 1) * sizeof(float) + lists + best);
     else if (l <= KM_LIST_TOKENS) rc = launch(kmeans_anchor_kernel<false, false>, 1, tile + lists + best);
     else if (glist_smem <= (size_t)MAX_SMEM) rc = launch(kmeans_anchor_kernel<false, true>, 2, glist_smem);

@@ -281,7 +281,7 @@ def test_kmeans_anchors_golden_and_oracle(H, comp):
     assert np.array_equal(assign[:3].numpy(), comp["km_ids"][:3].astype(np.int64))
 
 
-@pytest.mark.parametrize("l,k,d", [(64, 2, 64), (256, 16, 64), (384, 8, 64), (400, 8, 64), (1000, 5, 64), (1536, 16, 64),
+@pytest.mark.parametrize("l,k,d", [(64, 2, 64), (256, 16, 64), (256, 8, 64), (200, 32, 64), (130, 5, 64), (255, 3, 64), (384, 8, 64), (400, 8, 64), (1000, 5, 64), (1536, 16, 64),
                                    (4096, 32, 64), (4608, 8, 64), (8192, 16, 64), (32768, 32, 64), (96, 8, 2), (1536, 16, 2)])
 def test_kmeans_every_path_matches_oracle(H, l, k, d):
     """All four kernel paths - points in LDS (L <= 384), tiled 1024-thread path with the member list in LDS (L <= 4096) or in
@@ -308,6 +308,58 @@ def test_kmeans_every_path_matches_oracle(H, l, k, d):
     assert torch.equal(assign, want_assign)
     assert torch.equal(anchor, want_anchor) and torch.equal(mask, want_mask)
     assert info[:, 1].tolist() == events and (k < 4 or events[2] > 0)
+
+
+_KM_AB = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gpu_helpers as H
+from test_gpu_ops import _kmeans_gpu, _km_ab_inputs
+out = {}
+for case, (x, sizes, init, fallback, k) in enumerate(_km_ab_inputs()):
+    a, an, m, info = _kmeans_gpu(H, x, sizes, init, fallback, k)
+    out.update({"a%%d" %% case: a.numpy(), "an%%d" %% case: an.numpy(), "m%%d" %% case: m.numpy(), "i%%d" %% case: info.numpy()})
+np.savez(sys.argv[1], **out)
+"""
+
+
+def _km_ab_inputs():
+    """Token sets for the two k-means kernels side by side: clustered points, points on a coarse grid (exact ties between centres), half of
+    the points identical (empty clusters -> fallback rows), ragged sizes, K from 2 to 32."""
+    cases = []
+    for seed, (n, l, k) in enumerate([(16, 256, 8), (6, 256, 16), (4, 256, 32), (5, 200, 8), (5, 97, 5), (3, 64, 2), (3, 256, 8)]):
+        gen = g(900 + seed)
+        centres = torch.randn(n, k, 64, generator=gen) * 2.0
+        which = torch.randint(0, k, (n, l), generator=gen)
+        x = torch.gather(centres, 1, which[..., None].expand(-1, -1, 64)) + torch.randn(n, l, 64, generator=gen) * 0.7
+        if seed == 6:
+            x = torch.round(x)                               # a coarse grid: distance ties, repeated rows
+        x[n - 1, : l // 2] = x[n - 1, 0]
+        init = np.stack([np.random.RandomState(50 * seed + i).choice(l, k, replace=False) for i in range(n)]).astype(np.int32)
+        init[n - 1, : max(1, k // 2)] = np.arange(max(1, k // 2))
+        sizes = torch.randint(0, 512, (n, l), generator=gen).float() / 256.0
+        fallback = torch.randint(0, l, (n, 20 * k), generator=gen).numpy()
+        cases.append((x, sizes, init, fallback, k))
+    return cases
+
+
+def test_kmeans_small_kernel_equals_the_general_one(H, tmp_path):
+    """kmeans_small_kernel (<= 256 points of 64 features: the 256 x 256 image's latency path) against kmeans_anchor_kernel, which a
+    subprocess runs on the same inputs under DISCO_KMEANS_V1=1: assignments, anchors, hint masks, pass counts and empty-cluster events
+    identical, element by element."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "v1.npz")
+    env = dict(os.environ, DISCO_KMEANS_V1="1")
+    subprocess.run([sys.executable, "-c", _KM_AB % (os.path.dirname(here), here), out], check=True, env=env, cwd=os.path.dirname(here))
+    ref = np.load(out)
+    some_events = 0
+    for case, (x, sizes, init, fallback, k) in enumerate(_km_ab_inputs()):
+        a, an, m, info = _kmeans_gpu(H, x, sizes, init, fallback, k)
+        assert np.array_equal(a.numpy(), ref["a%d" % case]) and np.array_equal(an.numpy(), ref["an%d" % case])
+        assert np.array_equal(m.numpy(), ref["m%d" % case]) and np.array_equal(info.numpy(), ref["i%d" % case])
+        some_events += int(info[:, 1].sum())
+    assert some_events > 0
 
 
 @pytest.mark.parametrize("t", [0, 1, 2])
