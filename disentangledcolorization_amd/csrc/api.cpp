@@ -201,6 +201,7 @@ struct disco_ctx {
     // one-shot progress event, profiling vectors, calibration tables are plain members).
     std::mutex mu;
     float* d_enc[2] = {nullptr, nullptr};
+    float* d_enc_pk[2] = {nullptr, nullptr};     // their B-fragment images for encoder_tail_kernel (launch_encoder_pack)
     float* d_mid_w = nullptr; float* d_emb_w = nullptr; float* d_trg_w = nullptr; float* d_q_to_ab = nullptr;
     std::map<std::pair<int, int>, float*> pos_cache;
     // pinned staging ring for the small host->device index arrays of disco_forward: a pageable hipMemcpyAsync
@@ -1074,7 +1075,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
             }
         }
     };
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s, P.dbg_row >= 0 ? &enc_dbg : nullptr);
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s, P.dbg_row >= 0 ? &enc_dbg : nullptr, c->d_enc_pk[0]);
     P.dbg(enc, (size_t)n * L * 64 * 4);
     if (!dry && P.ok()) P.rc = launch_logits(enc, c->d_mid_w, a->d_pal_logit, n, L, s);
     P.dbg(a->d_pal_logit, (size_t)n * N_VOCAB * L * 4);
@@ -1123,7 +1124,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     float* hint = (float*)P.raw((size_t)n2 * L * 64 * 4);
     float* dec = (float*)P.raw((size_t)n2 * L * 64 * 4);
     if (!dry && P.ok()) P.rc = launch_hint_embed(src, rep, h2r ? nullptr : labels, h2r ? a->d_spix_colors : nullptr, a->d_hint_mask, rep, c->d_emb_w, hint, n2, L, s);
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(hint, pos, pos_rep ? rep : 0, c->d_enc[1], dec, n2, L, enc_ws, s);
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(hint, pos, pos_rep ? rep : 0, c->d_enc[1], dec, n2, L, enc_ws, s, nullptr, c->d_enc_pk[1]);
     if (!dry && P.ok()) P.rc = launch_logits(dec, c->d_trg_w, a->d_ref_logit, n2, L, s, h2r ? 2 : N_VOCAB);
     P.drop(enc_ws); P.drop(hint); P.drop(labels); P.drop(d_idx); P.drop(d_fb); P.drop(d_assign); P.drop(d_anchor);
     P.drop(enc); P.drop(src); P.drop(spix_ab); P.drop(sizes); if (pos_img) P.drop(pos_img);
@@ -1542,6 +1543,11 @@ int disco_finalize(disco_ctx* c) {
     if (sub == SUBNET_ENH) { c->finalized = true; return DISCO_OK; }
     if ((rc = make_encoder(c, "wildpath", &c->d_enc[0]))) return rc;
     if ((rc = make_encoder(c, "hintpath", &c->d_enc[1]))) return rc;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = dev_alloc(c, encoder_packed_floats() * sizeof(float), (void**)&c->d_enc_pk[i]))) return rc;
+        if ((rc = launch_encoder_pack(c->d_enc[i], c->d_enc_pk[i], nullptr))) return rc;
+    }
+    DISCO_HIP_CHECK(hipStreamSynchronize(nullptr));
     if ((rc = upload_vec(c, T(c, "mid_word_prj.weight").data, &c->d_mid_w))) return rc;
     if ((rc = upload_vec(c, T(c, "trg_word_emb.weight").data, &c->d_emb_w))) return rc;
     if ((rc = upload_vec(c, T(c, "trg_word_prj.weight").data, &c->d_trg_w))) return rc;
@@ -1992,6 +1998,14 @@ int disco_op_encoder_stack(const float* d_x, const float* d_pos, const float* d_
     if (!positive("encoder_stack", {n, l})) return DISCO_ESHAPE;
     if (!d_x || !d_pos || !d_weights || !d_out || !d_ws) { set_error("null argument"); return DISCO_EINVAL; }
     if (ws_bytes < encoder_ws_bytes(n, l)) { set_error("encoder workspace too small (%zu < %zu)", ws_bytes, encoder_ws_bytes(n, l)); return DISCO_ENOMEM; }
+    // a workspace with room for the weights' B-fragment image behind the stack's own buffers takes the 16-row tail kernel (what the
+    // forward does for small token counts); a smaller one the 64-row tiles.  Same results (the tests run both and compare).
+    const size_t base = (encoder_ws_bytes(n, l) + 255) & ~(size_t)255, pk = encoder_packed_floats() * sizeof(float);
+    if (ws_bytes >= base + pk) {
+        float* d_pk = reinterpret_cast<float*>(static_cast<char*>(d_ws) + base);
+        if (int rc = launch_encoder_pack(d_weights, d_pk, (hipStream_t)stream)) return rc;
+        return launch_encoder_stack(d_x, d_pos, 0, d_weights, d_out, n, l, d_ws, (hipStream_t)stream, nullptr, d_pk);
+    }
     return launch_encoder_stack(d_x, d_pos, 0, d_weights, d_out, n, l, d_ws, (hipStream_t)stream);
 }
 

@@ -371,8 +371,11 @@ constexpr int ENC_LAYERS = 6;
 constexpr size_t ENC_LAYER_FLOATS = 192 * 64 + 192 + 64 * 64 + 64 + 256 * 64 + 256 + 64 * 256 + 64 + 4 * 64;
 size_t encoder_ws_bytes(int n, int l);
 // pos: (l,64) shared by all images (pos_rep = 0) or (n/pos_rep, l, 64), virtual image i using image i/pos_rep
+// packed: the weights' B-fragment image for the 16-row tail kernel (launch_encoder_pack of the same `weights`), or null: 64-row tiles at every size
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
-                         void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg = nullptr);
+                         void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg = nullptr, const float* packed = nullptr);
+size_t encoder_packed_floats();
+int launch_encoder_pack(const float* raw, float* packed, hipStream_t s);
 void position_encoding_host(float* h_pos /*(h*w,64)*/, int h, int w);
 // logits: (n,L,64) x (n_out,64)^T -> NCHW (n,n_out,L)
 int launch_logits(const float* x, const float* w, float* out_nchw, int n, int l, hipStream_t s, int n_out = N_VOCAB);

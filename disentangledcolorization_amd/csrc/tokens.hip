@@ -163,6 +163,25 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
 //     the other LDS buffer afterwards (before: load, barrier, compute, barrier - nine exposed global-load latencies);
 //   * operand tiles live in LDS as [k parity][row][k >> 1]: lane (row, k parity) of v_mfma_f32_32x32x2 reads its 32
 //     k-values of a step with eight ds_read_b128 up front instead of one ds_read_b32 in front of every MFMA.
+// LayerNorm over the 64 columns of a token row held by four neighbouring lanes (16 consecutive columns each): biased variance, eps 1e-5.
+// EVERY operation is spelled out (mul_rn / add_rn / sub_rn never contract, fmaf always does): left to -ffp-contract=fast and the SLP
+// vectoriser, the sum of squares came out as an irregular mix of fused and unfused steps that depended on the kernel around it - the two
+// kernels that run a layer's second half (64-row and 16-row tiles) differed in a few rows per thousand by one ulp of the variance.
+__device__ __forceinline__ void layer_norm16(float* v, const float* __restrict__ w, const float* __restrict__ b, int cq) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum = add_rn(sum, v[j]);
+    sum = add_rn(sum, __shfl_xor(sum, 1)); sum = add_rn(sum, __shfl_xor(sum, 2));
+    const float mean = mul_rn(sum, 1.f / 64.f);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float d = sub_rn(v[j], mean); q = __builtin_fmaf(d, d, q); }
+    q = add_rn(q, __shfl_xor(q, 1)); q = add_rn(q, __shfl_xor(q, 2));
+    const float rstd = 1.f / sqrtf(__builtin_fmaf(q, 1.f / 64.f, 1e-5f));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = __builtin_fmaf(mul_rn(sub_rn(v[j], mean), rstd), w[cq + j], b[cq + j]);
+}
+
 constexpr int RS = 36;              // operand row: 32 k-values of one parity + 4 pad floats (16-byte aligned rows, conflict-free b128)
 constexpr int OT = 2 * 64 * RS;     // floats of one 64 x 64 operand tile
 struct PostAttnArgs {
@@ -231,20 +250,7 @@ __global__ __launch_bounds__(256) void post_attention_kernel(const PostAttnArgs 
             sA[rr * GP + wn * 32 + (lane & 31)] = acc[e];
         }
     };
-    auto layer_norm = [&](float* v, const float* w, const float* b) {      // biased variance, eps 1e-5, over the 64 columns
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sum += v[j];
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
-        const float mean = sum * (1.f / 64.f);
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const float d = v[j] - mean; q += d * d; }
-        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
-        const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + 1e-5f);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = (v[j] - mean) * rstd * w[cq + j] + b[cq + j];
-    };
+    auto layer_norm = [&](float* v, const float* w, const float* b) { layer_norm16(v, w, b, cq); };
     f32x16 acc;
 
     // ---- x1 = LN1(x + att Wo^T + bo) ----
@@ -318,6 +324,228 @@ __global__ __launch_bounds__(256) void post_attention_kernel(const PostAttnArgs 
             float* o = g.out + (size_t)row * 64 + cq;
 #pragma unroll
             for (int j = 0; j < 16; ++j) o[j] = v[j];
+        }
+    }
+}
+
+// ---- the encoder layer's tail on 16-row tiles (round 5: the latency path of small token counts) ----------------------------------------
+//   x1 = LN1(x + att Wo^T + bo);  out = LN2(x1 + relu(x1 W1^T + b1) W2^T + b2);  and, fused behind it, the NEXT layer's packed
+//   in-projection: q = ((out + pos) Wq^T + bq) q_scale, k = (out + pos) Wk^T + bk, v = out Wv^T + bv
+// One image of a 256 x 256 input has 256 tokens: post_attention_kernel then runs 4 workgroups, each a serial chain of nine 64 x 64 x 64
+// steps of 32 dependent v_mfma_f32_32x32x2_f32 (64 cycles each): 18 400 cycles of matrix pipe in a 20 us launch, followed by a 7 us
+// launch of its own for the next layer's q, k, v.  Here a workgroup owns 16 token rows and runs on v_mfma_f32_16x16x4_f32 - the same
+// arithmetic (both shapes are an fmaf chain over ascending k, bit for bit: tools/mfma_f32_shapes_probe.hip), 16 instructions of 40
+// cycles of dependent latency per 64 k instead of 32 of 64 - so the chain is 640 (Wo) + 2 048 (W1: four independent blocks per wave) +
+// 2 560 (W2, K = 256) + 1 536 (in-projection) cycles, on 16 workgroups.  Weights come as pre-packed B fragments (encoder_pack_kernel:
+// one coalesced 16-byte load per lane and four k-steps) straight from L2 into registers: no weight tile in LDS, no barrier for it.
+// Every output element sees the same operations in the same order as in token_gemm_kernel<QKV> + post_attention_kernel (k ascending,
+// bias, residual, the LayerNorm's 16-column partial sums and xor-1 / xor-2 merges), so the two paths are bit-identical
+// (tests/test_gpu_ops.py::test_encoder_tail_path_equals_the_tiled_one) and may be mixed freely over batch sizes.
+constexpr int TL_ROWS = 16;
+constexpr int TL_RSA = 64 / 4 + 4;       // A-operand row (floats) of a K = 64 tile: [k & 3][row][k >> 2] + pad, 16-byte aligned
+constexpr int TL_RSH = 256 / 4 + 4;      // ... of the K = 256 hidden tile
+constexpr int TL_GP = 65;
+constexpr size_t PK_WO = 0, PK_W1 = 64 * 64, PK_W2 = PK_W1 + 256 * 64, PK_WIN = PK_W2 + 64 * 256;
+constexpr size_t ENC_PACKED_LAYER_FLOATS = PK_WIN + 192 * 64;
+// packed[((nb (K/16) + g) 64 + lane) 4 + i] = W[16 nb + (lane & 15)][16 g + 4 i + (lane >> 4)]   for W (O, K) row-major
+__global__ void encoder_pack_kernel(const float* __restrict__ raw, float* __restrict__ packed) {
+    const int layer = blockIdx.y;
+    const float* w = raw + (size_t)layer * ENC_LAYER_FLOATS;
+    float* o = packed + (size_t)layer * ENC_PACKED_LAYER_FLOATS;
+    const float* in_w = w;  const float* out_w = in_w + 192 * 64 + 192;  const float* l1_w = out_w + 64 * 64 + 64;  const float* l2_w = l1_w + 256 * 64 + 256;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < ENC_PACKED_LAYER_FLOATS; u += (size_t)gridDim.x * blockDim.x) {
+        const float* src; int K; size_t v;
+        if (u < PK_W1) { src = out_w; K = 64; v = u; }
+        else if (u < PK_W2) { src = l1_w; K = 64; v = u - PK_W1; }
+        else if (u < PK_WIN) { src = l2_w; K = 256; v = u - PK_W2; }
+        else { src = in_w; K = 64; v = u - PK_WIN; }
+        const int i = (int)(v & 3), lane = (int)((v >> 2) & 63);
+        const size_t blk = v >> 8;                                  // nb (K/16) + g
+        const int g = (int)(blk % (K / 16)), nb = (int)(blk / (K / 16));
+        o[u] = src[(size_t)(16 * nb + (lane & 15)) * K + 16 * g + 4 * i + (lane >> 4)];
+    }
+}
+
+struct TailArgs {
+    const float* att;    // (T,64) attention output
+    const float* x;      // (T,64) layer input (residual)
+    const float* pk;     // this layer's packed Wo | W1 | W2 (| its own in-projection, unused here)
+    const float *bo, *b1, *b2, *n1w, *n1b, *n2w, *n2b;
+    float* out;          // (T,64)
+    // the next layer's in-projection (null: the stack's last layer)
+    const float* pk_in;  // packed (192,64)
+    const float* b_in;   // (192)
+    const float* pos; int pos_rep;
+    float* qkv;          // q | k | v, each (T,64)
+    float q_scale;
+    int T, L;
+};
+
+__device__ __forceinline__ int a_idx(int row, int k, int rs) { return ((k & 3) * TL_ROWS + row) * rs + (k >> 2); }
+
+__global__ __launch_bounds__(256) void encoder_tail_kernel(const TailArgs g) {
+    __shared__ __attribute__((aligned(16))) float sAtt[4 * TL_ROWS * TL_RSA];      // attention tile; later (out + pos)
+    __shared__ __attribute__((aligned(16))) float sX[4 * TL_ROWS * TL_RSA];        // x1; operand layout
+    __shared__ __attribute__((aligned(16))) float sV[4 * TL_ROWS * TL_RSA];        // out (the v projection's operand)
+    __shared__ __attribute__((aligned(16))) float sH[4 * TL_ROWS * TL_RSH];        // relu(x1 W1^T + b1)
+    __shared__ float sC[TL_ROWS * TL_GP];                                          // C staging, row-major
+    __shared__ float sX1[TL_ROWS * TL_GP];                                         // x1, row-major (LN2's residual)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int am = lane & 15, akq = lane >> 4;                 // this lane's row / k residue of an A fragment (and column / k residue of a B fragment)
+    const int row0 = blockIdx.x * TL_ROWS;
+    const int rows_valid = min(TL_ROWS, g.T - row0);
+    const float4* pk4 = reinterpret_cast<const float4*>(g.pk);
+    auto bfrag = [&](size_t mat_off, int kgroups, int nb, int grp) -> float4 { return pk4[(mat_off >> 2) + ((size_t)(nb * kgroups + grp) * 64 + lane)]; };
+    auto mma4 = [&](f32x4& acc, const float4& a, const float4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    };
+    auto layer_norm = [&](float* v, const float* w, const float* b, int cq) { layer_norm16(v, w, b, cq); };
+    // ---- the attention tile (rows beyond T zero) and Wo's fragments ----
+    float4 bwo[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) bwo[gi] = bfrag(PK_WO, 4, wave, gi);
+    {
+        const int rr = tid >> 4, c4 = (tid & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < rows_valid) v = *reinterpret_cast<const float4*>(g.att + (size_t)(row0 + rr) * 64 + c4);
+        sAtt[a_idx(rr, c4, TL_RSA)] = v.x; sAtt[a_idx(rr, c4 + 1, TL_RSA)] = v.y; sAtt[a_idx(rr, c4 + 2, TL_RSA)] = v.z; sAtt[a_idx(rr, c4 + 3, TL_RSA)] = v.w;
+    }
+    // W1's fragments: this wave's four hidden blocks 4 wave .. 4 wave + 3 (in flight across the first step and LN1)
+    float4 bw1[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) bw1[b][gi] = bfrag(PK_W1, 4, 4 * wave + b, gi);
+    __syncthreads();
+    // ---- x1 = LN1(x + att Wo^T + bo): this wave's 16 output columns ----
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float4* pa = reinterpret_cast<const float4*>(sAtt + (akq * TL_ROWS + am) * TL_RSA);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) mma4(acc, pa[gi], bwo[gi]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sC[(4 * akq + e) * TL_GP + wave * 16 + am] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int r = tid >> 2, cq = (tid & 3) * 16, row = row0 + r;
+        const bool rok = row < g.T;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = sC[r * TL_GP + cq + j] + g.bo[cq + j];
+        if (rok) {
+            const float* rp = g.x + (size_t)row * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] += rp[j];
+        }
+        layer_norm(v, g.n1w, g.n1b, cq);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const float o = rok ? v[j] : 0.f; sX[a_idx(r, cq + j, TL_RSA)] = o; sX1[r * TL_GP + cq + j] = o; }
+    }
+    // W2's fragments (K = 256: 16 groups) for this wave's 16 output columns
+    float4 bw2[16];
+#pragma unroll
+    for (int gi = 0; gi < 16; ++gi) bw2[gi] = bfrag(PK_W2, 16, wave, gi);
+    __syncthreads();
+    // ---- h = relu(x1 W1^T + b1): four independent 16-column blocks per wave ----
+    {
+        f32x4 acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4* pa = reinterpret_cast<const float4*>(sX + (akq * TL_ROWS + am) * TL_RSA);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const float4 a = pa[gi];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mma4(acc[b], a, bw1[b][gi]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = (4 * wave + b) * 16 + am;
+            const float bias = g.b1[col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sH[a_idx(4 * akq + e, col, TL_RSH)] = fmaxf(acc[b][e] + bias, 0.f);
+        }
+    }
+    // the next layer's in-projection fragments: blocks 3 wave .. 3 wave + 2 of its 12
+    float4 bin[3][4];
+    if (g.pk_in) {
+        const float4* pi4 = reinterpret_cast<const float4*>(g.pk_in);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) bin[b][gi] = pi4[(size_t)((3 * wave + b) * 4 + gi) * 64 + lane];
+    }
+    __syncthreads();
+    // ---- out = LN2(x1 + h W2^T + b2) ----
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float4* pa = reinterpret_cast<const float4*>(sH + (akq * TL_ROWS + am) * TL_RSH);
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi) mma4(acc, pa[gi], bw2[gi]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sC[(4 * akq + e) * TL_GP + wave * 16 + am] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int r = tid >> 2, cq = (tid & 3) * 16, row = row0 + r;
+        const bool rok = row < g.T;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = sC[r * TL_GP + cq + j] + g.b2[cq + j] + sX1[r * TL_GP + cq + j];
+        layer_norm(v, g.n2w, g.n2b, cq);
+        if (rok) {
+            float* o = g.out + (size_t)row * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = v[j];
+        }
+        if (g.pk_in) {
+            // the operands of the next layer's in-projection: out + pos for q and k (token_gemm_kernel<QKV>'s staging: v += p), out for v
+            const int img = rok ? row / g.L : 0, t = rok ? row - img * g.L : 0;
+            const size_t pimg = g.pos_rep > 0 ? (size_t)(img / g.pos_rep) * g.L : 0;
+            const float* pp = g.pos + (pimg + t) * 64 + cq;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float o = rok ? v[j] : 0.f;
+                float qk = o;
+                if (rok) qk += pp[j];
+                sV[a_idx(r, cq + j, TL_RSA)] = o;
+                sAtt[a_idx(r, cq + j, TL_RSA)] = qk;
+            }
+        }
+    }
+    if (!g.pk_in) return;
+    __syncthreads();
+    // ---- the next layer's q, k, v: 12 blocks of 16 columns, three per wave ----
+    {
+        f32x4 acc[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4* pq = reinterpret_cast<const float4*>(sAtt + (akq * TL_ROWS + am) * TL_RSA);
+        const float4* pv = reinterpret_cast<const float4*>(sV + (akq * TL_ROWS + am) * TL_RSA);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const float4 aq = pq[gi], av = pv[gi];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int nb = 3 * wave + b;                  // (wave-uniform) 0-3: q, 4-7: k, 8-11: v
+                mma4(acc[b], nb < 8 ? aq : av, bin[b][gi]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int nb = 3 * wave + b, mat = nb >> 2, col = (nb & 3) * 16 + am;
+            const float bias = g.b_in[nb * 16 + am];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = row0 + 4 * akq + e;
+                float val = acc[b][e] + bias;
+                if (mat == 0) val = val * g.q_scale;
+                if (row < g.T) g.qkv[(size_t)mat * g.T * 64 + (size_t)row * 64 + col] = val;
+            }
         }
     }
 }
@@ -606,7 +834,7 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
         // centre shift = sum_j sqrt(sum_c (new-old)^2)
         if (tid < K) {
             float q = 0.f;
-            for (int c = 0; c < D; ++c) { const float d = cnew[tid * 64 + c] - cen[tid * 64 + c]; q += d * d; }
+            for (int c = 0; c < D; ++c) { const float d = cnew[tid * 64 + c] - cen[tid * 64 + c]; q = __builtin_fmaf(d, d, q); }
             shift_part[tid] = sqrtf(q);
         }
         __syncthreads();
@@ -731,7 +959,7 @@ __global__ __launch_bounds__(1024) void kmeans_small_kernel(const float* __restr
         auto shift_of = [&](float dlane) -> float {
             float qv = 0.f;
 #pragma unroll
-            for (int c = 0; c < 64; ++c) { const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dlane), c)); qv += dc * dc; }
+            for (int c = 0; c < 64; ++c) { const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dlane), c)); qv = __builtin_fmaf(dc, dc, qv); }
             return sqrtf(qv);
         };
         for (int j = wave; j < K; j += 16) {
@@ -902,7 +1130,7 @@ __global__ __launch_bounds__(256) void kmeans_anchor_scan_kernel(const float* __
         // centre shift = sum_j sqrt(sum_c (new-old)^2)
         if (tid < K) {
             float q = 0.f;
-            for (int c = 0; c < D; ++c) { const float d = cnew[tid * 64 + c] - cen[tid * 64 + c]; q += d * d; }
+            for (int c = 0; c < D; ++c) { const float d = cnew[tid * 64 + c] - cen[tid * 64 + c]; q = __builtin_fmaf(d, d, q); }
             shift_part[tid] = sqrtf(q);
         }
         __syncthreads();
@@ -1090,14 +1318,31 @@ int launch_decode_annealed(const float* logit_nchw, const float* q_to_ab, float*
 // workspace of one encoder stack: q,k,v (3 T 64), attention output (T 64), two ping-pong layer outputs (2 T 64)
 size_t encoder_ws_bytes(int n, int l) { return (size_t)n * l * (3 * 64 + 3 * 64) * sizeof(float); }
 
+size_t encoder_packed_floats() { return (size_t)ENC_LAYERS * ENC_PACKED_LAYER_FLOATS; }
+
+int launch_encoder_pack(const float* raw, float* packed, hipStream_t s) {
+    hipLaunchKernelGGL(encoder_pack_kernel, dim3(48, ENC_LAYERS), dim3(256), 0, s, raw, packed);
+    DISCO_LAUNCH_CHECK("encoder_pack_kernel");
+    return DISCO_OK;
+}
+
+// up to this many token rows the stack runs its layers' tails on 16-row tiles (encoder_tail_kernel); beyond, on 64-row tiles
+// (post_attention_kernel + token_gemm_kernel<QKV>).  Same results either way; DISCO_ENCODER_TAIL_ROWS overrides (0: never)
+static int encoder_tail_max_rows() {
+    static const int v = [] { const char* e = std::getenv("DISCO_ENCODER_TAIL_ROWS"); return e ? atoi(e) : 4096; }();
+    return v;
+}
+
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
-                         void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg) {
+                         void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg, const float* packed) {
     const int T = n * l;
+    const bool tail = packed != nullptr && T <= encoder_tail_max_rows();
     float* qkv = reinterpret_cast<float*>(ws);
     float* att = qkv + (size_t)3 * T * 64;
     float* pp[2] = {att + (size_t)T * 64, att + (size_t)2 * T * 64};
     const float* cur = x;
-    for (int layer = 0; layer < ENC_LAYERS; ++layer) {
+    static const int dbg_layers = [] { const char* e = std::getenv("DISCO_ENC_DEBUG_LAYERS"); return e ? atoi(e) : ENC_LAYERS; }();
+    for (int layer = 0; layer < dbg_layers; ++layer) {
         const float* w = weights + (size_t)layer * ENC_LAYER_FLOATS;
         const float* in_w = w;                 const float* in_b = in_w + 192 * 64;
         const float* out_w = in_b + 192;       const float* out_b = out_w + 64 * 64;
@@ -1110,16 +1355,27 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         // q,k,v
         g.A = cur; g.pos = pos; g.pos_rep = pos_rep; g.W = in_w; g.ldw = 64; g.bias = in_b; g.K = 64; g.O = 192; g.out = qkv;
         g.q_scale = (float)std::sqrt(1.0 / 8.0);
-        int rc = launch_gemm<EPI_QKV>(g, s);
-        if (rc) return rc;
+        static const bool dbg_noqkv = std::getenv("DISCO_TAIL_NOQKV") != nullptr;      // bisecting aid: the tail kernel without its fused in-projection
+        if (!tail || layer == 0 || dbg_noqkv) {           // (the tail path: layers 1.. get their q, k, v from the previous layer's tail kernel)
+            int rc = launch_gemm<EPI_QKV>(g, s);
+            if (rc) return rc;
+        }
         if (dbg) (*dbg)(qkv, (size_t)3 * T * 64 * 4);
         hipLaunchKernelGGL(attention_kernel, dim3(cdiv(l, QPB), N_HEAD, n), dim3(256), 0, s, qkv, qkv + (size_t)T * 64,
                            qkv + (size_t)2 * T * 64, att, l);
         DISCO_LAUNCH_CHECK("attention_kernel");
         if (dbg) (*dbg)(att, (size_t)T * 64 * 4);
         // x1 = LN1(x + att Wo^T + bo); out = LN2(x1 + relu(x1 W1^T + b1) W2^T + b2): one fused launch
-        float* dst = layer == ENC_LAYERS - 1 ? out : pp[layer & 1];
-        {
+        float* dst = layer == dbg_layers - 1 ? out : pp[layer & 1];
+        if (tail) {
+            const bool more = layer + 1 < ENC_LAYERS && !dbg_noqkv;
+            const float* wn = weights + (size_t)(layer + 1) * ENC_LAYER_FLOATS;      // the next layer's in_proj_weight | in_proj_bias
+            TailArgs ta{att, cur, packed + (size_t)layer * ENC_PACKED_LAYER_FLOATS, out_b, l1_b, l2_b, n1_w, n1_b, n2_w, n2_b, dst,
+                        more ? packed + (size_t)(layer + 1) * ENC_PACKED_LAYER_FLOATS + PK_WIN : nullptr, more ? wn + 192 * 64 : nullptr,
+                        pos, pos_rep, qkv, g.q_scale, T, l};
+            hipLaunchKernelGGL(encoder_tail_kernel, dim3(cdiv(T, TL_ROWS)), dim3(256), 0, s, ta);
+            DISCO_LAUNCH_CHECK("encoder_tail_kernel");
+        } else {
             PostAttnArgs pa{att, cur, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, dst, T};
             constexpr size_t smem = POST_ATTN_SMEM;
             static std::atomic<int> attr_done[DISCO_MAX_DEVICES];      // per device; two host threads may get here together

@@ -247,6 +247,30 @@ def test_encoder_stack_matches_oracle(H, synth_sd, n, hw):
     assert H.max_err(out, want) < 2e-5
 
 
+@pytest.mark.parametrize("n,hw", [(1, (16, 16)), (3, (16, 16)), (2, (9, 11)), (1, (32, 48)), (5, (7, 3))])
+def test_encoder_tail_path_equals_the_tiled_one(H, synth_sd, n, hw):
+    """The two ways the stack runs a layer's second half: 64-row tiles (post_attention_kernel + a q/k/v launch per layer) and 16-row tiles on
+    v_mfma_f32_16x16x4_f32 with the next layer's in-projection fused in (encoder_tail_kernel: the latency path of small token counts).
+    The op takes the second when its workspace has room for the packed weight image.  Bit-identical, ragged last tiles included."""
+    h, w = hw
+    l = h * w
+    x = torch.randn(n, l, 64, generator=g(7 * l + n))
+    pos = R.position_encoding(h, w).flatten(1).t().contiguous()
+    wts = _encoder_weights(synth_sd, "hintpath").to(H.DEV)
+    xd, pd = x.to(H.DEV), pos.to(H.DEV)
+    outs = []
+    for extra in (0, 4 << 20):
+        out = torch.empty_like(xd)
+        ws = torch.empty(n * l * 384 * 4 + 256 + extra, device=H.DEV, dtype=torch.uint8)
+        _ffi.check(_ffi.lib().disco_op_encoder_stack(_ffi.ptr(xd), _ffi.ptr(pd), _ffi.ptr(wts), _ffi.ptr(out), n, l,
+                                                     _ffi.ptr(ws), ws.numel(), H.stream()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    want = R.encoder_stack(synth_sd, "hintpath", x, pos[None].expand(n, -1, -1))
+    assert H.max_err(outs[1], want) < 2e-5
+
+
 def _kmeans_gpu(H, x, sizes, init, fallback, k, d=64, channel_major=0):
     n, l = x.shape[0], (x.shape[2] if channel_major else x.shape[1])
     xd, sd_ = x.to(H.DEV).contiguous(), sizes.to(H.DEV).contiguous()
