@@ -154,6 +154,55 @@ def single_image_latency(model, gray1, ab1, sync, reps=30):
     return round(sorted(ts)[len(ts) // 2] * 1e3, 3)
 
 
+def other_single_gpu_configs(model, sd, precision, sync):
+    """The other BASELINE configurations one GPU can run, each timed the plain way (3 warm-ups, then `reps` asynchronous calls closed by one
+    synchronize), reported NEXT TO the headline and never as `value`:
+      config 4  --no_resize: eight 512x512 and eight 768x512 L images through runner.colorize_mixed (grouped by shape: two forwards), K = 8
+      config 5a --diverse, K = 16, clustering: the 32-image share one GPU has of the 8-GPU batch of 256 -> 96 colorizations per forward
+      small     8 x 256x256, K = 8: the largest forward that still takes the small-batch path (SpixelNet on a side stream)"""
+    from disentangledcolorization_amd import synth
+    from disentangledcolorization_amd.model import AnchorColorProb
+    from disentangledcolorization_amd.runner import colorize_mixed
+    out = {}
+
+    def timed(fn, reps):
+        for _ in range(3):
+            np.random.seed(130); fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            np.random.seed(130); fn()
+        sync()
+        return (time.perf_counter() - t0) / reps
+
+    keep = model.sync_kmeans_events
+    model.sync_kmeans_events = False
+    try:
+        grays = [synth.synth_inputs(1, 512, 512, seed=40 + i)[0].cuda() for i in range(8)] + [synth.synth_inputs(1, 768, 512, seed=60 + i)[0].cuda() for i in range(8)]
+        dt = timed(lambda: colorize_mixed(model, grays), 5)
+        px = 8 * 512 * 512 + 8 * 768 * 512
+        out["config4_no_resize_mixed"] = {"workload": "8 x 512x512 + 8 x 768x512 (H x W), K=8, grouped by shape", "ms_per_batch": round(dt * 1e3, 2),
+                                          "images_per_s": round(16 / dt, 1), "ns_per_pixel": round(dt * 1e9 / px, 2)}
+        g8, a8 = synth.synth_inputs(8, 256, 256, seed=5)
+        g8, a8 = g8.cuda(), a8.cuda()
+        dt = timed(lambda: model(g8, a8, True, 0), 20)
+        out["small_batch_8x256"] = {"workload": "8 x 256x256, K=8", "ms_per_forward": round(dt * 1e3, 3), "images_per_s": round(8 / dt, 1)}
+    finally:
+        model.sync_kmeans_events = keep
+    m16 = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, n_clusters=16, enhanced=True,
+                          precision=precision, init_weights=False)
+    m16.load_state_dict(sd)
+    m16 = m16.cuda().eval()
+    m16.sync_kmeans_events = False
+    g32, a32 = synth.synth_inputs(32, 256, 256, seed=5)
+    g32, a32 = g32.cuda(), a32.cuda()
+    dt = timed(lambda: m16(g32, a32, True, 1), 5)                 # sampled_T > 0: the three diverse colorizations of every image
+    out["config5a_diverse_k16_shard"] = {"workload": "32 x 256x256 (one GPU's share of batch 256 on 8), --diverse, K=16 clustering: 96 colorizations",
+                                         "ms_per_forward": round(dt * 1e3, 2), "colorizations_per_s": round(96 / dt, 1), "images_per_s": round(32 / dt, 1)}
+    del m16
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +214,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["mx6", "mx8", "x2q", "mx8all", "f16x3"],
                     help="conv arithmetic per stack (disentangledcolorization_amd/model.py); default: the package default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the extra timed lines for BASELINE configs 4 and 5a (reported next to the headline, never as `value`)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): successive steps alternate between two HIP streams, each a full-size forward, the second "
                                                               "staggered behind the first (runner.py), everything joined by the synchronize() that closes the timed region; "
                                                               "0: every step is issued as --micro micro-batches and joined before the next one")
@@ -192,13 +242,18 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # DISCO_DIST_BACKEND=gloo (tests/test_gpu_dist.py): several ranks on ONE GPU - real forwards, streams and events on device tensors, the
+    # collectives on gloo (RCCL wants a device per rank): the multi-rank code path on a single-GPU test box
+    backend = os.environ.get("DISCO_DIST_BACKEND", "nccl")
+    if not fake and backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     dev = torch.device("cpu") if fake else torch.device("cuda", local_rank)
     if not fake:
         torch.cuda.set_device(local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if fake:
+        if fake or backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -267,7 +322,7 @@ def main():
     conv_launches = 0
     stage_ms = {}
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -361,6 +416,8 @@ def main():
             if world == 1:
                 # the reference's own call pattern is one image per forward (main/colorizer/inference.py:93-109): its latency, NOT `value`
                 out["single_image_latency_ms"] = single_image_latency(model, gray[:1].contiguous(), ab[:1].contiguous(), sync)
+            if world == 1 and not args.no_other_configs and args.batch == 64 and args.size == 256 and args.global_batch == 0:
+                out["other_configs"] = other_single_gpu_configs(model, sd, args.precision, sync)
             if world == 1 and args.alt and not args.no_alt and args.precision == "mx6":
                 # the opt-in arithmetic on the same inputs, timed the same way (NOT `value`: DESIGN.md section 2 says why it is opt-in)
                 out["opt_in_precision"] = measure_alt("x2q", sd, gray, ab, n_global, args, sync)

@@ -22,7 +22,7 @@ class DiscoError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("sp_size", C.c_int32), ("n_clusters", C.c_int32), ("random_hint", C.c_int32),
-                ("precision", C.c_int32), ("segnet_only", C.c_int32), ("hint2regress", C.c_int32),
+                ("precision", C.c_int32), ("network", C.c_int32), ("hint2regress", C.c_int32),
                 ("spix_pos", C.c_int32)]
 
 

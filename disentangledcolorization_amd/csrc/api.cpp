@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <cstring>
+#include <array>
 #include <map>
 #include <string>
 #include <utility>
@@ -211,6 +212,8 @@ struct disco_ctx {
     int stg_next = 0;
     int profiling = 0;
     // small batches (run_plan): SpixelNet runs on this stream next to ColorProbNet on the caller's - neither fills the GPU on its own
+    bool side_failed = false;                    // creating it failed once: small forwards stay on the caller's stream
+    std::map<std::array<int, 3>, size_t> seg_ws_bytes;      // (n, H, W) -> workspace block of a forked SpixelNet
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // disco_set_progress_event: recorded on the next forward's stream behind its `progress_after`-th MFMA conv launch (one shot)
@@ -910,7 +913,7 @@ void enhance_stage(Plan& P, disco_ctx* c, Act full, Act g16, int out_act, float*
     P.drop(u);
 }
 
-// Stand-alone networks (ABI 9; models/network.py:125,147,260 as modules of their own): a context created with disco_options.segnet_only = 1
+// Stand-alone networks (ABI 9; models/network.py:125,147,260 as modules of their own): a context created with disco_options.network = 1
 // (SpixelNet), 2 (ColorProbNet) or 3 (HourGlass2) holds that network's tensors only and serves one entry point.
 //   1: d_in gray (n,1,H,W)           -> d_out (n,9,H,W)  softmax over the 9 slots (network.py:312)
 //   2: d_in gray (n,1,H,W)           -> d_out (n,64,H,W) features (network.py:234)
@@ -989,17 +992,30 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     void* seg_ws = nullptr;
     size_t seg_bytes = 0;
     if (fork_shape) {
-        Plan S(c, a, (size_t)1 << 46, true);
-        segnet_stage(S, c, nullptr, n, H, W, nullptr);
-        seg_bytes = S.arena.peak + 4096;
-        if (S.rc) P.rc = S.rc;
-        seg_ws = P.raw(seg_bytes);
+        // (cached per shape: every real forward would otherwise run a dry plan of SpixelNet just to learn the size again - host time on
+        // the latency path; the table is cleared whenever the layers are rebuilt)
+        const std::array<int, 3> key{n, H, W};
+        auto it = c->seg_ws_bytes.find(key);
+        if (it == c->seg_ws_bytes.end()) {
+            Plan S(c, a, (size_t)1 << 46, true);
+            segnet_stage(S, c, nullptr, n, H, W, nullptr);
+            if (S.rc) P.rc = S.rc;
+            else it = c->seg_ws_bytes.emplace(key, S.arena.peak + 4096).first;
+        }
+        if (P.ok()) { seg_bytes = it->second; seg_ws = P.raw(seg_bytes); }
     }
     bool forked = false;
     if (fork_shape && !dry && !calib && P.ok() && !c->progress_ev && !c->profiling && P.dbg_row < 0) {
-        if (!c->side) {
+        if (!c->side && !c->side_failed) {
             if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); }
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+                // whatever was created goes back, and the fork stays off for this context: no retry (and no leak) on every later small forward
+                if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+                if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+                if (c->side) (void)hipStreamDestroy(c->side);
+                c->ev_join = c->ev_fork = nullptr; c->side = nullptr; c->side_failed = true;
+                (void)hipGetLastError();
+            }
         }
         if (c->side && hipEventRecord(c->ev_fork, s) == hipSuccess && hipStreamWaitEvent(c->side, c->ev_fork, 0) == hipSuccess) {
             disco_forward_args a2 = *a;
@@ -1197,7 +1213,7 @@ int calibrate_ctx_impl(disco_ctx* c, const float* d_user_gray, int un, int uh, i
     disco_forward_args a{};
     a.n = n; a.h = H; a.w = W; a.sampled_T = 0; a.test_mode = 1;
     a.h_init_idx = idx.data(); a.h_hint_pos = idx.data();
-    const int sub = c->opt.segnet_only;
+    const int sub = c->opt.network;
     const bool seg = sub != SUBNET_FULL;          // a stand-alone network: input -> bufs[0], its one output -> bufs[5]
     if (sub == SUBNET_ENH && !d_user_gray) { set_error("a stand-alone HourGlass2 context is calibrated on its caller's input (disco_calibrate)"); return DISCO_ESTATE; }
     size_t peak = 0;
@@ -1253,7 +1269,7 @@ int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
     if (!c->finalized) { set_error("disco_forward before disco_finalize"); return DISCO_ESTATE; }
     const int sp = c->opt.sp_size;
     if (a->n < 1 || a->h < sp || a->w < sp || a->h % sp || a->w % sp) { set_error("bad input size %dx%dx%d (multiples of %d)", a->n, a->h, a->w, sp); return DISCO_ESHAPE; }
-    if (!c->opt.segnet_only && (a->h / sp) * (a->w / sp) < c->opt.n_clusters) { set_error("fewer tokens than clusters"); return DISCO_ESHAPE; }
+    if (!c->opt.network && (a->h / sp) * (a->w / sp) < c->opt.n_clusters) { set_error("fewer tokens than clusters"); return DISCO_ESHAPE; }
     if (a->max_fallback < 0) { set_error("max_fallback %d", a->max_fallback); return DISCO_EINVAL; }
     if (a->max_fallback > c->opt.n_clusters * 20) { set_error("max_fallback %d > K*20", a->max_fallback); return DISCO_EINVAL; }
     if (a->test_mode & ~1) { set_error("test_mode must be 0 or 1"); return DISCO_EINVAL; }
@@ -1385,8 +1401,22 @@ constexpr float MX6_DISPARITY_LIMIT = 64.f;
 // Channels levelled first (keeps fp6) when a block's spread exceeds this; the plain synthetic checkpoint (9) is left as it is
 constexpr float MX6_EQUALISE_ABOVE = 16.f;
 int enhance_disparity_guard(disco_ctx* c, const float* d_user_gray = nullptr, int un = 0, int uh = 0, int uw = 0) {
-    if (c->opt.segnet_only == SUBNET_SEG || c->opt.segnet_only == SUBNET_REP || c->enhance_fp8_fallback || arith_of(c, "enhanceNet.outConv") != ARITH_MX6) return DISCO_OK;
+    if (c->opt.network == SUBNET_SEG || c->opt.network == SUBNET_REP || c->enhance_fp8_fallback || arith_of(c, "enhanceNet.outConv") != ARITH_MX6) return DISCO_OK;
     if (!c->sd.count("enhanceNet.outConv.weight")) return DISCO_OK;      // (host weights gone: cannot happen after disco_finalize)
+    // All or nothing: everything a rebuild touches - the layers, the exponents and maxima of the HourGlass2's tensors, the levelling
+    // factors and the flags - is saved first and put back if the rebuild or its calibration fails, so that "a failing disco_calibrate
+    // leaves the previous calibration in place" (include/disco_hip.h) also holds on this path
+    struct Saved {
+        decltype(c->conv) conv; decltype(c->sexp) sexp; decltype(c->sexp_nat) sexp_nat; decltype(c->amax) amax; decltype(c->chan_amax) chan_amax;
+        decltype(c->eq_in) eq_in; decltype(c->eq_out) eq_out; bool equalised, fp8; float disp, disp_before;
+    };
+    auto save = [&]() { return Saved{c->conv, c->sexp, c->sexp_nat, c->amax, c->chan_amax, c->eq_in, c->eq_out, c->equalised, c->enhance_fp8_fallback, c->mx6_disparity, c->mx6_disparity_before_eq}; };
+    auto restore = [&](Saved& v) {
+        c->conv.swap(v.conv); c->sexp.swap(v.sexp); c->sexp_nat.swap(v.sexp_nat); c->amax.swap(v.amax); c->chan_amax.swap(v.chan_amax);
+        c->eq_in.swap(v.eq_in); c->eq_out.swap(v.eq_out); c->equalised = v.equalised; c->enhance_fp8_fallback = v.fp8;
+        c->mx6_disparity = v.disp; c->mx6_disparity_before_eq = v.disp_before;
+        c->seg_ws_bytes.clear();
+    };
     auto rebuild = [&]() -> int {
         // the old layers' device buffers stay in c->allocs until disco_destroy (a few tens of MB); the tensors' exponents and maxima are measured again
         int rc = make_enhance(c);
@@ -1396,18 +1426,24 @@ int enhance_disparity_guard(disco_ctx* c, const float* d_user_gray = nullptr, in
         for (auto it = c->amax.begin(); it != c->amax.end();) it = it->first.compare(0, 11, "enhanceNet.") == 0 ? c->amax.erase(it) : std::next(it);
         c->chan_amax.clear();
         c->mx6_disparity = 0.f;
+        c->seg_ws_bytes.clear();
         return calibrate_ctx(c, d_user_gray, un, uh, uw);
     };
     static const bool no_eq = std::getenv("DISCO_NO_EQUALISE") != nullptr;       // (tests of the fp8 fallback)
-    if (!c->equalised && !no_eq && c->mx6_disparity > MX6_EQUALISE_ABOVE && plan_equalisation(c)) {
-        c->equalised = true;
-        c->mx6_disparity_before_eq = c->mx6_disparity;
-        if (int rc = rebuild()) return rc;
+    if (!c->equalised && !no_eq && c->mx6_disparity > MX6_EQUALISE_ABOVE) {
+        Saved before = save();
+        if (plan_equalisation(c)) {
+            c->equalised = true;
+            c->mx6_disparity_before_eq = c->mx6_disparity;
+            if (int rc = rebuild()) { restore(before); return rc; }
+        }
     }
     if (!(c->mx6_disparity > MX6_DISPARITY_LIMIT)) return DISCO_OK;
+    Saved before = save();
     c->enhance_fp8_fallback = true;
     const float measured = c->mx6_disparity;          // (no fp6 tensor is left to measure after the rebuild: keep what decided it)
     const int rc = rebuild();
+    if (rc) { restore(before); return rc; }
     c->mx6_disparity = measured;
     return rc;
 }
@@ -1438,8 +1474,8 @@ int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
     if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL && opt->precision != DISCO_PREC_X2Q && opt->precision != DISCO_PREC_MX6) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
     if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }
-    if (opt->segnet_only < 0 || opt->segnet_only > 3) { set_error("segnet_only %d: 0 (colorizer), 1 SpixelNet, 2 ColorProbNet, 3 HourGlass2", opt->segnet_only); return DISCO_EINVAL; }
-    if (opt->segnet_only && (opt->hint2regress || opt->spix_pos)) { set_error("a stand-alone network context takes no colorizer flags"); return DISCO_EINVAL; }
+    if (opt->network < 0 || opt->network > 3) { set_error("network %d: 0 (colorizer), 1 SpixelNet, 2 ColorProbNet, 3 HourGlass2", opt->network); return DISCO_EINVAL; }
+    if (opt->network && (opt->hint2regress || opt->spix_pos)) { set_error("a stand-alone network context takes no colorizer flags"); return DISCO_EINVAL; }
     int ndev = 0;
     DISCO_HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) { set_error("device %d of %d", device, ndev); return DISCO_EINVAL; }
@@ -1478,7 +1514,7 @@ int disco_load_tensor(disco_ctx* c, const char* key, const float* h_data, const 
 int disco_finalize(disco_ctx* c) {
     if (!c) { set_error("null context"); return DISCO_EINVAL; }
     if (c->finalized) return DISCO_OK;
-    const int sub = c->opt.segnet_only;
+    const int sub = c->opt.network;
     const std::string only = subnet_prefix(sub);            // stand-alone network contexts hold that network's tensors and nothing else
     auto mine = [&](const std::string& key) { return only.empty() || key.compare(0, only.size(), only) == 0; };
     // strict: same key set and shapes as the reference's load_state_dict(strict=True) (utils_train.py:151)
@@ -1564,7 +1600,7 @@ int disco_finalize(disco_ctx* c) {
 
 int disco_calibrate(disco_ctx* c, const float* d_gray, int n, int h, int w) {
     if (!c || !c->finalized || !d_gray) { set_error("disco_calibrate: bad argument / context not finalized"); return DISCO_EINVAL; }
-    if (n < 1 || n > 64 || h < 16 || w < 16 || h % 16 || w % 16 || (!c->opt.segnet_only && (h / 16) * (w / 16) < c->opt.n_clusters)) { set_error("disco_calibrate: bad size %dx%dx%d", n, h, w); return DISCO_ESHAPE; }
+    if (n < 1 || n > 64 || h < 16 || w < 16 || h % 16 || w % 16 || (!c->opt.network && (h / 16) * (w / 16) < c->opt.n_clusters)) { set_error("disco_calibrate: bad size %dx%dx%d", n, h, w); return DISCO_ESHAPE; }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mu);
     ProgressDisarm disarm{c, nullptr};
@@ -1585,19 +1621,26 @@ int disco_saturation_count(disco_ctx* c, void* stream, uint64_t* count) {
     return DISCO_OK;
 }
 
-int disco_calibration_count(disco_ctx* c) { return c ? (int)c->amax.size() : 0; }
+int disco_calibration_count(disco_ctx* c) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);          // (a calibration on another host thread rewrites these tables)
+    return (int)c->amax.size();
+}
 
 int disco_enhance_arithmetic(disco_ctx* c, int* precision, float* channel_disparity, float* disparity_before_equalisation) {
     if (!c || !precision || !channel_disparity || !disparity_before_equalisation) { set_error("null argument"); return DISCO_EINVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
     *disparity_before_equalisation = c->equalised ? c->mx6_disparity_before_eq : 0.f;
-    const int ar = (c->opt.segnet_only == SUBNET_SEG || c->opt.segnet_only == SUBNET_REP) ? ARITH_F16X3 : arith_of(c, "enhanceNet.outConv");
+    const int ar = (c->opt.network == SUBNET_SEG || c->opt.network == SUBNET_REP) ? ARITH_F16X3 : arith_of(c, "enhanceNet.outConv");
     *precision = ar == ARITH_MX6 ? DISCO_PREC_MX6 : (ar == ARITH_F16X3 ? DISCO_PREC_F16X3 : DISCO_PREC_MX8);
     *channel_disparity = c->mx6_disparity;
     return DISCO_OK;
 }
 
 int disco_calibration_entry(disco_ctx* c, int i, const char** key, float* amax, int* sexp) {
-    if (!c || i < 0 || i >= (int)c->amax.size() || !key || !amax || !sexp) { set_error("bad calibration index"); return DISCO_EINVAL; }
+    if (!c || !key || !amax || !sexp) { set_error("bad calibration index"); return DISCO_EINVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (i < 0 || i >= (int)c->amax.size()) { set_error("bad calibration index"); return DISCO_EINVAL; }
     auto it = c->amax.begin();
     std::advance(it, i);
     *key = it->first.c_str(); *amax = it->second;
@@ -1612,10 +1655,11 @@ int disco_workspace_bytes(disco_ctx* c, int n, int h, int w, int sampled_T, size
     a.n = n; a.h = h; a.w = w; a.sampled_T = sampled_T; a.test_mode = 1;   // inference needs at least what validation does
     int rc = check_forward_args(c, &a);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);          // the dry plan reads the layer and exponent tables a concurrent disco_calibrate may rebuild
     size_t peak = 0;
-    if (c->opt.segnet_only) {
+    if (c->opt.network) {
         Plan P(c, &a, (size_t)1 << 46, true);
-        subnet_stage(P, c, c->opt.segnet_only, nullptr, n, h, w, nullptr);
+        subnet_stage(P, c, c->opt.network, nullptr, n, h, w, nullptr);
         peak = P.arena.peak; rc = P.rc;
     } else rc = run_plan(c, &a, (size_t)1 << 46, true, &peak);
     *bytes = peak + 4096;
@@ -1631,11 +1675,11 @@ static int forward_subnet(disco_ctx* c, int which, const char* entry, int n, int
     disco_forward_args a{};
     a.n = n; a.h = h; a.w = w; a.d_workspace = d_ws; a.workspace_bytes = ws_bytes; a.stream = stream;
     if (!c || !c->finalized) { set_error("%s before disco_finalize", entry); return DISCO_ESTATE; }
-    if (c->opt.segnet_only && c->opt.segnet_only != which) { set_error("%s on the stand-alone context of another network", entry); return DISCO_ESTATE; }
+    if (c->opt.network && c->opt.network != which) { set_error("%s on the stand-alone context of another network", entry); return DISCO_ESTATE; }
     if (n < 1 || h < 16 || w < 16 || h % 16 || w % 16) { set_error("bad input size %dx%dx%d (multiples of 16)", n, h, w); return DISCO_ESHAPE; }
     if (!d_in || !d_out || !d_ws) { set_error("null tensor pointer"); return DISCO_EINVAL; }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
-    if (!c->calibrated) { set_error(c->opt.segnet_only == SUBNET_ENH ? "stand-alone HourGlass2 context: disco_calibrate on a first batch of its input comes first" : "context used before its calibration pass"); return DISCO_ESTATE; }
+    if (!c->calibrated) { set_error(c->opt.network == SUBNET_ENH ? "stand-alone HourGlass2 context: disco_calibrate on a first batch of its input comes first" : "context used before its calibration pass"); return DISCO_ESTATE; }
     Plan P(c, &a, ws_bytes, false);
     subnet_stage(P, c, which, d_in, n, h, w, d_out);
     return P.rc;
@@ -1652,8 +1696,9 @@ int disco_forward_enhance(disco_ctx* c, int n, int h, int w, const float* d_inpu
 }
 int disco_subnet_workspace_bytes(disco_ctx* c, int which, int n, int h, int w, size_t* bytes) {
     if (!c || !bytes || !c->finalized) { set_error("disco_subnet_workspace_bytes: bad argument / context not finalized"); return DISCO_EINVAL; }
-    if (which < SUBNET_SEG || which > SUBNET_ENH || (c->opt.segnet_only && c->opt.segnet_only != which)) { set_error("network %d is not in this context", which); return DISCO_EINVAL; }
+    if (which < SUBNET_SEG || which > SUBNET_ENH || (c->opt.network && c->opt.network != which)) { set_error("network %d is not in this context", which); return DISCO_EINVAL; }
     if (n < 1 || h < 16 || w < 16 || h % 16 || w % 16) { set_error("bad input size %dx%dx%d (multiples of 16)", n, h, w); return DISCO_ESHAPE; }
+    std::lock_guard<std::mutex> lk(c->mu);
     disco_forward_args a{};
     a.n = n; a.h = h; a.w = w;
     Plan P(c, &a, (size_t)1 << 46, true);
@@ -1666,7 +1711,7 @@ int disco_forward(disco_ctx* c, const disco_forward_args* a) {
     std::unique_lock<std::mutex> lk;
     if (c) lk = std::unique_lock<std::mutex>(c->mu);
     ProgressDisarm disarm{c, a ? (hipStream_t)a->stream : nullptr};
-    if (c && c->opt.segnet_only) { set_error("stand-alone network context: use disco_forward_segnet / _repnet / _enhance"); return DISCO_ESTATE; }
+    if (c && c->opt.network) { set_error("stand-alone network context: use disco_forward_segnet / _repnet / _enhance"); return DISCO_ESTATE; }
     int rc = check_forward_args(c, a);
     if (rc) return rc;
     if (!a->d_gray || !a->d_ab || !a->d_pal_logit || !a->d_ref_logit || !a->d_pred_colors || !a->d_affinity ||

@@ -175,7 +175,6 @@ class AnchorColorProb(nn.Module):
         self._ws_need = {}
         self._keep = None
         self._range_checks_left = {}
-        self._clamped_unreported = 0     # clamps the automatic range checks read off the device counter, owed to saturation_count()
         if init_weights:
             from .synth import synth_state_dict
             super().load_state_dict(synth_state_dict(130, hint2regress=self.hint2regress), strict=True)
@@ -282,6 +281,11 @@ class AnchorColorProb(nn.Module):
         with torch.cuda.device(g.device):
             ctx = self._context(g.device)
             _ffi.check(_ffi.lib().disco_calibrate(ctx, _ffi.ptr(g), g.shape[0], g.shape[2], g.shape[3]))
+        # a calibration may rebuild the HourGlass2 on another arithmetic (channel levelling, the fp8 fallback): its activation planes then have
+        # another size, so every cached workspace requirement is stale - and a workspace sized for the old plan would fail the very re-run
+        # the automatic range check makes (DISCO_ENOMEM "workspace too small")
+        self._ws_need = {}
+        self._workspace = {}
         self._warn_fp8_fallback()
 
     def _read_clamp_counter(self):
@@ -291,11 +295,11 @@ class AnchorColorProb(nn.Module):
 
     def saturation_count(self):
         """fp8 activation elements clamped since the previous call (one device synchronisation on the current stream).  The automatic
-        range checks of the first forwards read the same device counter; what they saw is carried over here, not lost."""
+        range checks of the first forwards read - and thereby reset - the same device counter: a forward they found clamping is discarded,
+        re-calibrated and run again, so its count is not owed to the caller."""
         if self._ctx is None:
             return 0
-        seen, self._clamped_unreported = self._clamped_unreported, 0
-        return seen + self._read_clamp_counter()
+        return self._read_clamp_counter()
 
     def set_profiling(self, level=1):
         """0 off, 1 per-stage hipEvents, 2 additionally an event pair around every MFMA conv launch."""

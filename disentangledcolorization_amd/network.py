@@ -6,7 +6,7 @@
 
 in the configurations `models/model.py:15,41,44` constructs them with (anything else raises NotImplementedError).  Each holds the
 reference's `state_dict` of that network (keys without the colorizer's `segnet.net.` / `repnet.` / `enhanceNet.` prefix, strict
-`load_state_dict`) and runs on a stand-alone context of the C ABI (`disco_options.segnet_only` = 1 / 2 / 3, `disco_forward_segnet` /
+`load_state_dict`) and runs on a stand-alone context of the C ABI (`disco_options.network` = 1 / 2 / 3, `disco_forward_segnet` /
 `_repnet` / `_enhance`, include/disco_hip.h): the same kernels, arithmetic and calibration as inside `model.AnchorColorProb`.
 Inference only; CUDA/HIP tensors only (no CPU fallback: without the library this module raises).
 
@@ -25,7 +25,7 @@ from .model import _Node, _PARAM_KINDS, _PRECISIONS, default_precision
 
 class _SubNet(nn.Module):
     _PREFIX = ""        # the network's keys inside the colorizer's state_dict
-    _WHICH = 0          # disco_options.segnet_only
+    _WHICH = 0          # disco_options.network
     _IN_CH = 1
     _OUT_CH = 0
     _ENTRY = ""

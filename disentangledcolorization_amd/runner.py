@@ -144,6 +144,12 @@ class ShardedColorizer:
         if hasattr(model, "set_progress_event"):
             r.progress_fn = model.set_progress_event
             r.stagger_convs = STAGGER_CONVS
+        # Under a process group the automatic range check is OFF: it would re-calibrate a rank on ITS shard (activation exponents are a
+        # per-context property, and an exponent moves pred_colors at the 1e-5 level), so the result of an image could depend on how many
+        # ranks share the batch.  Every rank keeps the load-time calibration (the same on all of them); a caller whose data lie outside it
+        # calls model.calibrate() with the SAME images on every rank and watches model.saturation_count().
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and hasattr(model, "range_checks"):
+            model.range_checks = 0
         return r
 
     # ---- local forward (optionally as micro-batches on separate streams) ----------------------------------------
@@ -263,7 +269,7 @@ class ShardedColorizer:
             buf[: len(ev_local)] = torch.as_tensor(ev_local, dtype=torch.int32)
         buf[mx] = int(checksum & 0x7fffffff)
         out = torch.empty(world * (mx + 1), dtype=torch.int32, device=device)
-        dist.all_gather_into_tensor(out, buf, group=self.group)
+        all_gather_into(out, buf, group=self.group)
         out = out.cpu().numpy().reshape(world, mx + 1)
         if len(set(int(v) for v in out[:, mx])) != 1:
             raise RuntimeError("the ranks drew different k-means rows / fallback streams: seed NumPy, random and torch identically "
@@ -397,12 +403,36 @@ class ShardedColorizer:
         if keep is not None:
             for t in (send, recv, pred_g, mask_g):
                 keep(t)
-        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=async_op)
+        work = all_gather_into(recv, send, group=self.group, async_op=async_op)
         if async_op:
             self._pending.append((work, finish))
         elif finish is not None:
             finish()
         return pred_g, mask_g
+
+
+class _DoneWork:
+    """Stand-in for the work handle of a collective that has already completed."""
+    def wait(self):
+        return True
+
+
+def all_gather_into(recv, send, group=None, async_op=False):
+    """dist.all_gather_into_tensor, plus ONE special case: device tensors on the gloo backend - two or more ranks sharing one GPU, which
+    is how tests/test_gpu_dist.py runs world size 2 on a single-GPU box (RCCL wants a device per rank).  gloo's all_gather_into_tensor
+    takes host tensors only, so the rows are staged through pinned host buffers; the device-side ordering is the caller's: the copy out
+    follows everything enqueued on the current stream, the copy back is complete when this returns."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        st = torch.cuda.current_stream(send.device)
+        h_send = torch.empty(send.shape, dtype=send.dtype, pin_memory=True)
+        h_send.copy_(send, non_blocking=True)
+        st.synchronize()
+        h_recv = torch.empty(recv.shape, dtype=recv.dtype, pin_memory=True)
+        dist.all_gather_into_tensor(h_recv, h_send, group=group)
+        recv.copy_(h_recv, non_blocking=True)
+        st.synchronize()
+        return _DoneWork() if async_op else None
+    return dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
 
 
 def colorize_mixed(model, grays, abs_=None, sampled_T=0, max_batch=64):

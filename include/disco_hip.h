@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 9
+#define DISCO_ABI_VERSION 10
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -101,7 +101,7 @@ typedef struct disco_options {
     int32_t n_clusters;  /* K anchors (inference.py:156) */
     int32_t random_hint; /* 1: anchors come from h_hint_pos instead of k-means (model.py:69) */
     int32_t precision;   /* DISCO_PREC_* for the conv stacks */
-    int32_t segnet_only; /* stand-alone network contexts (the field keeps its round-1 name; 0 = the colorizer):
+    int32_t network;     /* which network the context holds (ABI 10: the field was `segnet_only` through ABI 9; 0 = the colorizer):
                             1: only the SpixelSeg weights ("segnet.net.*", 94 tensors), serves disco_forward_segnet
                                (models/model.py:12-29, main/spixelseg/inference.py:89);
                             2 (ABI 9): only ColorProbNet's ("repnet.*", models/network.py:147-236), serves disco_forward_repnet;
@@ -170,7 +170,7 @@ int disco_saturation_count(disco_ctx *ctx, void *stream, uint64_t *count);
  * n <= 64, h and w multiples of 16.  Blocking (synchronises the device first: no forward of this context may be in flight).
  * Calibrations accumulate (a tensor's recorded max |x| only grows), so results of later forwards change at the 1e-5 level only
  * when a scale actually moves.  disco_finalize has already calibrated on two synthetic images; call this when
- * disco_saturation_count reports clamping on your data.  On a stand-alone HourGlass2 context (segnet_only = 3) the input is that
+ * disco_saturation_count reports clamping on your data.  On a stand-alone HourGlass2 context (network = 3) the input is that
  * network's own: d_gray = (n,65,h,w), and the first call is what makes the context usable. */
 int disco_calibrate(disco_ctx *ctx, const float *d_gray, int n, int h, int w);
 /* The calibration pass's per-tensor record (diagnostics): producer key, max |x| over the calibration images, chosen scale exponent
@@ -190,7 +190,7 @@ int disco_calibration_count(disco_ctx *ctx);
 int disco_enhance_arithmetic(disco_ctx *ctx, int *precision, float *channel_disparity, float *disparity_before_equalisation);
 int disco_calibration_entry(disco_ctx *ctx, int i, const char **key, float *amax, int *sexp);
 /* One network of the colorizer on its own (the reference's models/network.py classes as modules of their own), on a full context or on
- * the stand-alone context of that network (disco_options.segnet_only = 1 / 2 / 3); workspace as reported by
+ * the stand-alone context of that network (disco_options.network = 1 / 2 / 3); workspace as reported by
  * disco_subnet_workspace_bytes(ctx, which = 1 / 2 / 3, ...) (on a stand-alone context disco_workspace_bytes reports the same).
  *   disco_forward_segnet:  SpixelNet.forward(gray (n,1,h,w)) -> affinity (n,9,h,w), softmax over the 9 neighbour slots (network.py:293-313)
  *   disco_forward_repnet:  ColorProbNet.forward(gray (n,1,h,w)) -> features (n,64,h,w) (network.py:220-236)                       [ABI 9]
@@ -226,7 +226,7 @@ int disco_set_debug_checksums(disco_ctx *ctx, void *d_table, int rows, int cols)
 int disco_set_debug_dump(disco_ctx *ctx, void *d_buf, size_t bytes_per_row);
 int disco_profile_count(disco_ctx *ctx);
 int disco_profile_entry(disco_ctx *ctx, int i, const char **name, float *ms, double *flops);
-/* level 2: number of conv3x3_mfma launches of the last forward, their summed duration (hipEvent pairs around
+/* level 2: number of conv3x3_mx_kernel launches of the last forward, their summed duration (hipEvent pairs around
  * each launch on the forward's stream) and their summed algorithmic FLOPs (2*9*Cin*Cout*Hout*Wout*N). */
 int disco_profile_conv(disco_ctx *ctx, int *launches, float *total_ms, double *total_flops);
 /* level 2: summed compulsory HBM bytes of those launches (sources and residual read once, output written once,

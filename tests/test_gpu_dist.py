@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra_env, launcher):
+def _bench(extra_env, launcher, args=("--gpus", "1", "--batch", "4")):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    cmd = launcher + [os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"]
+    cmd = launcher + [os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + list(args)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -32,3 +32,21 @@ def test_bench_on_rccl_with_forced_gather_matches_single_process():
                         "--master-port", str(port)])
     assert dist_line["n_gpus"] == 1 and dist_line["kmeans_events"] == 0
     assert dist_line["result_checksum"] == plain["result_checksum"]
+
+
+@pytest.mark.parametrize("n_global", [16, 17])
+def test_world_2_on_one_gpu_with_device_tensors(n_global):
+    """Two ranks SHARING cuda:0: bench.py's real N>1 configuration - real forwards, steps pipelined over two HIP streams per rank, results
+    written in place, the packed all-gather enqueued behind each forward with `record_stream` bookkeeping on device tensors, the event-count
+    exchange of the exact mode, the closing barrier - with the collectives on gloo (RCCL wants a device per rank, so it has only ever
+    seen world size 1 here; this torch build's gloo takes host tensors only for all_gather_into_tensor: runner.all_gather_into stages
+    device rows through pinned host buffers for that backend).  Equal shards (8 + 8: gathered straight into the result) and ragged
+    ones (9 + 8: padded and unpacked); the result checksum must equal the single-process run of the same global batch."""
+    plain = _bench({}, [sys.executable], ("--gpus", "1", "--global-batch", str(n_global)))
+    port = 35600 + os.getpid() % 1000 + n_global
+    two = _bench({"DISCO_DIST_BACKEND": "gloo"},
+                 [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", str(port)], ("--gpus", "2", "--global-batch", str(n_global)))
+    assert two["n_gpus"] == 2 and two["world_size_seen_by_backend"] == 2 and two["kmeans_events"] == 0
+    assert two["config"]["global_batch"] == n_global
+    assert two["result_checksum"] == plain["result_checksum"]

@@ -123,6 +123,33 @@ def test_batch_invariance_at_bench_size(synth_sd, q_to_ab):
         assert _err(pred[i], want[2][0]) <= AB_TOL and _err(pal[i], want[0][0]) < LOGIT_TOL
 
 
+def test_every_image_of_the_bench_batch_matches_the_oracle(synth_sd, q_to_ab):
+    """ALL 64 images of bench.py's timed batch (seed 5, K = 8, the k-means rows of NumPy seed 130 in image order) against the CPU oracle,
+    which runs the whole batch in one forward under the same seed: anchors exact for every image, |ab| within the 1e-3 bar, the logits
+    within theirs.  (The test above compares three of them image by image and ties the batch to single-image runs.)"""
+    n, k = 64, 8
+    gray, ab = synth.synth_inputs(n, 256, 256, seed=5)
+    m = _model(synth_sd, k)
+    _seed(130)
+    pal, ref, pred, aff, spix, mask = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    assert m.last_kmeans_events() is None or int(np.asarray(m.last_kmeans_events()).sum()) == 0
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    oracle = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=k)
+    worst = 0.0
+    for i0 in range(0, n, 8):                    # eight images per oracle forward: the draws of NumPy's stream consumed in image order
+        _seed(130)
+        for _ in range(i0):
+            np.random.choice(256, k, replace=False)
+        want = oracle.forward(gray[i0:i0 + 8], ab[i0:i0 + 8])
+        sl = slice(i0, i0 + 8)
+        assert torch.equal(mask[sl].cpu(), want[5]), "anchors of bench images %d..%d differ from the oracle" % (i0, i0 + 7)
+        assert torch.equal(spix[sl].cpu(), want[4])
+        assert _err(pal[sl], want[0]) < LOGIT_TOL and _err(ref[sl], want[1]) < LOGIT_TOL
+        worst = max(worst, _err(pred[sl], want[2]))
+    assert worst <= AB_TOL
+
+
 def test_diverse_batch_equals_per_image_runs(synth_sd):
     """BASELINE config 5a: diverse sampling is N=1-only in the reference (model.py:148-159 expand()); batched diverse
     is defined here as the per-image N=1 results, image-major [n][t].  K=16 clustering anchors."""
