@@ -1048,6 +1048,204 @@ __global__ __launch_bounds__(1024) void kmeans_small_kernel(const float* __restr
     for (int tt = tid; tt < L; tt += 1024) hint_mask[(size_t)img * L + tt] = hm_l[tt];
 }
 
+// ---- k-means + anchors for MORE than 256 points of 64 features: kmeans_small_kernel's pass, tile by tile (round 5) ------------------------
+// The --no_resize path clusters 1 024 ... 16 384 tokens per image, still on one workgroup (the member sums are one sequential chain per
+// cluster and feature, in ascending point order: that is what makes the result independent of everything but the data).
+// kmeans_anchor_kernel spends ~55 ns per point and pass there (a counting sort per pass, member rows fetched from L2 four at a time:
+// 82 us per pass at 1 536 points, 1.2 ms at 16 384).  Here the points stream through LDS in tiles of 256, ONCE per pass, and a tile is
+// assigned AND added to the running member sums while it is there: tiles come in ascending point order, members inside a tile in
+// ascending order, so the chain of additions per (cluster, feature) is the same as before - bit-identical centres, shifts, pass counts
+// and assignments (tests: the k-means cases of tests/test_gpu_ops.py run both kernels) - at ~17 ns per point and pass.
+__global__ __launch_bounds__(1024) void kmeans_tiled_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
+                                                            const int32_t* __restrict__ init_idx, const int32_t* __restrict__ fallback,
+                                                            int max_fallback, int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
+                                                            int32_t* info, int L, int K) {
+    extern __shared__ float dyn[];          // 2 x [256][KS_PITCH]: the tile being worked on and the one being written
+    __shared__ __attribute__((aligned(16))) float cen[2][KMAX * KS_CP];
+    __shared__ int asg[2][KS_MAXL];         // the tiles' assignments (double-buffered like the tiles)
+    __shared__ int cnt[KMAX];
+    __shared__ float shift_part[KMAX];
+    __shared__ int s_anchor[KMAX];
+    __shared__ int s_events, s_any_empty;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* X = x + (size_t)img * L * 64;
+    int32_t* assign = assign_out + (size_t)img * L;
+    for (int u = tid; u < K * 64; u += 1024) cen[0][(u >> 6) * KS_CP + (u & 63)] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
+    if (tid == 0) { s_events = 0; s_any_empty = 0; }
+    const int t = tid >> 2, q = tid & 3;          // point of the tile, quarter of the centres
+    const int KQ = (K + 3) >> 2;
+    const int ntiles = (L + 255) >> 8;
+    int cur = 0, passes = 0;
+    auto shift_of = [&](float dlane) -> float {
+        float qv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) { const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dlane), c)); qv = __builtin_fmaf(dc, dc, qv); }
+        return sqrtf(qv);
+    };
+    // a tile travels L2 -> registers (four coalesced 16-byte loads per thread, in flight while the previous tile is worked on) -> LDS
+    float4 pre[4];
+    auto fetch = [&](int b) {
+        const int base = b << 8, rows = min(256, L - base);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u4 = tid + 1024 * i;                     // float4 index inside the tile: row u4 >> 4, columns 4 (u4 & 15) ..
+            pre[i] = (u4 >> 4) < rows ? *reinterpret_cast<const float4*>(X + (size_t)base * 64 + (size_t)u4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto deposit = [&](int buf) {
+        float* xs = dyn + buf * (256 * KS_PITCH);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u4 = tid + 1024 * i;
+            float* d = xs + (u4 >> 4) * KS_PITCH + (u4 & 15) * 4;
+            d[0] = pre[i].x; d[1] = pre[i].y; d[2] = pre[i].z; d[3] = pre[i].w;
+        }
+    };
+    while (true) {
+        const int nxt = cur ^ 1;
+        // this wave's clusters: wave and wave + 16 (K <= 32); running member sum (lane = feature) and member count of each
+        float sum0 = 0.f, sum1 = 0.f; int m0 = 0, m1 = 0;
+        fetch(0);
+        __syncthreads();                                      // the previous pass is done with both tile buffers (and the centres are written)
+        deposit(0);
+        for (int b = 0; b < ntiles; ++b) {
+            const int base = b << 8, rows = min(256, L - base), buf = b & 1;
+            const float* xs = dyn + buf * (256 * KS_PITCH);
+            if (b + 1 < ntiles) fetch(b + 1);
+            __syncthreads();                                  // tile b is in LDS
+            // ---- assign ----
+            {
+                // this thread's centres j0 .. j0 + nq - 1 (at most 8: K <= 32), one distance chain each; the point's features are read four
+                // at a time as the chains advance (held all 64 at once next to the prefetched tile they spilled to scratch memory)
+                const int j0 = q * KQ, nq = min(K, (q + 1) * KQ) - j0;
+                float d[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) d[jj] = 0.f;
+                const float* rp = xs + (t < rows ? t : 0) * KS_PITCH;
+#pragma unroll 4
+                for (int c4 = 0; c4 < 16; ++c4) {
+                    const float r0 = rp[4 * c4], r1 = rp[4 * c4 + 1], r2 = rp[4 * c4 + 2], r3 = rp[4 * c4 + 3];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        if (jj >= nq) break;
+                        const float4 cv = *reinterpret_cast<const float4*>(cen[cur] + (j0 + jj) * KS_CP + 4 * c4);
+                        float df = r0 - cv.x; d[jj] = fmaf(df, df, d[jj]);
+                        df = r1 - cv.y; d[jj] = fmaf(df, df, d[jj]);
+                        df = r2 - cv.z; d[jj] = fmaf(df, df, d[jj]);
+                        df = r3 - cv.w; d[jj] = fmaf(df, df, d[jj]);
+                    }
+                }
+                float best = INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    if (jj < nq && d[jj] < best) { best = d[jj]; bi = j0 + jj; }
+#pragma unroll
+                for (int sft = 1; sft < 4; sft <<= 1) {
+                    const float od = __shfl_xor(best, sft); const int oj = __shfl_xor(bi, sft);
+                    if (od < best || (od == best && oj < bi)) { best = od; bi = oj; }
+                }
+                if (q == 0 && t < rows) { asg[buf][t] = bi; assign[base + t] = bi; }
+            }
+            __syncthreads();                                  // the tile's assignments are written; everybody is done with tile b - 1
+            if (b + 1 < ntiles) deposit(buf ^ 1);             // (its buffer takes tile b + 1 while this one is added up)
+            // ---- add the tile's members to the running sums: wave = cluster, lane = feature, ascending point order ----
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = wave + 16 * h;
+                if (j >= K) break;
+                unsigned long long mk[4]; int m = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int tt = bb * 64 + lane;
+                    const int av = tt < rows ? asg[buf][tt] : -1;
+                    mk[bb] = __ballot(av == j);
+                    m += __popcll(mk[bb]);
+                }
+                float sum = h ? sum1 : sum0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    unsigned long long mask = mk[bb];
+                    while (mask) {
+                        float v[8]; bool ok[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            ok[u] = mask != 0ull;
+                            const int tt = bb * 64 + (ok[u] ? __builtin_ctzll(mask) : 0);
+                            mask &= mask - 1ull;
+                            v[u] = xs[tt * KS_PITCH + lane];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (ok[u]) sum += v[u];
+                    }
+                }
+                if (h) { sum1 = sum; m1 += m; } else { sum0 = sum; m0 += m; }
+            }
+        }
+        // ---- the new centres and their shifts ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = wave + 16 * h;
+            if (j >= K) break;
+            const int m = h ? m1 : m0;
+            if (m > 0) {
+                const float sum = (h ? sum1 : sum0) / (float)m;
+                cen[nxt][j * KS_CP + lane] = sum;
+                const float sh = shift_of(sum - cen[cur][j * KS_CP + lane]);
+                if (lane == 0) { shift_part[j] = sh; cnt[j] = m; }
+            } else if (lane == 0) { cnt[j] = 0; s_any_empty = 1; }
+        }
+        __syncthreads();
+        if (s_any_empty) {
+            if (tid == 0) {
+                for (int j = 0; j < K; ++j)
+                    if (cnt[j] == 0) {
+                        const int e = s_events++;
+                        const int r = (fallback && e < max_fallback) ? fallback[(size_t)img * max_fallback + e] : 0;
+                        cnt[j] = -(r + 1);
+                    }
+            }
+            __syncthreads();
+            for (int j = wave; j < K; j += 16)
+                if (cnt[j] < 0) {
+                    const float sum = X[(size_t)(-cnt[j] - 1) * 64 + lane];
+                    cen[nxt][j * KS_CP + lane] = sum;
+                    const float sh = shift_of(sum - cen[cur][j * KS_CP + lane]);
+                    if (lane == 0) shift_part[j] = sh;
+                }
+            __syncthreads();
+            if (tid == 0) s_any_empty = 0;
+        }
+        ++passes;
+        float sh = 0.f;
+        for (int j = 0; j < K; ++j) sh += shift_part[j];
+        cur = nxt;
+        if ((sh * sh < 1e-4f) || passes >= 20) break;
+    }
+    __syncthreads();                        // every assignment of the last pass is in assign_out (this workgroup's own writes)
+    // anchors: per cluster the first argmax of [assign==j] + sizes*0.01 (exact fp32 ops, no fma); one wave per cluster
+    const float* sz = sizes + (size_t)img * L;
+    float* hm = hint_mask + (size_t)img * L;
+    for (int j = wave; j < K; j += 16) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int tt = lane; tt < L; tt += 64) {
+            const float sc = add_rn(assign[tt] == j ? 1.f : 0.f, mul_rn(sz[tt], 0.01f));
+            if (sc > bv) { bv = sc; bi = tt; }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { anchor_out[img * K + j] = bi; s_anchor[j] = bi; }
+    }
+    for (int tt = tid; tt < L; tt += 1024) hm[tt] = 0.f;
+    __syncthreads();
+    if (tid == 0) {
+        for (int j = 0; j < K; ++j) hm[s_anchor[j]] += 1.f;       // sequential: two clusters may share an anchor
+        if (info) { info[img * 2] = passes; info[img * 2 + 1] = s_events; }
+    }
+}
+
 // ---- k-means + anchors, fallback for more than KM_LIST_TOKENS points: one workgroup (256 threads) per image --------
 // The token matrix (L x 64 fp32) is staged once in LDS (row pitch 65 floats: conflict-free row-per-thread reads)
 // when it fits (L <= KM_LDS_TOKENS); larger images (no_resize path) read it from L2 with unconditional,
@@ -1470,6 +1668,12 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
         static std::atomic<int> small_done[DISCO_MAX_DEVICES];
         DISCO_HIP_CHECK(set_dyn_lds_once(small_done, reinterpret_cast<const void*>(kmeans_small_kernel), MAX_SMEM));
         hipLaunchKernelGGL(kmeans_small_kernel, dim3(n), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
+                           hint_mask, info, l, k);
+    } else if (small_ok && d == 64 && !channel_major) {
+        const size_t smem = (size_t)2 * 256 * KS_PITCH * sizeof(float);
+        static std::atomic<int> tiled_done[DISCO_MAX_DEVICES];
+        DISCO_HIP_CHECK(set_dyn_lds_once(tiled_done, reinterpret_cast<const void*>(kmeans_tiled_kernel), MAX_SMEM));
+        hipLaunchKernelGGL(kmeans_tiled_kernel, dim3(n), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
                            hint_mask, info, l, k);
     } else
     if (l <= KM_LDS_TOKENS) rc = launch(kmeans_anchor_kernel<true, false>, 0, (size_t)l * (d + 1) * sizeof(float) + lists + best);

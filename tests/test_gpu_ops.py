@@ -351,7 +351,8 @@ def _km_ab_inputs():
     """Token sets for the two k-means kernels side by side: clustered points, points on a coarse grid (exact ties between centres), half of
     the points identical (empty clusters -> fallback rows), ragged sizes, K from 2 to 32."""
     cases = []
-    for seed, (n, l, k) in enumerate([(16, 256, 8), (6, 256, 16), (4, 256, 32), (5, 200, 8), (5, 97, 5), (3, 64, 2), (3, 256, 8)]):
+    for seed, (n, l, k) in enumerate([(16, 256, 8), (6, 256, 16), (4, 256, 32), (5, 200, 8), (5, 97, 5), (3, 64, 2), (3, 256, 8),
+                                      (3, 1536, 8), (2, 1000, 5), (2, 4096, 32), (2, 5000, 16), (2, 300, 8)]):
         gen = g(900 + seed)
         centres = torch.randn(n, k, 64, generator=gen) * 2.0
         which = torch.randint(0, k, (n, l), generator=gen)
@@ -368,9 +369,9 @@ def _km_ab_inputs():
 
 
 def test_kmeans_small_kernel_equals_the_general_one(H, tmp_path):
-    """kmeans_small_kernel (<= 256 points of 64 features: the 256 x 256 image's latency path) against kmeans_anchor_kernel, which a
-    subprocess runs on the same inputs under DISCO_KMEANS_V1=1: assignments, anchors, hint masks, pass counts and empty-cluster events
-    identical, element by element."""
+    """kmeans_small_kernel (<= 256 points of 64 features: the 256 x 256 image's latency path) and kmeans_tiled_kernel (more points: the
+    --no_resize sizes) against kmeans_anchor_kernel, which a subprocess runs on the same inputs under DISCO_KMEANS_V1=1 (its LDS-list and
+    global-list paths): assignments, anchors, hint masks, pass counts and empty-cluster events identical, element by element."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     out = str(tmp_path / "v1.npz")

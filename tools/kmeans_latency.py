@@ -8,7 +8,7 @@ import numpy as np, torch
 import gpu_helpers as H
 from disentangledcolorization_amd import _ffi
 
-def run(x, k, iters=200):
+def run(x, k, iters=50):
     n, l, d = x.shape
     xd = x.to(H.DEV).contiguous(); sizes = torch.rand(n, l, device=H.DEV)
     idx = torch.as_tensor(np.stack([np.random.RandomState(i).choice(l, k, replace=False) for i in range(n)]).astype(np.int32)).to(H.DEV)
@@ -26,7 +26,8 @@ def run(x, k, iters=200):
     return e0.elapsed_time(e1) / iters * 1e3, info.cpu()[:, 0].tolist()
 
 g = torch.Generator().manual_seed(0)
-for l, k, spread in [(256, 8, 0.0), (256, 8, 0.05), (256, 8, 0.7), (256, 8, 3.0), (256, 16, 0.7), (256, 32, 0.7), (128, 8, 0.7)]:
+for l, k, spread in [(256, 8, 0.0), (256, 8, 0.7), (256, 8, 3.0), (256, 16, 0.7), (256, 32, 0.7), (128, 8, 0.7), (1024, 8, 0.7), (1024, 8, 3.0), (1536, 8, 0.7), (1536, 8, 3.0),
+                     (1536, 16, 3.0), (4096, 8, 3.0), (16384, 8, 3.0)]:
     c = torch.randn(1, k, 64, generator=g) * 2
     which = torch.randint(0, k, (1, l), generator=g)
     x = torch.gather(c, 1, which[..., None].expand(-1, -1, 64)) + torch.randn(1, l, 64, generator=g) * spread
