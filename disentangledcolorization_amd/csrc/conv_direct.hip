@@ -114,7 +114,10 @@ int launch_conv_c1(const float* d_gray, const float* d_w, const float* d_bias, c
     if (c_out % 16 || out.c % (out.q_off ? 32 : 16) || out.c < c_out) { set_error("conv_c1: c_out %d into a %d-channel act", c_out, out.c); return DISCO_ESHAPE; }
     const long hw = (long)out.h * out.w;
     // few fat workgroups per (image, block): the 192-float parameter staging + barrier is paid once per workgroup
-    dim3 grid((unsigned)std::min<long>((2 * hw + 255) / 256, 64), (unsigned)(out.n * (out.c / 16)));
+    // ... unless that leaves CUs idle (one image): then more, thinner workgroups, up to one pixel pair per thread - a thread's loop iterations
+    // are dependent load -> compute -> store round trips, 8 of them in a row at one 256 x 256 image (21 us a launch)
+    const long per_block = std::max<long>(64, cdiv(8 * num_cus_current(), out.n * (out.c / 16)));
+    dim3 grid((unsigned)std::min<long>((2 * hw + 255) / 256, per_block), (unsigned)(out.n * (out.c / 16)));
     hipLaunchKernelGGL(conv_c1_kernel, grid, dim3(256), 0, s, d_gray, d_w, d_bias, d_bn_scale, d_bn_shift, out.p, (long)out.plane,
                        (long)out.q_off, out.sexp, sat, out.n, out.h, out.w, c_out, out.c, act, slope, out.q_kind);
     DISCO_LAUNCH_CHECK("conv_c1_kernel");

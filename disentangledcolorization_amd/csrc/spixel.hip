@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ t
 // uniform over the workgroup: their addresses depend on blockIdx only, so they arrive through the scalar cache into SGPRs
 // (s_load_dwordx16) instead of 36 sixteen-byte vector loads per pixel and 16-channel block - the pixel-per-thread kernel above is
 // bound by exactly those (a row of 64 pixels spans 4 cells).  Same products and the same slot order as above.
+// TOK_LDS (round 5, grids that do not fill the GPU): the nine token rows are fetched ONCE, with one vector load per thread, into LDS and read
+// from there as broadcasts.  The scalar loads of the other variant are issued trip by trip (576 floats do not fit the 102 SGPRs), so a
+// workgroup alone on its CU sits out eight scalar-cache round trips one after the other: 38 us for the 256 cells of one 256 x 256 image.
+template <bool TOK_LDS>
 __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restrict__ tok, const float* __restrict__ prob, int prob_rep,
                                                           f16* out_act, long out_plane, long q_off, int sexp, unsigned int* sat_out,
                                                           int c, int hs, int ws) {
@@ -91,6 +95,14 @@ __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restric
         const bool inside = ty >= 0 && ty < hs && tx >= 0 && tx < ws;               // uniform over the workgroup
         pw[s] = inside ? pr[s * HW] : 0.f;
         trow[s] = tok + ((long)img * L + (inside ? ty * ws + tx : cy * ws + cx)) * c;
+    }
+    __shared__ __attribute__((aligned(16))) float s_tok[TOK_LDS ? 9 * 64 : 4];
+    if (TOK_LDS) {
+        for (int u = threadIdx.x; u < 9 * (c >> 2); u += 256) {
+            const int sidx = u / (c >> 2), c4 = (u - sidx * (c >> 2)) * 4;
+            *reinterpret_cast<float4*>(s_tok + sidx * 64 + c4) = *reinterpret_cast<const float4*>(trow[sidx] + c4);
+        }
+        __syncthreads();
     }
     unsigned sat = 0;
     // packed arithmetic written out by hand (this file is built without the SLP vectoriser, see build.py): the nine weights as real
@@ -124,7 +136,8 @@ __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restric
         for (int s = 0; s < 9; ++s) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x2_t tv = {trow[s][hb * 8 + 2 * j], trow[s][hb * 8 + 2 * j + 1]};
+                const f32x2_t tv = TOK_LDS ? f32x2_t{s_tok[s * 64 + hb * 8 + 2 * j], s_tok[s * 64 + hb * 8 + 2 * j + 1]}
+                                           : f32x2_t{trow[s][hb * 8 + 2 * j], trow[s][hb * 8 + 2 * j + 1]};
                 acc2[j] = s == 0 ? mul_rn2(tv, pw2[0]) : add_rn2(acc2[j], mul_rn2(tv, pw2[s]));
             }
         }
@@ -235,8 +248,13 @@ int launch_upfeat(const float* tok, int tok_layout, const float* prob, int prob_
         if (out_act && (out_act->c != c || (out_act->q_off && c % 32))) { set_error("upfeat: act of %d channels for c=%d", out_act->c, c); return DISCO_ESHAPE; }
         const long total = (long)n * h * sp * w * sp;
         if (sp == 16 && tok_layout && out_act && !out_nchw) {
-            hipLaunchKernelGGL(upfeat_cell_kernel, dim3(n * h * w), dim3(256), 0, s, tok, prob, prob_rep, out_act->p, (long)out_act->plane,
-                               (long)out_act->q_off, out_act->sexp, sat, c, h, w);
+            // up to four workgroups per CU the launch is a latency matter: token rows through LDS (same arithmetic, same results)
+            if (c <= 64 && (long)n * h * w <= 4L * num_cus_current())
+                hipLaunchKernelGGL(upfeat_cell_kernel<true>, dim3(n * h * w), dim3(256), 0, s, tok, prob, prob_rep, out_act->p, (long)out_act->plane,
+                                   (long)out_act->q_off, out_act->sexp, sat, c, h, w);
+            else
+                hipLaunchKernelGGL(upfeat_cell_kernel<false>, dim3(n * h * w), dim3(256), 0, s, tok, prob, prob_rep, out_act->p, (long)out_act->plane,
+                                   (long)out_act->q_off, out_act->sexp, sat, c, h, w);
             DISCO_LAUNCH_CHECK("upfeat_cell_kernel");
             return DISCO_OK;
         }

@@ -559,9 +559,10 @@ __global__ __launch_bounds__(256) void encoder_tail_kernel(const TailArgs g) {
 // products and the P V accumulation run as packed fp32 FMAs (v_pk_fma_f32); exponentials are v_exp_f32 (__expf:
 // relative error ~1e-6 on arguments <= 0, far inside the 2e-5 encoder tolerance).
 constexpr int KCH = 256;
-constexpr int QT = 4;      // queries per thread
 constexpr int KP = 16;     // key partitions (lanes) per query group
-constexpr int QPB = (256 / KP) * QT;   // 64 queries per block
+// QT: queries per thread (a block covers (256 / KP) QT of them).  4 for throughput; 1 when the grid would not fill the GPU (one image of
+// 256 tokens: 32 workgroups at QT = 4) - a query's arithmetic does not depend on how many neighbours share its thread: same results
+template <int QT>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, float* out, int L) {
     // halves of a key / value in separate arrays: the 16 partitions of a wave read 16 consecutive float4 (256 contiguous
@@ -569,6 +570,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     __shared__ float4 sk[2][KCH];
     __shared__ float4 sv[2][KCH];
     const int qb = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
+    constexpr int QPB = (256 / KP) * QT;
     const int part = threadIdx.x & (KP - 1);
     const int q0i = qb * QPB + (threadIdx.x / KP) * QT;
     const size_t base = (size_t)img * L * 64 + head * 8;
@@ -1559,8 +1561,12 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
             if (rc) return rc;
         }
         if (dbg) (*dbg)(qkv, (size_t)3 * T * 64 * 4);
-        hipLaunchKernelGGL(attention_kernel, dim3(cdiv(l, QPB), N_HEAD, n), dim3(256), 0, s, qkv, qkv + (size_t)T * 64,
-                           qkv + (size_t)2 * T * 64, att, l);
+        if ((long)cdiv(l, 64) * N_HEAD * n < num_cus_current())
+            hipLaunchKernelGGL(attention_kernel<1>, dim3(cdiv(l, 16), N_HEAD, n), dim3(256), 0, s, qkv, qkv + (size_t)T * 64,
+                               qkv + (size_t)2 * T * 64, att, l);
+        else
+            hipLaunchKernelGGL(attention_kernel<4>, dim3(cdiv(l, 64), N_HEAD, n), dim3(256), 0, s, qkv, qkv + (size_t)T * 64,
+                               qkv + (size_t)2 * T * 64, att, l);
         DISCO_LAUNCH_CHECK("attention_kernel");
         if (dbg) (*dbg)(att, (size_t)T * 64 * 4);
         // x1 = LN1(x + att Wo^T + bo); out = LN2(x1 + relu(x1 W1^T + b1) W2^T + b2): one fused launch
