@@ -36,7 +36,7 @@ sys.path.insert(0, REPO)
 GFLOP_PER_IMAGE = 255.470          # algorithmic work of one 256x256 image
 FP16_MFMA_PEAK = 2.5e15            # dense, MI355X_MICROARCH.md
 FP32_MFMA_PEAK = 157.3e12
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"
 
 
 def cpu_baseline(sd, seconds_budget=30.0, all_cores=False):
@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["mx6", "mx8", "x2q", "mx8all", "f16x3"],
                     help="conv arithmetic per stack (disentangledcolorization_amd/model.py); default: the package default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-image latency measurement (the PMC passes of tools/collect_profiles.sh count conv launches by position)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra timed lines for BASELINE configs 4 and 5a (reported next to the headline, never as `value`)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 (default): successive steps alternate between two HIP streams, each a full-size forward, the second "
                                                               "staggered behind the first (runner.py), everything joined by the synchronize() that closes the timed region; "
@@ -413,7 +414,7 @@ def main():
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
             }
             out["stage_ms_per_step"] = {k: round(v / prof_steps, 3) for k, v in stage_ms.items()}        # of the profiled single-stream forwards
-            if world == 1:
+            if world == 1 and not args.no_latency:
                 # the reference's own call pattern is one image per forward (main/colorizer/inference.py:93-109): its latency, NOT `value`
                 out["single_image_latency_ms"] = single_image_latency(model, gray[:1].contiguous(), ab[:1].contiguous(), sync)
             if world == 1 and not args.no_other_configs and args.batch == 64 and args.size == 256 and args.global_batch == 0:

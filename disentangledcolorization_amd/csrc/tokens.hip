@@ -1527,9 +1527,11 @@ int launch_encoder_pack(const float* raw, float* packed, hipStream_t s) {
 }
 
 // up to this many token rows the stack runs its layers' tails on 16-row tiles (encoder_tail_kernel); beyond, on 64-row tiles
-// (post_attention_kernel + token_gemm_kernel<QKV>).  Same results either way; DISCO_ENCODER_TAIL_ROWS overrides (0: never)
+// (post_attention_kernel + token_gemm_kernel<QKV>).  Same results either way.  Measured at 256 ... 16 384 rows the 16-row kernel is the
+// faster one everywhere (one image 36 -> 16 us per layer, 64 images 0.58 -> 0.54 ms per stack: profiles/r05_encoder_tail_ab.txt), so the
+// default is "always"; DISCO_ENCODER_TAIL_ROWS overrides (0: never - the A/B switch)
 static int encoder_tail_max_rows() {
-    static const int v = [] { const char* e = std::getenv("DISCO_ENCODER_TAIL_ROWS"); return e ? atoi(e) : 4096; }();
+    static const int v = [] { const char* e = std::getenv("DISCO_ENCODER_TAIL_ROWS"); return e ? atoi(e) : 0x7fffffff; }();
     return v;
 }
 
@@ -1561,6 +1563,7 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
             if (rc) return rc;
         }
         if (dbg) (*dbg)(qkv, (size_t)3 * T * 64 * 4);
+        // (beyond one workgroup per CU the two forms run the same: n = 2 ... 16 images measured with the threshold at 1x, 2x, 5x, 9x the CU count)
         if ((long)cdiv(l, 64) * N_HEAD * n < num_cus_current())
             hipLaunchKernelGGL(attention_kernel<1>, dim3(cdiv(l, 16), N_HEAD, n), dim3(256), 0, s, qkv, qkv + (size_t)T * 64,
                                qkv + (size_t)2 * T * 64, att, l);

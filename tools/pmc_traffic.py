@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """HBM bytes per conv launch from two rocprofv3 PMC passes (run on the GPU box, see the recipe below) ->
-profiles/r04_pmc_traffic.json, which bench.py reports as roofline.traffic (it carries the hash of the conv sources it was measured
+profiles/r05_pmc_traffic.json, which bench.py reports as roofline.traffic (it carries the hash of the conv sources it was measured
 on; bench.py reports null when the sources have changed since).
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o fetch --output-format csv -- \
-        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --pipeline 0 --micro 1
+        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-latency --no-other-configs --pipeline 0 --micro 1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o write --output-format csv -- \
-        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
+        python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-other-configs --pipeline 0 --micro 1
     python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/pmc_traffic.json
 
 Counters are collected in their own passes (--kernel-trace only).  Units and the gfx950 correction follow
@@ -54,7 +54,7 @@ def main():
     write, nw, write_l = total(write_dir, "WRITE_SIZE")
     with open(os.path.splitext(out)[0] + "_layers.txt", "w") as fh:
         fh.write("# HBM-side MB per conv launch by position in the forward (reads = FETCH_SIZE x 2 KiB, writes = WRITE_SIZE KiB); the positions are the\n"
-                 "# rows of profiles/r04_final_layers.txt (0-17 SpixelNet, 18-44 ColorProbNet, 45-68 HourGlass2)\n")
+                 "# rows of profiles/r05_final_layers.txt (0-17 SpixelNet, 18-44 ColorProbNet, 45-68 HourGlass2)\n")
         for i in range(PER_FORWARD):
             fh.write("%3d  read %8.1f MB  write %8.1f MB\n" % (i, fetch_l[i] * 2048 / 1e6, write_l[i] * 1024 / 1e6))
     if not nf or nf != nw:
@@ -66,7 +66,7 @@ def main():
     json.dump({
         "source_hash": bench.source_hash(),
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around "
-                  "`python bench.py --steps 1 --warmup 1 --no-alt --pipeline 0 --micro 1` (tools/pmc_traffic.py)",
+                  "`python bench.py --steps 1 --warmup 1 --no-alt --no-latency --no-other-configs --pipeline 0 --micro 1` (tools/pmc_traffic.py)",
         "unit_note": "counter unit is KiB; per MI355X_MICROARCH.md the gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of "
                      "wide coalesced streaming reads, so reads are doubled below; WRITE_SIZE is uncalibrated and taken as is",
         "conv_launches (conv3x3_mx_kernel, all arithmetics; 64-image forwards only: the calibration pass is dropped)": nf, "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
