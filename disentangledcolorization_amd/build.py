@@ -17,7 +17,7 @@ SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.h
 # per-file extra flags
 # -fno-slp-vectorize: the SLP vectoriser forms v_pk_*_f32 with op_sel (the low result half takes the HIGH dword of a source), and on this part
 # that form returns a wrong low half while other waves of the CU issue MFMAs (tools/pk_fault_repro.hip, profiles/r03_pk_fma_op_sel_fault.txt;
-# DESIGN.md section 4).  The conv kernels and tokens.hip contain no such instruction (tools/audit_op_sel.py checks every file).
+# HISTORY.md section 4).  The conv kernels and tokens.hip contain no such instruction (tools/audit_op_sel.py checks every file).
 EXTRA_FLAGS = {"pool.hip": ["-fno-slp-vectorize"], "spixel.hip": ["-fno-slp-vectorize"], "color.hip": ["-fno-slp-vectorize"]}
 HEADERS = ["common.h", "conv_mx_kernel.h", os.path.join("..", "..", "include", "disco_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

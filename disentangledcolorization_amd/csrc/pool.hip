@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolArgs a) {
         // LDS-loaded probabilities with op_sel, and `v_pk_fma_f32 ... op_sel:[0,1,0]` (low result half from the HIGH dword of a source)
         // returns a wrong low half while other waves of the CU issue MFMAs - tools/pk_fault_repro.hip shows it with registers only;
         // here it meant a missing contribution of ~0.1-1 % in a handful of tokens about once per 12 concurrent small forwards
-        // (profiles/r03_stagger_probe.txt, r03_pk_fma_op_sel_fault.txt; tools/audit_op_sel.py guards every file).
+        // (HISTORY.md section 4, profiles/r03_stagger_probe.txt, r03_pk_fma_op_sel_fault.txt; tools/audit_op_sel.py guards every file).
         // The 64 act channels of a 16x16 cell, 16 bytes per load: thread = (8-channel group q = tid & 7, pixel subset r = tid >> 3),
         // pixel p = 32 i + r (i = 0..7): a wave reads 8 consecutive pixels x 64 channels = 4 planes x 256 contiguous bytes per
         // load instruction (the scalar path below moves 2 bytes per lane: 8x the instructions, address-unit bound).  Each thread

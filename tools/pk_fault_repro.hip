@@ -1,4 +1,4 @@
-// Stand-alone reproducer of the packed-fp32 fault of DESIGN.md section 4 (found through pool_partial_kernel, round 3).
+// Stand-alone reproducer of the packed-fp32 fault of HISTORY.md section 4 (found through pool_partial_kernel, round 3).
 //   hipcc --offload-arch=gfx950 -O3 tools/pk_fault_repro.hip -o /tmp/pk_repro
 //   /tmp/pk_repro [bg_streams=7] [rounds=40] [bg_kind=0|1] [bg_lds_kib=100]
 // Part 1 (registers only): a kernel runs the same multiply-add recurrences as v_pk_fma_f32 - one operand-selection form per group of

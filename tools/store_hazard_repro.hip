@@ -1,4 +1,4 @@
-// Does a buffer store read its data registers at issue, or later?  (Background: DESIGN.md section 4, "a store-data hazard".)
+// Does a buffer store read its data registers at issue, or later?  (Background: HISTORY.md section 4, "a store-data hazard".)
 // Each wave queues NLOAD LDS-DMA loads (cache-missing addresses), then issues ONE buffer_store_dwordx4 and overwrites the store's
 // data registers with a poison value WAIT instructions later.  The output is then scanned for poison.
 //   hipcc --offload-arch=gfx950 -O3 tools/store_hazard_repro.hip -o /tmp/shr && /tmp/shr
