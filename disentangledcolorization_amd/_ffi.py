@@ -108,6 +108,8 @@ SIGNATURES = {
     "disco_op_encoder_weight_floats": (_SZ, []),
     "disco_op_encoder_stack": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
     "disco_op_kmeans_anchors": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "disco_op_kmeans_workspace_bytes": (_SZ, [_I, _I]),
+    "disco_op_kmeans_anchors_ws": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "disco_op_select_colors": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "disco_op_nearest_bin": (_I, [_P, _P, _I, _I, _P]),
     "disco_op_position_encoding": (_I, [_P, _I, _I, _P]),

@@ -1104,6 +1104,9 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     int32_t* d_assign = (int32_t*)P.raw((size_t)n * L * 4);
     int32_t* d_anchor = (int32_t*)P.raw((size_t)n * K * 4);
     int32_t* d_info = (int32_t*)P.raw((size_t)n * 2 * 4);
+    // scratch of the several-workgroups-per-image k-means (images of more than 512 tokens: running member sums, centres, flags)
+    const size_t km_bytes = (test && !c->opt.random_hint) ? kmeans_ws_bytes(n, L) : 0;
+    void* km_ws = km_bytes ? P.raw(km_bytes) : nullptr;
     if (!dry && P.ok()) {
         if (c->opt.random_hint) {
             if (!a->h_hint_pos) { set_error("random_hint context needs h_hint_pos"); P.rc = DISCO_EINVAL; }
@@ -1119,11 +1122,12 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
                 if (P.ok() && mf) P.rc = staged_h2d(c, d_fb, a->h_fallback_rows, (size_t)n * mf * 4, s);
                 // inference clusters the wild-path tokens (model.py:140-141); the validation forward clusters the pooled
                 // GT colours (N,2,h,w) (model.py:169-171)
-                if (P.ok()) P.rc = test ? launch_kmeans_anchors(enc, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s)
+                if (P.ok()) P.rc = test ? launch_kmeans_anchors(enc, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s, 64, 0, km_ws, km_bytes)
                                         : launch_kmeans_anchors(spix_ab, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s, 2, 1);
             }
         }
     }
+    if (km_ws) P.drop(km_ws);
     P.mark("anchors");
 
     // ---- a10/a11 anchor colours + labels (model.py:142-168) ----------------------------------------------------
@@ -2057,10 +2061,19 @@ int disco_op_encoder_stack(const float* d_x, const float* d_pos, const float* d_
 int disco_op_kmeans_anchors(const float* d_x, const float* d_sizes, const int32_t* d_init_idx, const int32_t* d_fallback_rows,
                             int max_fallback, int32_t* d_assign, int32_t* d_anchor, float* d_hint_mask, int32_t* d_info, int n,
                             int l, int k, int d, int channel_major, void* stream) {
+    return disco_op_kmeans_anchors_ws(d_x, d_sizes, d_init_idx, d_fallback_rows, max_fallback, d_assign, d_anchor, d_hint_mask, d_info, n, l, k, d,
+                                      channel_major, nullptr, 0, stream);
+}
+
+size_t disco_op_kmeans_workspace_bytes(int n, int l) { return (n > 0 && l > 0) ? kmeans_ws_bytes(n, l) : 0; }
+
+int disco_op_kmeans_anchors_ws(const float* d_x, const float* d_sizes, const int32_t* d_init_idx, const int32_t* d_fallback_rows,
+                               int max_fallback, int32_t* d_assign, int32_t* d_anchor, float* d_hint_mask, int32_t* d_info, int n,
+                               int l, int k, int d, int channel_major, void* d_ws, size_t ws_bytes, void* stream) {
     if (!positive("kmeans_anchors", {n, l, k, d})) return DISCO_ESHAPE;
     if (!d_x || !d_sizes || !d_init_idx || !d_assign || !d_anchor || !d_hint_mask) { set_error("null argument"); return DISCO_EINVAL; }
     return launch_kmeans_anchors(d_x, d_sizes, d_init_idx, d_fallback_rows, max_fallback, d_assign, d_anchor, d_hint_mask, d_info,
-                                 n, l, k, (hipStream_t)stream, d, channel_major);
+                                 n, l, k, (hipStream_t)stream, d, channel_major, d_ws, ws_bytes);
 }
 
 static int gamut_device(float** out) {

@@ -398,7 +398,9 @@ int launch_decode_annealed(const float* logit_nchw, const float* q_to_ab, float*
 int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labels, int n, int l, hipStream_t s);
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,
-                          int l, int k, hipStream_t s, int d = 64, int channel_major = 0);   // x: (n,l,d) or (n,d,l)
+                          int l, int k, hipStream_t s, int d = 64, int channel_major = 0,   // x: (n,l,d) or (n,d,l)
+                          void* ws = nullptr, size_t ws_bytes = 0);   // ws: kmeans_ws_bytes(n, l) of scratch lets images of more than 512 tokens run on several workgroups
+size_t kmeans_ws_bytes(int n, int l);
 int launch_hint_mask_from_pos(const int32_t* pos, float* hint_mask, int n, int l, int k, hipStream_t s);
 // hint[t] = W[:, :64] src + m W[:, 64+label] + m W[:, 377]           (labels, W (64,378))
 //         = W[:, :64] src + m a W[:, 64] + m b W[:, 65] + m W[:, 66]  (hint2regress: colors (n,2,l), W (64,67))

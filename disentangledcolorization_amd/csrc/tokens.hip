@@ -1248,6 +1248,245 @@ __global__ __launch_bounds__(1024) void kmeans_tiled_kernel(const float* __restr
     }
 }
 
+// ---- k-means + anchors for more than 512 points on SEVERAL workgroups per image (round 5) ----------------------------------------------
+// kmeans_tiled_kernel walks an image's tiles one after the other on one workgroup: 40 us per Lloyd pass at 1 536 tokens, 470 at 16 384 -
+// 13 % of a --no_resize forward.  Here workgroup g of G keeps tiles 2g and 2g + 1 (512 points) RESIDENT in LDS for the whole kernel, all
+// workgroups assign their points at once, and the member sums - one sequential chain per (cluster, feature) in ascending point order: the
+// property that makes the result independent of everything but the data - travel down the workgroups as a pipeline: g waits for g - 1's
+// running sums (2 KB through global memory + a flag), adds its own members in order, hands on; the last workgroup divides, measures the
+// shift, decides, and publishes the new centres, which everybody picks up.  Same additions in the same order as the one-workgroup
+// kernels: bit-identical assignments, pass counts and events (tests/test_gpu_ops.py::test_kmeans_small_kernel_equals_the_general_one
+// runs it against the general kernel).  ~G x 2.5 us + 5 us per pass instead of G x 13.
+// Measured (profiles/r05_kmeans_latency_ab.txt): a hop costs ~8 us whatever the fences (agent-scope release / acquire, or - as now -
+// system-scope relaxed accesses past the non-coherent L2s): a store-acknowledge, a flag and a load round trip through memory each.
+// 1 536 tokens 40 -> 29 us per pass, 16 384 tokens 472 -> 294.  (What would be faster: workers that only assign + ONE reducer workgroup
+// that streams the members' rows from L2 in order - DESIGN.md section 7.)
+// The workgroups of an image spin on each other's flags, so they must all be resident: the launcher takes this kernel only when
+// n x G <= a quarter of the CUs, and every spin is bounded by a wall-clock deadline (2 s from kernel entry); a workgroup that runs into
+// it TRAPS - the launch fails loudly (hipErrorLaunchFailure), never returns a wrong clustering.
+constexpr int KC_MAXG = 64;
+struct KmCoopCtl { int flagS[KC_MAXG]; int flagC; int stop_pass; int err; int pad; };
+constexpr size_t KC_IMG_BYTES = ((size_t)(2 * KMAX * 64 + KMAX) * 4 + sizeof(KmCoopCtl) + 255) & ~(size_t)255;
+__global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
+                                                           const int32_t* __restrict__ init_idx, const int32_t* __restrict__ fallback,
+                                                           int max_fallback, int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
+                                                           int32_t* info, int L, int K, int G, unsigned char* scratch) {
+    extern __shared__ float dyn[];          // 2 x [256][KS_PITCH]: this workgroup's two tiles, resident
+    __shared__ __attribute__((aligned(16))) float cen[2][KMAX * KS_CP];
+    __shared__ int asg[2][KS_MAXL];
+    __shared__ int cnt[KMAX];
+    __shared__ float shift_part[KMAX];
+    __shared__ int s_anchor[KMAX];
+    __shared__ int s_events, s_any_empty, s_bcast;
+    const int img = blockIdx.x / G, g = blockIdx.x - img * G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool last_wg = g == G - 1;
+    const float* X = x + (size_t)img * L * 64;
+    int32_t* assign = assign_out + (size_t)img * L;
+    unsigned char* sc = scratch + (size_t)img * KC_IMG_BYTES;
+    float* gS = reinterpret_cast<float*>(sc);                    // running member sums [K][64]
+    int* gM = reinterpret_cast<int*>(gS + KMAX * 64);            // running member counts [K]
+    float* gC = reinterpret_cast<float*>(gM + KMAX);             // the pass's new centres [K][64]
+    KmCoopCtl* ctl = reinterpret_cast<KmCoopCtl*>(gC + KMAX * 64);
+    // Everything the workgroups exchange goes through SYSTEM-scope relaxed accesses (stores written through, loads past the non-coherent
+    // caches: the XCDs' L2s do not see each other's lines): no cache-wide write-back / invalidate per hop, which an agent-scope
+    // release / acquire pair costs (measured: 8 us per hop with fences, ~3 with these).  Order: data stores, s_waitcnt vmcnt(0) (a store
+    // counts until it is acknowledged), workgroup barrier, flag store; the reader polls the flag, then loads the data.
+    auto st_f = [](float* ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto st_i = [](int* ptr, int v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto ld_f = [](const float* ptr) -> float { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto ld_i = [](const int* ptr) -> int { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + 200000000ull;     // 100 MHz counter: 2 s
+    // one lane waits until *flag >= want (agent-scope acquire), then the workgroup passes a barrier; false: deadline passed
+    auto wait_flag = [&](int* flag, int want) -> bool {
+        if (tid == 0) {
+            int ok = 1;
+            while (ld_i(flag) < want) {
+                if (__builtin_amdgcn_s_memrealtime() > deadline) { ok = 0; __builtin_trap(); }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_bcast = ok;
+        }
+        __syncthreads();
+        const int ok = s_bcast;
+        __syncthreads();
+        return ok != 0;
+    };
+    const int tile0 = 2 * g, ntl = min(2, ((L + 255) >> 8) - tile0);
+    for (int u = tid; u < ntl * 256 * 16; u += 1024) {          // float4 index: tile, row, 4 columns
+        const int tl = u >> 12, r = (u >> 4) & 255, c4 = (u & 15) * 4;
+        const int pt = (tile0 + tl) * 256 + r;
+        const float4 v = pt < L ? *reinterpret_cast<const float4*>(X + (size_t)pt * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = dyn + tl * (256 * KS_PITCH) + r * KS_PITCH + c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int u = tid; u < K * 64; u += 1024) cen[0][(u >> 6) * KS_CP + (u & 63)] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
+    if (tid == 0) { s_events = 0; s_any_empty = 0; }
+    __syncthreads();
+    const int t = tid >> 2, q = tid & 3;
+    const int KQ = (K + 3) >> 2;
+    int cur = 0, passes = 0;
+    bool failed = false;
+    auto shift_of = [&](float dlane) -> float {
+        float qv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) { const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dlane), c)); qv = __builtin_fmaf(dc, dc, qv); }
+        return sqrtf(qv);
+    };
+    while (true) {
+        const int nxt = cur ^ 1, p = passes + 1;
+        // ---- assign this workgroup's tiles ----
+        for (int tl = 0; tl < ntl; ++tl) {
+            const int base = (tile0 + tl) << 8, rows = min(256, L - base);
+            const float* xs = dyn + tl * (256 * KS_PITCH);
+            const int j0 = q * KQ, nq = min(K, (q + 1) * KQ) - j0;
+            float d[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) d[jj] = 0.f;
+            const float* rp = xs + (t < rows ? t : 0) * KS_PITCH;
+#pragma unroll 4
+            for (int c4 = 0; c4 < 16; ++c4) {
+                const float r0 = rp[4 * c4], r1 = rp[4 * c4 + 1], r2 = rp[4 * c4 + 2], r3 = rp[4 * c4 + 3];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    if (jj >= nq) break;
+                    const float4 cv = *reinterpret_cast<const float4*>(cen[cur] + (j0 + jj) * KS_CP + 4 * c4);
+                    float df = r0 - cv.x; d[jj] = fmaf(df, df, d[jj]);
+                    df = r1 - cv.y; d[jj] = fmaf(df, df, d[jj]);
+                    df = r2 - cv.z; d[jj] = fmaf(df, df, d[jj]);
+                    df = r3 - cv.w; d[jj] = fmaf(df, df, d[jj]);
+                }
+            }
+            float best = INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                if (jj < nq && d[jj] < best) { best = d[jj]; bi = j0 + jj; }
+#pragma unroll
+            for (int sft = 1; sft < 4; sft <<= 1) {
+                const float od = __shfl_xor(best, sft); const int oj = __shfl_xor(bi, sft);
+                if (od < best || (od == best && oj < bi)) { best = od; bi = oj; }
+            }
+            if (q == 0 && t < rows) { asg[tl][t] = bi; st_i(assign + base + t, bi); }
+        }
+        __syncthreads();
+        // ---- the member sums: take over from workgroup g - 1, add this workgroup's members in ascending order, hand on ----
+        if (g > 0 && !wait_flag(&ctl->flagS[g - 1], p)) failed = true;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = wave + 16 * h;
+            if (j >= K) break;
+            float sum = g > 0 ? ld_f(gS + j * 64 + lane) : 0.f;
+            int m = g > 0 ? ld_i(gM + j) : 0;
+            for (int tl = 0; tl < ntl; ++tl) {
+                const int rows = min(256, L - ((tile0 + tl) << 8));
+                const float* xs = dyn + tl * (256 * KS_PITCH);
+                unsigned long long mk[4];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int tt = bb * 64 + lane;
+                    const int av = tt < rows ? asg[tl][tt] : -1;
+                    mk[bb] = __ballot(av == j);
+                    m += __popcll(mk[bb]);
+                }
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    unsigned long long mask = mk[bb];
+                    while (mask) {
+                        float v[8]; bool ok[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            ok[u] = mask != 0ull;
+                            const int tt = bb * 64 + (ok[u] ? __builtin_ctzll(mask) : 0);
+                            mask &= mask - 1ull;
+                            v[u] = xs[tt * KS_PITCH + lane];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (ok[u]) sum += v[u];
+                    }
+                }
+            }
+            if (!last_wg) { st_f(gS + j * 64 + lane, sum); if (lane == 0) st_i(gM + j, m); }
+            else if (m > 0) {
+                const float c = sum / (float)m;
+                cen[nxt][j * KS_CP + lane] = c;
+                st_f(gC + j * 64 + lane, c);
+                const float sh = shift_of(c - cen[cur][j * KS_CP + lane]);
+                if (lane == 0) { shift_part[j] = sh; cnt[j] = m; }
+            } else if (lane == 0) { cnt[j] = 0; s_any_empty = 1; }
+        }
+        // every wave's stores (running sums, centres, this pass's assignments) have reached L2 (vmcnt counts a store until it is written
+        // there); the agent-scope release below - one lane - then writes the workgroup's dirty lines back for the other XCDs.  (A
+        // __threadfence() by all 1 024 threads did the same sixteen times over: the hop cost 8 us.)
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+        __syncthreads();
+        int stop = 0;
+        if (!last_wg) {
+            if (tid == 0) st_i(&ctl->flagS[g], p);
+            if (!wait_flag(&ctl->flagC, p)) failed = true;
+            for (int u = tid; u < K * 64; u += 1024) cen[nxt][(u >> 6) * KS_CP + (u & 63)] = ld_f(gC + u);
+            stop = ld_i(&ctl->stop_pass) == p;
+            __syncthreads();
+        } else {
+            if (s_any_empty) {
+                if (tid == 0) {
+                    for (int j = 0; j < K; ++j)
+                        if (cnt[j] == 0) {
+                            const int e = s_events++;
+                            const int r = (fallback && e < max_fallback) ? fallback[(size_t)img * max_fallback + e] : 0;
+                            cnt[j] = -(r + 1);
+                        }
+                }
+                __syncthreads();
+                for (int j = wave; j < K; j += 16)
+                    if (cnt[j] < 0) {
+                        const float c = X[(size_t)(-cnt[j] - 1) * 64 + lane];
+                        cen[nxt][j * KS_CP + lane] = c;
+                        st_f(gC + j * 64 + lane, c);
+                        const float sh = shift_of(c - cen[cur][j * KS_CP + lane]);
+                        if (lane == 0) shift_part[j] = sh;
+                    }
+                __syncthreads();
+                if (tid == 0) s_any_empty = 0;
+            }
+            float sh = 0.f;
+            for (int j = 0; j < K; ++j) sh += shift_part[j];
+            stop = (sh * sh < 1e-4f) || p >= 20;
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the centres of the rare fallback path too
+            __syncthreads();
+            if (tid == 0) {
+                if (stop) { st_i(&ctl->stop_pass, p); __builtin_amdgcn_s_waitcnt(0x0f70); }
+                st_i(&ctl->flagC, p);
+            }
+        }
+        ++passes;
+        cur = nxt;
+        if (stop || failed) break;
+    }
+    if (!last_wg) return;
+    // ---- the last workgroup has seen every other one's assignments (the flag chain): anchors and the hint mask of the image ----
+    const float* sz = sizes + (size_t)img * L;
+    float* hm = hint_mask + (size_t)img * L;
+    for (int j = wave; j < K; j += 16) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int tt = lane; tt < L; tt += 64) {
+            const float scv = add_rn(ld_i(assign + tt) == j ? 1.f : 0.f, mul_rn(sz[tt], 0.01f));
+            if (scv > bv) { bv = scv; bi = tt; }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { anchor_out[img * K + j] = bi; s_anchor[j] = bi; }
+    }
+    for (int tt = tid; tt < L; tt += 1024) hm[tt] = 0.f;
+    __syncthreads();
+    if (tid == 0) {
+        for (int j = 0; j < K; ++j) hm[s_anchor[j]] += 1.f;
+        if (info) { info[img * 2] = failed ? -1 : passes; info[img * 2 + 1] = s_events; }
+    }
+}
+
 // ---- k-means + anchors, fallback for more than KM_LIST_TOKENS points: one workgroup (256 threads) per image --------
 // The token matrix (L x 64 fp32) is staged once in LDS (row pitch 65 floats: conflict-free row-per-thread reads)
 // when it fits (L <= KM_LDS_TOKENS); larger images (no_resize path) read it from L2 with unconditional,
@@ -1646,9 +1885,11 @@ int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labe
     return DISCO_OK;
 }
 
+size_t kmeans_ws_bytes(int n, int l) { return l > 512 ? (size_t)n * KC_IMG_BYTES : 0; }
+
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,
-                          int l, int k, hipStream_t s, int d, int channel_major) {
+                          int l, int k, hipStream_t s, int d, int channel_major, void* ws, size_t ws_bytes) {
     if (k < 1 || k > KMAX) { set_error("kmeans: K=%d outside [1,%d]", k, KMAX); return DISCO_ESHAPE; }
     if (k > l) { set_error("kmeans: K=%d larger than %d tokens", k, l); return DISCO_ESHAPE; }
     if (d < 1 || d > 64) { set_error("kmeans: %d features outside [1,64]", d); return DISCO_ESHAPE; }
@@ -1672,12 +1913,24 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
     int rc = DISCO_OK;
     // DISCO_KMEANS_V1=1: the general kernel at every size (A/B runs; results are bit-identical)
     static const bool small_ok = [] { const char* e = std::getenv("DISCO_KMEANS_V1"); return !(e && e[0] == '1'); }();
+    static const bool coop_ok = [] { const char* e = std::getenv("DISCO_KMEANS_COOP"); return !(e && e[0] == '0'); }();      // 0: one workgroup per image at every size
     if (small_ok && l <= KS_MAXL && d == 64 && !channel_major) {
         const size_t smem = (size_t)l * KS_PITCH * sizeof(float);
         static std::atomic<int> small_done[DISCO_MAX_DEVICES];
         DISCO_HIP_CHECK(set_dyn_lds_once(small_done, reinterpret_cast<const void*>(kmeans_small_kernel), MAX_SMEM));
         hipLaunchKernelGGL(kmeans_small_kernel, dim3(n), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
                            hint_mask, info, l, k);
+    } else if (small_ok && d == 64 && !channel_major && l > 512 && ws && ws_bytes >= kmeans_ws_bytes(n, l) && cdiv(l, 512) <= KC_MAXG &&
+               (long)n * cdiv(l, 512) <= num_cus_current() / 4 && coop_ok) {
+        // several workgroups per image, all of them resident (they wait for each other): a quarter of the CUs at most, so that the launches
+        // of up to four concurrent forwards (runner.py pipelines two) always fit side by side; the flags start at zero
+        const int G = cdiv(l, 512);
+        DISCO_HIP_CHECK(hipMemsetAsync(ws, 0, kmeans_ws_bytes(n, l), s));
+        const size_t smem = (size_t)2 * 256 * KS_PITCH * sizeof(float);
+        static std::atomic<int> coop_done[DISCO_MAX_DEVICES];
+        DISCO_HIP_CHECK(set_dyn_lds_once(coop_done, reinterpret_cast<const void*>(kmeans_coop_kernel), MAX_SMEM));
+        hipLaunchKernelGGL(kmeans_coop_kernel, dim3(n * G), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
+                           hint_mask, info, l, k, G, static_cast<unsigned char*>(ws));
     } else if (small_ok && d == 64 && !channel_major) {
         const size_t smem = (size_t)2 * 256 * KS_PITCH * sizeof(float);
         static std::atomic<int> tiled_done[DISCO_MAX_DEVICES];

@@ -355,6 +355,16 @@ int disco_op_kmeans_anchors(const float *d_x, const float *d_sizes, const int32_
                             const int32_t *d_fallback_rows, int max_fallback, int32_t *d_assign,
                             int32_t *d_anchor, float *d_hint_mask, int32_t *d_info, int n, int l, int k, int d,
                             int channel_major, void *stream);
+/* ... with caller-owned scratch (round 5): point sets of more than 512 points of 64 row-major features then run on SEVERAL workgroups
+ * per image (ceil(l / 512), all resident: taken while n * ceil(l / 512) fits a quarter of the CUs) - the member sums travel down the
+ * workgroups as a pipeline in ascending point order, so assignments, pass counts and events are those of the one-workgroup form.  A
+ * workgroup that waits longer than 2 s for its predecessor traps: the launch fails (never seen).  Sizes: disco_op_kmeans_workspace_bytes
+ * (0 when the shape does not use scratch). */
+size_t disco_op_kmeans_workspace_bytes(int n, int l);
+int disco_op_kmeans_anchors_ws(const float *d_x, const float *d_sizes, const int32_t *d_init_idx,
+                               const int32_t *d_fallback_rows, int max_fallback, int32_t *d_assign,
+                               int32_t *d_anchor, float *d_hint_mask, int32_t *d_info, int n, int l, int k, int d,
+                               int channel_major, void *d_ws, size_t ws_bytes, void *stream);
 
 /* softmax(313) -> stable top-10 -> colour pick (anchor_gen.py:54-90) and nearest-bin label (basic.py:177-194) */
 int disco_op_select_colors(const float *d_logit_nchw, float *d_colors, int32_t *d_labels, int n, int hw, int t,

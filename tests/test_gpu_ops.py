@@ -279,8 +279,12 @@ def _kmeans_gpu(H, x, sizes, init, fallback, k, d=64, channel_major=0):
     mf = fb.shape[1] if fb is not None else 0
     assign = torch.empty(n, l, dtype=torch.int32, device=H.DEV); anchor = torch.empty(n, k, dtype=torch.int32, device=H.DEV)
     mask = torch.empty(n, l, device=H.DEV); info = torch.empty(n, 2, dtype=torch.int32, device=H.DEV)
-    _ffi.check(_ffi.lib().disco_op_kmeans_anchors(_ffi.ptr(xd), _ffi.ptr(sd_), _ffi.ptr(idx), _ffi.ptr(fb), mf, _ffi.ptr(assign),
-                                                  _ffi.ptr(anchor), _ffi.ptr(mask), _ffi.ptr(info), n, l, k, d, channel_major, H.stream()))
+    # with scratch: images of more than 512 tokens run on several workgroups (kmeans_coop_kernel); DISCO_KMEANS_V1 / _COOP switch paths
+    wsb = _ffi.lib().disco_op_kmeans_workspace_bytes(n, l)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=H.DEV)
+    _ffi.check(_ffi.lib().disco_op_kmeans_anchors_ws(_ffi.ptr(xd), _ffi.ptr(sd_), _ffi.ptr(idx), _ffi.ptr(fb), mf, _ffi.ptr(assign),
+                                                     _ffi.ptr(anchor), _ffi.ptr(mask), _ffi.ptr(info), n, l, k, d, channel_major,
+                                                     _ffi.ptr(ws), wsb, H.stream()))
     torch.cuda.synchronize()
     return assign.cpu().long(), anchor.cpu().long(), mask.cpu(), info.cpu()
 
@@ -378,6 +382,12 @@ def test_kmeans_small_kernel_equals_the_general_one(H, tmp_path):
     env = dict(os.environ, DISCO_KMEANS_V1="1")
     subprocess.run([sys.executable, "-c", _KM_AB % (os.path.dirname(here), here), out], check=True, env=env, cwd=os.path.dirname(here))
     ref = np.load(out)
+    # ... and the one-workgroup tiled kernel (DISCO_KMEANS_COOP=0) against the same reference: in-process the larger sets take kmeans_coop_kernel
+    out2 = str(tmp_path / "tiled.npz")
+    subprocess.run([sys.executable, "-c", _KM_AB % (os.path.dirname(here), here), out2], check=True, env=dict(os.environ, DISCO_KMEANS_COOP="0"),
+                   cwd=os.path.dirname(here))
+    tiled = np.load(out2)
+    assert all(np.array_equal(tiled[k], ref[k]) for k in ref.files)
     some_events = 0
     for case, (x, sizes, init, fallback, k) in enumerate(_km_ab_inputs()):
         a, an, m, info = _kmeans_gpu(H, x, sizes, init, fallback, k)

@@ -14,9 +14,11 @@ def run(x, k, iters=50):
     idx = torch.as_tensor(np.stack([np.random.RandomState(i).choice(l, k, replace=False) for i in range(n)]).astype(np.int32)).to(H.DEV)
     assign = torch.empty(n, l, dtype=torch.int32, device=H.DEV); anchor = torch.empty(n, k, dtype=torch.int32, device=H.DEV)
     mask = torch.empty(n, l, device=H.DEV); info = torch.empty(n, 2, dtype=torch.int32, device=H.DEV)
+    wsb = _ffi.lib().disco_op_kmeans_workspace_bytes(n, l)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=H.DEV)
     def f():
-        _ffi.check(_ffi.lib().disco_op_kmeans_anchors(_ffi.ptr(xd), _ffi.ptr(sizes), _ffi.ptr(idx), None, 0, _ffi.ptr(assign), _ffi.ptr(anchor),
-                                                      _ffi.ptr(mask), _ffi.ptr(info), n, l, k, d, 0, H.stream()))
+        _ffi.check(_ffi.lib().disco_op_kmeans_anchors_ws(_ffi.ptr(xd), _ffi.ptr(sizes), _ffi.ptr(idx), None, 0, _ffi.ptr(assign), _ffi.ptr(anchor),
+                                                         _ffi.ptr(mask), _ffi.ptr(info), n, l, k, d, 0, _ffi.ptr(ws), wsb, H.stream()))
     for _ in range(10): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
