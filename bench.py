@@ -186,7 +186,26 @@ def other_single_gpu_configs(model, sd, precision, sync):
         g8, a8 = synth.synth_inputs(8, 256, 256, seed=5)
         g8, a8 = g8.cuda(), a8.cuda()
         dt = timed(lambda: model(g8, a8, True, 0), 20)
-        out["small_batch_8x256"] = {"workload": "8 x 256x256, K=8", "ms_per_forward": round(dt * 1e3, 3), "images_per_s": round(8 / dt, 1)}
+        out["small_batch_8x256"] = {"workload": "8 x 256x256, K=8, forwards back to back on one stream", "ms_per_forward": round(dt * 1e3, 3), "images_per_s": round(8 / dt, 1)}
+        # ... and issued the way the headline is: successive forwards alternating between two staggered streams (runner.ShardedColorizer.pipeline),
+        # so that one forward's token path / k-means (a few CUs busy) runs under the other's convolutions
+        from disentangledcolorization_amd.runner import ShardedColorizer
+        r8 = ShardedColorizer.from_model(model, micro_batches=1, exact_fallback=False)
+        r8.pipeline = True
+
+        def step8():
+            torch.manual_seed(130)
+            r8.colorize(g8, a8, 8, 0, gather=False)
+        for _ in range(6):
+            np.random.seed(130); step8()
+        r8.wait(); sync()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            np.random.seed(130); step8()
+        r8.wait(); sync()
+        dt = (time.perf_counter() - t0) / 40
+        out["small_batch_8x256_pipelined"] = {"workload": "8 x 256x256, K=8, successive forwards pipelined over 2 HIP streams (the headline's issue mode)",
+                                              "ms_per_forward": round(dt * 1e3, 3), "images_per_s": round(8 / dt, 1)}
     finally:
         model.sync_kmeans_events = keep
     m16 = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, n_clusters=16, enhanced=True,
