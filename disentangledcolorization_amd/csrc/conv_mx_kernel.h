@@ -170,7 +170,13 @@ struct GeoMx {
 // for launches that cannot fill the GPU (one image, the deep layers of small batches): a chunk's whole DMA goes out in one burst TWO chunks
 // ahead, right behind the barrier that frees its buffer; fragment reads run one tap ahead of the MFMAs; the chunk barrier sits inside the
 // last tap of the preceding chunk.  Same chunks, same taps, same MFMAs in the same order per accumulator: results are bit-identical to NB = 2.
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR, bool GENC1 = false, int NB = 2>
+// NJ: images per WEIGHT chunk (throughput loop).  1: a workgroup walks image after image through all chunks, fetching every weight chunk
+// once per image.  4 (round 5, the stride-2 tile): it walks FOUR of its images chunk by chunk - the stages (chunk c, image j), j = 0..3, run
+// back to back on four accumulator sets, the pixel buffers alternate per stage, the weight buffers per chunk - so a weight chunk comes in
+// once per four images.  The stride-2 tile moves 38 KB of pixels + 36 KB of weights per 27 MFMAs of a wave and is bound by that L2->LDS
+// volume (r01_conv_s2d_timeline.txt, r03_lds_dma_rate.txt); with NJ = 4 it moves 38 + 9.  Every accumulator sees the same chunks and taps
+// in the same order: bit-identical to NJ = 1.
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR, bool GENC1 = false, int NB = 2, int NJ = 1>
 __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3_mx_kernel(const ConvMxArgs a) {
     constexpr bool XQ = AR == 1, X3 = AR == 2, Q6 = AR == 3;
     constexpr int QFMT = Q6 ? 2 : MX_QFMT;                // operand format code of the K = 64 MFMA: 0 = fp8 e4m3, 2 = fp6 e2m3
@@ -199,6 +205,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     constexpr int APT = (APW + 8) / 9, WPT = (WPW + 8) / 9;
     constexpr int PAR_OFF = NB * BUF_BYTES;
     static_assert(NB == 2 || NB == 3, "two or three LDS buffers");
+    static_assert(NJ == 1 || (NB == 2 && !GENC1 && AR != 1 && !NSRC2 && NJ * MT * NTW <= 4), "several images per weight chunk: plain one-source chunk sequences, at most 64 accumulator registers");
     constexpr int DUMP_OFF = PAR_OFF + 3 * 32 * NT * 4;       // NB = 3: 1 KiB that absorbs the out-of-range DMA pieces (every wave issues the same number)
     constexpr int DMA_PER_CHUNK = APW + WPW;                  // NB = 3: LDS-DMA instructions per wave and chunk, exactly (the s_waitcnt immediate)
     static_assert(DMA_PER_CHUNK <= 60, "vmcnt is a 6-bit counter");
@@ -414,7 +421,8 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     const unsigned w_tile_b = (unsigned)(by * NT) * (unsigned)nchunks * W_NB, w_nt_b = (unsigned)nchunks * W_NB;
 
     // one ninth (part 0..8) of the DMA of chunk `ck` of image `img` into LDS buffer `buf`; part < 0: all of it
-    auto issue = [&](int img, int ck, int buf, int part) {
+    // (NJ > 1: the weight pieces go to weight buffer `wb` and only if `with_w`; NJ = 1: wb = buf, always)
+    auto issue = [&](int img, int ck, int buf, int part, int wb, bool with_w) {
         int c0 = (ck >> 1) << 5;                       // first channel of the chunk's 32-channel group
         bool isq = ck & 1;
         if (X3) { c0 = ck << 4; isq = false; }         // one chunk per 16 channels: planes = hi / lo
@@ -431,7 +439,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
                            : (unsigned)img * img_b0 + (unsigned)(c0 >> 4) * blk_b0 + (isq ? qo0 : 0u);
         if (XQ && isq) soff = (unsigned)img * (img_b0 >> 1) + (unsigned)(c0 >> 5) * blk_b0 + qo0;
         char* dA = smem + buf * BUF_BYTES;
-        char* dW = dA + A_BYTES;
+        char* dW = smem + (NJ == 1 ? buf : wb) * BUF_BYTES + A_BYTES;
         const bool tail = NSRC2 && AR == 0 && (nchunks & 1) && ck == nchunks - 1;       // 16-channel H-only chunk: plane 0 alone
         if constexpr (NB == 3) {
             // the latency loop: every producer wave issues exactly DMA_PER_CHUNK instructions per chunk (its s_waitcnt counts them); a piece
@@ -481,6 +489,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(dA + piece * 1024), 16, vsel, soff, 0, MX_PIX_AUX);
             }
         }
+        if (NJ > 1 && !with_w) return;
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             if (part >= 0 && i / WPT != part) continue;
@@ -528,6 +537,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     }
     MX_TL(13);                           // parameters staged, offsets computed: the first chunk's DMA goes out
     int buf = 0;
+    int wbuf = 0;                        // NJ > 1: the weight buffer of the chunk being computed (NJ = 1: the pixel buffer's index serves both)
     bool dma_waited = false;
     int l_cbuf = 0;                      // NB = 3: the LDS buffer the consumers compute from
     if constexpr (NB == 3) {
@@ -543,17 +553,17 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
             int l_ibuf = 0, l_img = n, l_ck = 0;
             auto issue_next = [&]() -> bool {
                 if (l_img >= a.n) return false;
-                issue(l_img, l_ck, l_ibuf, -1);
+                issue(l_img, l_ck, l_ibuf, -1, l_ibuf, true);
                 l_ibuf = l_ibuf == NB - 1 ? 0 : l_ibuf + 1;
                 if (++l_ck == nchunks) { l_ck = 0; l_img += img_step; }
                 return true;
             };
             MX_TL(13);
-            issue(n, 0, 0, -2);                                   // the first chunk's weights: nothing to compute for them
+            issue(n, 0, 0, -2, 0, true);                                   // the first chunk's weights: nothing to compute for them
             MX_TL(14);
             compute_voff();
             MX_TL(15);
-            issue(n, 0, 0, -3);
+            issue(n, 0, 0, -3, 0, true);
             l_ibuf = 1;
             if (++l_ck == nchunks) { l_ck = 0; l_img += img_step; }
             MX_TL(14);
@@ -577,19 +587,22 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
         stage_params();                                           // (the consumers: the producers have nothing in flight but DMA pieces, which is what their s_waitcnt counts)
         __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the staged parameters are written
         __builtin_amdgcn_s_setprio(2);                            // the consumers' MFMAs before the producers' address arithmetic
-    } else issue(n, 0, 0, -1);
+    } else issue(n, 0, 0, -1, 0, true);
 
     for (;;) {
     MX_TL(1);                            // tile start
-    f32x16 acc[MT][NTW];
+    f32x16 accs[NJ][MT][NTW];            // one accumulator set per image of the group (NJ = 1: per image)
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int g = 0; g < NJ; ++g)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accs[g][i][j][e] = 0.f;
+    f32x16 (&acc)[MT][NTW] = accs[0];    // (the latency loop's name for its one set)
 
-    const int next_n = n + img_step;
+    const int next_n = n + NJ * img_step;       // the first image of the next group
     // one chunk: wait for its DMA, barrier, then 9 taps with the next chunk's DMA issued in ninths between them.
     // ISQ = false: H chunk, planes = channels 0-15 / 16-31 (fp16); a lane feeds k = 8 kh .. 8 kh + 7 of both planes to two
     //              K = 16 MFMAs.  ISQ = true: Q chunk, planes = a8 / al8; lane half kh reads all 32 bytes of plane kh
@@ -603,20 +616,29 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     // KIND 2 (X3): the f16x3 arithmetic of conv_mfma2.hip on this skeleton - planes = hi / lo of 16 channels, weight tile = w_hi / w_lo
     //              fragments (conv3x3_pack_host's image), three K = 16 MFMAs per tap in conv_mfma2's order (w_lo a_hi, w_hi a_lo,
     //              w_hi a_hi), so results are bit-identical to that kernel's
-    auto chunk = [&](auto kind_tag, int ck) {
+    // NJ > 1: a STAGE = (chunk ck, image J of the group); the next stage is the same chunk of image J + 1 (pixels only) or, behind the
+    // group's last image, the next chunk of image 0 with its weights (into the other weight buffer, which the previous chunk left with its
+    // last stage)
+    auto chunk = [&](auto kind_tag, int ck, auto j_tag) {
         constexpr int KIND = decltype(kind_tag)::value;
+        constexpr int J = decltype(j_tag)::value;
         constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
+        f32x16 (&acc)[MT][NTW] = accs[J];
         MX_TL(2);                        // chunk start
-        if (!(ck == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(ck == 0 && J == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (GENC1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's share of the computed pixel tile has been written
         MX_TL(3);                        // this chunk's DMA has landed (own pieces)
         __builtin_amdgcn_s_barrier();
         MX_TL(ISQ ? 5 : 4);              // barrier passed: taps of an H (4) / Q (5) chunk begin
         const bool more = ck + 1 < nchunks;
-        const int dma_img = more ? n : (next_n < a.n ? next_n : n), dma_ck = more ? ck + 1 : 0;
+        constexpr bool new_chunk = J == NJ - 1;             // the next stage opens a chunk
+        const int dma_img = !new_chunk ? n + (J + 1) * img_step : (more ? n : (next_n < a.n ? next_n : n));
+        const int dma_ck = !new_chunk ? ck : (more ? ck + 1 : 0);
         const char* sA = smem + buf * BUF_BYTES;
-        const char* sW = sA + A_BYTES;
+        const char* sW = smem + (NJ == 1 ? buf : wbuf) * BUF_BYTES + A_BYTES;
         buf ^= 1;
+        const int wnext = wbuf ^ 1;
+        if (NJ > 1 && new_chunk) wbuf = wnext;
         // the tap ORDER is a property of the tile width alone (never of how the tile is split over waves): every instantiation
         // that can serve a given layer shape accumulates in the same order, so a result does not depend on the batch size
         constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
@@ -639,7 +661,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
             const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
             const int tap = ky * 3 + kx;
 #if !(MX_ABL & 1)
-            issue(dma_img, dma_ck, buf, slot);
+            issue(dma_img, dma_ck, buf, slot, wnext, new_chunk);
 #endif
             if (GENC1) {
                 // the next chunk's pixel tile, a third per wave in taps 0, 3 and 6; in the tile's first chunk also the NEXT image's gray tile
@@ -831,21 +853,31 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
             }
             chunk_lat(KQ{}, KH{}, No{}, Yes{});
         }
-    } else if constexpr (X3) {
-        for (int ck = 0; ck < nchunks; ++ck) chunk(K3{}, ck);
-    } else if constexpr (XQ) {
-        for (int ck = 0; ck < nchunks; ck += 5) {
-#pragma unroll 1
-            for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h);     // H, L, H, L: the same code, other weights
-            chunk(KQ{}, ck + 4);
-        }
     } else {
-        for (int ck = 0; ck + 1 < nchunks; ck += 2) {
-            chunk(KH{}, ck);
-            chunk(KQ{}, ck + 1);
-        }
-        if constexpr (NSRC2 && AR == 0) {
-            if (nchunks & 1) chunk(KT{}, nchunks - 1);
+        using J0 = std::integral_constant<int, 0>;
+        // every image of the group through one chunk
+        auto stages = [&](auto kind_tag, int ck) __attribute__((always_inline)) {
+            chunk(kind_tag, ck, J0{});
+            if constexpr (NJ > 1) chunk(kind_tag, ck, std::integral_constant<int, 1>{});
+            if constexpr (NJ > 2) chunk(kind_tag, ck, std::integral_constant<int, 2>{});
+            if constexpr (NJ > 3) chunk(kind_tag, ck, std::integral_constant<int, 3>{});
+        };
+        if constexpr (X3) {
+            for (int ck = 0; ck < nchunks; ++ck) stages(K3{}, ck);
+        } else if constexpr (XQ) {
+            for (int ck = 0; ck < nchunks; ck += 5) {
+#pragma unroll 1
+                for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h, J0{});     // H, L, H, L: the same code, other weights
+                chunk(KQ{}, ck + 4, J0{});
+            }
+        } else {
+            for (int ck = 0; ck + 1 < nchunks; ck += 2) {
+                stages(KH{}, ck);
+                stages(KQ{}, ck + 1);
+            }
+            if constexpr (NSRC2 && AR == 0) {
+                if (nchunks & 1) chunk(KT{}, nchunks - 1, J0{});
+            }
         }
     }
 
@@ -855,7 +887,11 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     // per-lane part of an address is a 32-bit pixel offset per M block, everything that depends on the channel group, the
     // image and the plane is a scalar offset, and out-of-tile pixels get an out-of-range offset (the hardware drops the
     // store) - no 64-bit address arithmetic, no predication.
-    {
+    // (NJ > 1: once per image of the group, from its accumulator set)
+    auto epilogue_of = [&](auto j_tag) {
+    constexpr int J = decltype(j_tag)::value;
+    f32x16 (&acc)[MT][NTW] = accs[J];
+    const int n_out = n + J * img_step;
     int by_e = by, oy0_e = oy0, ox0_e = ox0;
     typedef const __attribute__((address_space(3))) float lds_cfloat;
     lds_cfloat* par_e = (lds_cfloat*)s_par;            // LDS address space: ds_read, not flat loads
@@ -898,8 +934,8 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
                 const int cv = (by_e * NT + wn * NTW + nt) * 32 + 16 * q;
                 int cb = cv; unsigned php = 0;
                 if (MODE == 1) { const int ph = cv / a.d2s_c; cb = cv - ph * a.d2s_c; php = (unsigned)((ph >> 1) * ow + (ph & 1)) * 32u; }
-                so_hi[nt][q] = ((unsigned)(n * oc) + (unsigned)cb) * ohw * 2u + php;
-                so_q[nt][q] = (unsigned)a.out_q_off + ((unsigned)(n * oc) + (unsigned)(cb & ~31)) * ohw * (ql_only ? 1u : 2u) + (unsigned)(cb & 16) + php;
+                so_hi[nt][q] = ((unsigned)(n_out * oc) + (unsigned)cb) * ohw * 2u + php;
+                so_q[nt][q] = (unsigned)a.out_q_off + ((unsigned)(n_out * oc) + (unsigned)(cb & ~31)) * ohw * (ql_only ? 1u : 2u) + (unsigned)(cb & 16) + php;
             }
         // per-lane pixel offset (bytes, 32 per pixel) of M block mt, or OOB
         unsigned vo[MT];
@@ -952,7 +988,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
                     for (int e = 0; e < 16; ++e) {
                         if (cob + (e & 3) + 8 * (e >> 2) >= a.c_out) continue;       // no lane has this channel (wave-uniform)
                         const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * kh;        // differs between the half-waves: per-lane offset
-                        const unsigned vof = (vo[mt] == OOB || co >= a.c_out) ? OOB : vo[mt] + (unsigned)(n * a.c_out + co) * ohw * 4u;
+                        const unsigned vof = (vo[mt] == OOB || co >= a.c_out) ? OOB : vo[mt] + (unsigned)(n_out * a.c_out + co) * ohw * 4u;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(t[e]), ro, vof, 0, 0);
                     }
                 }
@@ -963,7 +999,8 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
         // every block's stores go out right behind its math, so that the address unit works through them (1 KiB per instruction at
         // 64 B/clk: ~2 000 cycles per 512 x 64 tile, profiles/r04_conv_timeline_before.txt "stores") while the VALU does the next block -
         // round 3 parked all four blocks and stored them in a phase of its own, with the waves idle behind the store queue.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (NJ > 1: a group's further images have nothing new in flight but the previous image's stores)
+        if (J == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         // ---- phase 1: math ----
         // Everything the hot (activation-tensor) modes do per element is branch-free and packed where the ISA has a packed form:
@@ -1268,7 +1305,11 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     else if (a.d2s_c > 0) epilogue(std::integral_constant<int, 1>{});
     else epilogue(std::integral_constant<int, 0>{});
 #endif
-    }
+    };
+    epilogue_of(std::integral_constant<int, 0>{});
+    if constexpr (NJ > 1) epilogue_of(std::integral_constant<int, 1>{});
+    if constexpr (NJ > 2) epilogue_of(std::integral_constant<int, 2>{});
+    if constexpr (NJ > 3) epilogue_of(std::integral_constant<int, 3>{});
     dma_waited = true;
     MX_TL(9);                            // stores issued
     gbuf ^= 1;
@@ -1283,7 +1324,19 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
 
 inline int num_cus_mx() { return num_cus_current(); }
 
-template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0, bool GENC1 = false, int NB = 2>
+// NJ > 1: images per workgroup must come in whole groups of NJ: mx_groups_nj() says whether a launch can (and how many image slots to use)
+inline int mx_groups(long combos, int n, int nj) {
+    const long cus = num_cus_mx();
+    long best_cost = -1; int groups = 0;
+    for (int g = 1; g <= n; ++g) {
+        if (nj > 1 && n % (g * nj)) continue;                   // every workgroup walks n / g images: a multiple of nj
+        const long cost = (long)cdiv((long)combos * g, cus) * cdiv(n, g);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; groups = g; }
+    }
+    return groups;                                              // 0: no such split
+}
+
+template <int TW, int TH, int NT, int STRIDE, int WM, int WN, bool MASKED, bool NSRC2, int AR = 0, bool GENC1 = false, int NB = 2, int NJ = 1>
 int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
     using G = GeoMx<TW, TH, STRIDE>;
     constexpr int A_BYTES = ((2 * G::NPIX * 2 + 63) / 64) * 1024;
@@ -1292,20 +1345,13 @@ int launch_mx4(const ConvMxArgs& a, hipStream_t s) {
     // NB = 3: + the 1 KiB dump area of the out-of-range DMA pieces
     constexpr int smem = NB * (A_BYTES + NT * 18 * 1024) + 3 * 32 * NT * 4 + (GENC1 ? 2 * GT_BYTES + 64 * 10 * 4 : 0) + (NB == 3 ? 1024 : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR, GENC1, NB>;
+    auto kern = conv3x3_mx_kernel<TW, TH, NT, STRIDE, WM, WN, MASKED, NSRC2, AR, GENC1, NB, NJ>;
     // function attributes are per device and per kernel instantiation (this static lives in the instantiation)
     static std::atomic<int> attr_done[DISCO_MAX_DEVICES];
     DISCO_HIP_CHECK(set_dyn_lds_once(attr_done, reinterpret_cast<const void*>(kern), smem));
     const int combos = cdiv(a.w_out, TW) * cdiv(a.h_out, TH) * cdiv(a.c_out, 32 * NT);
-    int groups = a.n;
-    {
-        const long cus = num_cus_mx();
-        long best_cost = -1;
-        for (int g = 1; g <= a.n; ++g) {
-            const long cost = (long)cdiv((long)combos * g, cus) * cdiv(a.n, g);
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; groups = g; }
-        }
-    }
+    const int groups = mx_groups(combos, a.n, NJ);
+    if (groups <= 0) return DISCO_ESHAPE;                       // (NJ > 1: the dispatcher has asked mx_groups() before coming here)
     dim3 grid(combos, groups);
     hipLaunchKernelGGL(kern, grid, dim3((WM * WN + (NB == 3 ? 4 : 0)) * 64), smem, s, a);
     DISCO_LAUNCH_CHECK("conv3x3_mx_kernel");
@@ -1325,6 +1371,12 @@ int launch_mx2(const ConvMxArgs& a, hipStream_t s) {
 // DISCO_CONV_LAT=0: the latency loop off (A/B runs: small grids then take round 4's tiles and loop; results are bit-identical either way)
 inline bool conv_lat_enabled() {
     static const bool on = [] { const char* e = std::getenv("DISCO_CONV_LAT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// DISCO_CONV_NJ=0: the stride-2 tile fetches its weight chunks per image, as in rounds 1-4 (A/B runs; bit-identical results)
+inline bool conv_nj_enabled() {
+    static const bool on = [] { const char* e = std::getenv("DISCO_CONV_NJ"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -1366,6 +1418,16 @@ int dispatch_mx_ar(const ConvMxArgs& a, hipStream_t s) {
                 if constexpr (AR != 1) return launch_mx2<32, 4, 1, 1, 4, 1, AR, 3>(a, s);
                 [[fallthrough]];
             default: return launch_mx2<16, 16, 1, 1, 8, 1, AR>(a, s);
+        }
+    }
+    if constexpr (AR == 2 || AR == 3) {
+        // the stride-2 tile with four images per weight chunk (NJ = 4; bit-identical): when the images split into whole groups of four without
+        // a worse balance over the CUs than the plain launch finds
+        if (wide && nt2 && !a.tapmask && a.nsrc == 1 && conv_nj_enabled()) {
+            const long combos = (long)cdiv(a.w_out, 32) * cdiv(a.h_out, 4) * cdiv(a.c_out, 64), cus = num_cus_mx();
+            const int g1 = mx_groups(combos, a.n, 1), g4 = mx_groups(combos, a.n, 4);
+            if (g4 > 0 && cdiv(combos * g4, cus) * cdiv(a.n, g4) <= cdiv(combos * g1, cus) * cdiv(a.n, g1))
+                return launch_mx4<32, 4, 2, 2, 4, 2, false, false, AR, false, 2, 4>(a, s);
         }
     }
     if (wide) return nt2 ? launch_mx2<32, 4, 2, 2, 4, 2, AR>(a, s) : launch_mx2<32, 4, 1, 2, 4, 1, AR>(a, s);

@@ -296,6 +296,44 @@ def test_conv3x3_mx6_matches_torch(H, case):
         assert torch.equal(again.buf, first)
 
 
+# (cin, cout, h, w, n): shapes whose launch takes NJ = 4 on 256 CUs (dispatch_mx_ar: whole groups of four per workgroup at no worse balance than
+# the per-image launch finds), the forward's stride-2 layers among them; the last two do not (too few tiles: the per-image loop) and pin the fallback
+NJ4_CASES = [(64, 128, 256, 256, 4), (64, 128, 256, 256, 8), (128, 256, 128, 128, 8), (256, 512, 64, 64, 16), (32, 64, 250, 254, 8),
+             (64, 128, 128, 192, 12), (64, 128, 64, 96, 12), (32, 64, 33, 47, 4)]
+
+
+@pytest.mark.parametrize("case", NJ4_CASES)
+def test_conv3x3_stride2_weight_chunks_shared_by_four_images(H, case):
+    """Round 5: batches whose images split into whole groups of four per workgroup take the stride-2 tile with NJ = 4 (a weight chunk fetched
+    once per four images, four accumulator sets: conv_mx_kernel.h).  Every accumulator sees the same chunks and taps in the same order, so
+    the batch must equal - bit for bit - its images run one at a time (one image: the per-image loop), in both arithmetics that have
+    stride-2 layers (f16x3: SpixelNet / ColorProbNet; f16 + fp6x2: HourGlass2), and match torch."""
+    cin, cout, h, w, n = case
+    gen = g(cin * 31 + cout + h + n)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    want = _ref(x, wt, b, 2, _ffi.ACT_LRELU, 0.2, None, None)
+    scale = max(1.0, want.abs().max().item())
+    # f16x3
+    got = H.from_act(H.conv3x3(H.to_act(x), wt, b, stride=2, act=_ffi.ACT_LRELU, slope=0.2)).cpu()
+    assert H.max_err(got, want) < 2e-5 * scale
+    for i in range(n):
+        one = H.from_act(H.conv3x3(H.to_act(x[i:i + 1]), wt, b, stride=2, act=_ffi.ACT_LRELU, slope=0.2)).cpu()
+        assert torch.equal(one[0], got[i])
+    # f16 + fp6x2
+    kw = dict(stride=2, act=_ffi.ACT_LRELU, slope=0.2, q6=True, out_planes=LO | Q6, out_sexp=H.sexp_for(want))
+    packed = H.pack_conv_mx(wt, 2)
+    sx = H.sexp_for(x)                                   # one input scale for the batch and for its images alone
+    out, sat = H.conv3x3_mx(H.to_act_mx(x, Q6, sx), wt, b, packed=packed, **kw)
+    assert sat == 0 and H.max_err(out.read(0), want) < TOL6 * scale
+    planes = [out.read(k).cpu() for k in range(3)]
+    for i in range(n):
+        one, _ = H.conv3x3_mx(H.to_act_mx(x[i:i + 1], Q6, sx), wt, b, packed=packed, **kw)
+        for k in range(3):
+            assert torch.equal(one.read(k).cpu()[0], planes[k][i])
+
+
 def test_conv3x3_mx6_heavy_tailed_rows_block_scaled_weights(H):
     """Round 4: the fp6 WEIGHT operands carry one E8M0 scale per (output channel, 32-input-channel block, tap) - byte 24 of the weight
     slot, taken by the MFMA as its weight-side scale operand - where round 3 scaled a whole row of 9 Cin weights with one exponent: a
