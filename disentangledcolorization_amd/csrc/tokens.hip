@@ -1251,22 +1251,29 @@ __global__ __launch_bounds__(1024) void kmeans_tiled_kernel(const float* __restr
 // ---- k-means + anchors for more than 512 points on SEVERAL workgroups per image (round 5) ----------------------------------------------
 // kmeans_tiled_kernel walks an image's tiles one after the other on one workgroup: 40 us per Lloyd pass at 1 536 tokens, 470 at 16 384 -
 // 13 % of a --no_resize forward.  Here workgroup g of G keeps tiles 2g and 2g + 1 (512 points) RESIDENT in LDS for the whole kernel, all
-// workgroups assign their points at once, and the member sums - one sequential chain per (cluster, feature) in ascending point order: the
-// property that makes the result independent of everything but the data - travel down the workgroups as a pipeline: g waits for g - 1's
-// running sums (2 KB through global memory + a flag), adds its own members in order, hands on; the last workgroup divides, measures the
-// shift, decides, and publishes the new centres, which everybody picks up.  Same additions in the same order as the one-workgroup
-// kernels: bit-identical assignments, pass counts and events (tests/test_gpu_ops.py::test_kmeans_small_kernel_equals_the_general_one
-// runs it against the general kernel).  ~G x 2.5 us + 5 us per pass instead of G x 13.
-// Measured (profiles/r05_kmeans_latency_ab.txt): a hop costs ~8 us whatever the fences (agent-scope release / acquire, or - as now -
-// system-scope relaxed accesses past the non-coherent L2s): a store-acknowledge, a flag and a load round trip through memory each.
-// 1 536 tokens 40 -> 29 us per pass, 16 384 tokens 472 -> 294.  (What would be faster: workers that only assign + ONE reducer workgroup
-// that streams the members' rows from L2 in order - DESIGN.md section 7.)
-// The workgroups of an image spin on each other's flags, so they must all be resident: the launcher takes this kernel only when
-// n x G <= a quarter of the CUs, and every spin is bounded by a wall-clock deadline (2 s from kernel entry); a workgroup that runs into
-// it TRAPS - the launch fails loudly (hipErrorLaunchFailure), never returns a wrong clustering.
+// workgroups assign their points at once (the distance pass is VALU-bound: 12 300 cycles per 512 points on one CU) and sort them by
+// (cluster, point) - a counting sort from ballot masks - and the member sums - one sequential chain per (cluster, feature) in ascending
+// point order: the property that makes the result independent of everything but the data - travel down the workgroups as a pipeline:
+// wave j of workgroup g waits for g - 1's running sum of cluster j, adds its own members from its list (rows streamed from LDS sixteen
+// deep), hands on; the last workgroup divides, measures the shift, decides, and publishes the new centres, which everybody picks up.
+// Same additions in the same order as the one-workgroup kernels: bit-identical assignments, pass counts and events
+// (tests/test_gpu_ops.py::test_kmeans_small_kernel_equals_the_general_one runs it against the general kernel).
+// Exchange: every word is an aligned 8 bytes {value, tag}, the tag naming the pass (and for a sum the writer and the member count), so
+// the reader polls the DATA: one round trip per hop (a flag behind the data cost a store acknowledge, a flag round trip and a data round
+// trip).  s_memtime stamps (profiles/r05_kmeans_coop_phases.txt): a hop is ~2 700 cycles whichever way the words travel; what the first
+// version of this kernel spent per workgroup was its own sums - ~6 700 cycles walking ballot masks (105 per member) - now ~4 000 from
+// the lists.  1 536 tokens 40 -> 23 us per pass, 16 384 tokens 472 -> 198.  A REDUCER form (workers publish their lists, one workgroup
+// streams every member's row from L2 in order) was built too: bit-identical, but at 16 rows in flight per wave an L2 row costs ~270
+// cycles per member against ~70 from LDS - 264 us per pass at 16 384 tokens; it would need a ring of ~64 rows per cluster in flight
+// (LDS-DMA + a second wave per cluster for the list polls) to win.
+// The workgroups of an image spin on each other's words, so they must all be resident: the launcher takes this kernel only while n x G
+// fits a quarter of the CUs, and every spin is bounded by a deadline (5e9 shader cycles from kernel entry); a wave that runs into it
+// TRAPS - the launch fails loudly (hipErrorLaunchFailure), never returns a wrong clustering.
 constexpr int KC_MAXG = 64;
-struct KmCoopCtl { int flagS[KC_MAXG]; int flagC; int stop_pass; int err; int pad; };
-constexpr size_t KC_IMG_BYTES = ((size_t)(2 * KMAX * 64 + KMAX) * 4 + sizeof(KmCoopCtl) + 255) & ~(size_t)255;
+struct KmCoopCtl { int done[KC_MAXG]; int pad[4]; };
+// per image: the running member sums and the pass's new centres, [KMAX][64] 8-byte words {value, tag} each, + the flags
+constexpr size_t KC_IMG_BYTES = ((size_t)(2 * KMAX * 64) * 8 + sizeof(KmCoopCtl) + 255) & ~(size_t)255;
+constexpr int KC_MAX_POINTS = 1 << 18;
 __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
                                                            const int32_t* __restrict__ init_idx, const int32_t* __restrict__ fallback,
                                                            int max_fallback, int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
@@ -1277,41 +1284,47 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
     __shared__ int cnt[KMAX];
     __shared__ float shift_part[KMAX];
     __shared__ int s_anchor[KMAX];
-    __shared__ int s_events, s_any_empty, s_bcast;
+    __shared__ int s_events, s_any_empty, s_stop;
+    __shared__ int cntblk[KMAX][8];             // members of cluster j in 64-point block b of this workgroup's 512 points; then their start in order[]
+    __shared__ int seg[KMAX][2];                // cluster j's segment of order[]: start (as a byte offset into order), count
+    __shared__ int order[512];                  // this workgroup's points sorted by (cluster, point), as the byte offsets of their rows in dyn
     const int img = blockIdx.x / G, g = blockIdx.x - img * G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool last_wg = g == G - 1;
     const float* X = x + (size_t)img * L * 64;
     int32_t* assign = assign_out + (size_t)img * L;
     unsigned char* sc = scratch + (size_t)img * KC_IMG_BYTES;
-    float* gS = reinterpret_cast<float*>(sc);                    // running member sums [K][64]
-    int* gM = reinterpret_cast<int*>(gS + KMAX * 64);            // running member counts [K]
-    float* gC = reinterpret_cast<float*>(gM + KMAX);             // the pass's new centres [K][64]
+    typedef unsigned long long u64;
+    u64* gS = reinterpret_cast<u64*>(sc);                        // running member sums [K][64]: {sum, pass << 24 | writer << 18 | members so far}
+    u64* gC = gS + KMAX * 64;                                    // the pass's new centres [K][64]: {centre, pass << 24 | stop}
     KmCoopCtl* ctl = reinterpret_cast<KmCoopCtl*>(gC + KMAX * 64);
     // Everything the workgroups exchange goes through SYSTEM-scope relaxed accesses (stores written through, loads past the non-coherent
-    // caches: the XCDs' L2s do not see each other's lines): no cache-wide write-back / invalidate per hop, which an agent-scope
-    // release / acquire pair costs (measured: 8 us per hop with fences, ~3 with these).  Order: data stores, s_waitcnt vmcnt(0) (a store
-    // counts until it is acknowledged), workgroup barrier, flag store; the reader polls the flag, then loads the data.
-    auto st_f = [](float* ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    auto st_i = [](int* ptr, int v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    auto ld_f = [](const float* ptr) -> float { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    auto ld_i = [](const int* ptr) -> int { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + 200000000ull;     // 100 MHz counter: 2 s
-    // one lane waits until *flag >= want (agent-scope acquire), then the workgroup passes a barrier; false: deadline passed
-    auto wait_flag = [&](int* flag, int want) -> bool {
-        if (tid == 0) {
-            int ok = 1;
-            while (ld_i(flag) < want) {
-                if (__builtin_amdgcn_s_memrealtime() > deadline) { ok = 0; __builtin_trap(); }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            s_bcast = ok;
-        }
-        __syncthreads();
-        const int ok = s_bcast;
-        __syncthreads();
-        return ok != 0;
+    // caches: the XCDs' L2s do not see each other's lines) - no cache-wide write-back / invalidate per hop, which an agent-scope
+    // release / acquire pair costs.  (A variant that placed an image's workgroups on ONE XCD - workgroup id mod 8, verified through
+    // HW_REG_XCC_ID - and exchanged through that XCD's L2 - plain stores, polls as atomic ORs executed in the L2; sc0 loads hit the CU's own
+    // L1 forever, sc1 accesses go to memory like system-scope ones - was built and measured equal to 0.1 us at every size: the exchange,
+    // ~1 400 cycles per hop, is not where a pass spends its time.  Removed.)
+    auto st_u = [](u64* ptr, unsigned v, unsigned tag) {
+        __hip_atomic_store(ptr, ((u64)tag << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
+    auto st_i = [](int* ptr, int v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto ld_i = [](const int* ptr) -> int { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    // (s_memtime - the shader clock - not s_memrealtime: this runs inside every poll iteration)
+    const unsigned long long deadline = __builtin_amdgcn_s_memtime() + 5000000000ull;     // 2-4 s
+    // this wave polls one word per lane until every taking-part lane's tag equals `want` under `mask`; a lane with !mine takes no part.
+    // A wave that runs into the deadline TRAPS.
+    auto poll = [&](const u64* ptr, bool mine, unsigned want, unsigned mask) -> u64 {
+        u64 w = 0;
+        for (;;) {
+            if (mine) w = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const bool ok = !mine || (((unsigned)(w >> 32)) & mask) == want;
+            if (__ballot(!ok) == 0ull) break;
+            if (__builtin_amdgcn_s_memtime() > deadline) __builtin_trap();
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return w;
+    };
+    constexpr unsigned MASK_S = 0xfffc0000u, MASK_C = 0xff000000u;
     const int tile0 = 2 * g, ntl = min(2, ((L + 255) >> 8) - tile0);
     for (int u = tid; u < ntl * 256 * 16; u += 1024) {          // float4 index: tile, row, 4 columns
         const int tl = u >> 12, r = (u >> 4) & 255, c4 = (u & 15) * 4;
@@ -1321,12 +1334,11 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     for (int u = tid; u < K * 64; u += 1024) cen[0][(u >> 6) * KS_CP + (u & 63)] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
-    if (tid == 0) { s_events = 0; s_any_empty = 0; }
+    if (tid == 0) { s_events = 0; s_any_empty = 0; s_stop = 0; }
     __syncthreads();
     const int t = tid >> 2, q = tid & 3;
     const int KQ = (K + 3) >> 2;
     int cur = 0, passes = 0;
-    bool failed = false;
     auto shift_of = [&](float dlane) -> float {
         float qv = 0.f;
 #pragma unroll
@@ -1335,6 +1347,7 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
     };
     while (true) {
         const int nxt = cur ^ 1, p = passes + 1;
+        const unsigned ptag = (unsigned)p << 24;
         // ---- assign this workgroup's tiles ----
         for (int tl = 0; tl < ntl; ++tl) {
             const int base = (tile0 + tl) << 8, rows = min(256, L - base);
@@ -1369,64 +1382,98 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
             if (q == 0 && t < rows) { asg[tl][t] = bi; st_i(assign + base + t, bi); }
         }
         __syncthreads();
-        // ---- the member sums: take over from workgroup g - 1, add this workgroup's members in ascending order, hand on ----
-        if (g > 0 && !wait_flag(&ctl->flagS[g - 1], p)) failed = true;
+        // ---- the member lists: a counting sort of this workgroup's points by (cluster, point) ----
+        int my_rank = 0, my_a = -1;
+        const int blk_tl = wave >> 2, blk_tt = ((wave & 3) << 6) + lane;      // waves 0..7: one 64-point block each, lane = point
+        if (wave < 8) {
+            const int rows = blk_tl < ntl ? min(256, L - ((tile0 + blk_tl) << 8)) : 0;
+            my_a = blk_tt < rows ? asg[blk_tl][blk_tt] : -1;
+            for (int j = 0; j < K; ++j) {
+                const unsigned long long mk = __ballot(my_a == j);
+                if (lane == 0) cntblk[j][wave] = __popcll(mk);
+                if (my_a == j) my_rank = __popcll(mk & ((1ull << lane) - 1ull));
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane j: its cluster's counts per block -> starts per block; the clusters' segments by a prefix sum over the lanes
+            int c[8], tot = 0;
 #pragma unroll
+            for (int b = 0; b < 8; ++b) { c[b] = lane < K ? cntblk[lane][b] : 0; tot += c[b]; }
+            int incl = tot;
+#pragma unroll
+            for (int sft = 1; sft < 32; sft <<= 1) { const int o = __shfl_up(incl, sft); if (lane >= sft) incl += o; }
+            int run = incl - tot;
+            if (lane < K) {
+                seg[lane][0] = run; seg[lane][1] = tot;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) { cntblk[lane][b] = run; run += c[b]; }
+            }
+        }
+        __syncthreads();
+        if (wave < 8 && my_a >= 0) order[cntblk[my_a][wave] + my_rank] = (blk_tl * 256 + blk_tt) * (KS_PITCH * 4);
+        __syncthreads();
+        // ---- the member sums: wave j takes cluster j over from workgroup g - 1 (polling its tagged words), adds this workgroup's members in
+        // ascending order, hands on ----
+        const char* dynb = reinterpret_cast<const char*>(dyn) + lane * 4;
+#pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             const int j = wave + 16 * h;
             if (j >= K) break;
-            float sum = g > 0 ? ld_f(gS + j * 64 + lane) : 0.f;
-            int m = g > 0 ? ld_i(gM + j) : 0;
-            for (int tl = 0; tl < ntl; ++tl) {
-                const int rows = min(256, L - ((tile0 + tl) << 8));
-                const float* xs = dyn + tl * (256 * KS_PITCH);
-                unsigned long long mk[4];
+            float sum = 0.f; int m = 0;
+            if (g > 0) {
+                const u64 w = poll(gS + j * 64 + lane, true, ptag | ((unsigned)(g - 1) << 18), MASK_S);
+                sum = __uint_as_float((unsigned)w);
+                m = (int)((unsigned)(w >> 32) & 0x3ffffu);
+            }
+            const int st = __builtin_amdgcn_readfirstlane(seg[j][0]), mine = __builtin_amdgcn_readfirstlane(seg[j][1]);
+            m += mine;
+#pragma unroll 1
+            for (int i0 = 0; i0 < mine; i0 += 64) {
+                const int cc = min(64, mine - i0);                                  // (scalar)
+                const int ov = lane < cc ? order[st + i0 + lane] : 0;               // ONE read: the next 64 members' row offsets, a lane each
+                float v[2][16];
+                // 16 rows in flight while the previous 16 are added: the offset comes out of lane `base + u` into a scalar register
+                auto ld = [&](int buf, int base) __attribute__((always_inline)) {
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    const int tt = bb * 64 + lane;
-                    const int av = tt < rows ? asg[tl][tt] : -1;
-                    mk[bb] = __ballot(av == j);
-                    m += __popcll(mk[bb]);
-                }
+                    for (int u = 0; u < 16; ++u) v[buf][u] = *reinterpret_cast<const float*>(dynb + __builtin_amdgcn_readlane(ov, base + u));
+                };
+                ld(0, 0);
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    unsigned long long mask = mk[bb];
-                    while (mask) {
-                        float v[8]; bool ok[8];
+                for (int gq = 0; gq < 4; ++gq) {
+                    if (gq * 16 >= cc) break;
+                    if (gq < 3 && (gq + 1) * 16 < cc) ld((gq + 1) & 1, (gq + 1) * 16);
+                    if ((gq + 1) * 16 <= cc) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            ok[u] = mask != 0ull;
-                            const int tt = bb * 64 + (ok[u] ? __builtin_ctzll(mask) : 0);
-                            mask &= mask - 1ull;
-                            v[u] = xs[tt * KS_PITCH + lane];
-                        }
+                        for (int u = 0; u < 16; ++u) sum += v[gq & 1][u];
+                    } else {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) if (ok[u]) sum += v[u];
+                        for (int u = 0; u < 16; ++u) if (gq * 16 + u < cc) sum += v[gq & 1][u];
                     }
                 }
             }
-            if (!last_wg) { st_f(gS + j * 64 + lane, sum); if (lane == 0) st_i(gM + j, m); }
+            if (!last_wg) st_u(gS + j * 64 + lane, __float_as_uint(sum), ptag | ((unsigned)g << 18) | (unsigned)m);
             else if (m > 0) {
                 const float c = sum / (float)m;
                 cen[nxt][j * KS_CP + lane] = c;
-                st_f(gC + j * 64 + lane, c);
                 const float sh = shift_of(c - cen[cur][j * KS_CP + lane]);
                 if (lane == 0) { shift_part[j] = sh; cnt[j] = m; }
             } else if (lane == 0) { cnt[j] = 0; s_any_empty = 1; }
         }
-        // every wave's stores (running sums, centres, this pass's assignments) have reached L2 (vmcnt counts a store until it is written
-        // there); the agent-scope release below - one lane - then writes the workgroup's dirty lines back for the other XCDs.  (A
-        // __threadfence() by all 1 024 threads did the same sixteen times over: the hop cost 8 us.)
-        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
-        __syncthreads();
         int stop = 0;
         if (!last_wg) {
-            if (tid == 0) st_i(&ctl->flagS[g], p);
-            if (!wait_flag(&ctl->flagC, p)) failed = true;
-            for (int u = tid; u < K * 64; u += 1024) cen[nxt][(u >> 6) * KS_CP + (u & 63)] = ld_f(gC + u);
-            stop = ld_i(&ctl->stop_pass) == p;
+            // the pass's centres, word by word as they arrive (thread 0's word decides for everybody: every word carries the stop bit)
+            for (int u0 = 0; u0 < K * 64; u0 += 1024) {
+                const int u = u0 + tid;
+                if ((u0 + (wave << 6)) >= K * 64) break;            // (wave-uniform: K x 64 is a multiple of 64)
+                const u64 w = poll(gC + u, true, ptag, MASK_C);
+                cen[nxt][(u >> 6) * KS_CP + (u & 63)] = __uint_as_float((unsigned)w);
+                if (u == 0) s_stop = (int)((unsigned)(w >> 32) & 1u);
+            }
             __syncthreads();
+            stop = s_stop;
         } else {
+            __syncthreads();
             if (s_any_empty) {
                 if (tid == 0) {
                     for (int j = 0; j < K; ++j)
@@ -1441,7 +1488,6 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
                     if (cnt[j] < 0) {
                         const float c = X[(size_t)(-cnt[j] - 1) * 64 + lane];
                         cen[nxt][j * KS_CP + lane] = c;
-                        st_f(gC + j * 64 + lane, c);
                         const float sh = shift_of(c - cen[cur][j * KS_CP + lane]);
                         if (lane == 0) shift_part[j] = sh;
                     }
@@ -1451,19 +1497,29 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
             float sh = 0.f;
             for (int j = 0; j < K; ++j) sh += shift_part[j];
             stop = (sh * sh < 1e-4f) || p >= 20;
-            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the centres of the rare fallback path too
-            __syncthreads();
-            if (tid == 0) {
-                if (stop) { st_i(&ctl->stop_pass, p); __builtin_amdgcn_s_waitcnt(0x0f70); }
-                st_i(&ctl->flagC, p);
-            }
+            for (int u = tid; u < K * 64; u += 1024) st_u(gC + u, __float_as_uint(cen[nxt][(u >> 6) * KS_CP + (u & 63)]), ptag | (unsigned)stop);
+            __syncthreads();                    // (shift_part / cnt / s_any_empty are rewritten in the next pass)
         }
         ++passes;
         cur = nxt;
-        if (stop || failed) break;
+        if (stop) break;
     }
-    if (!last_wg) return;
-    // ---- the last workgroup has seen every other one's assignments (the flag chain): anchors and the hint mask of the image ----
+    // ---- the end of the run: every workgroup's last assignments have reached memory before the last one reads them ----
+    if (!last_wg) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): a store counts until it is acknowledged
+        __syncthreads();
+        if (tid == 0) st_i(&ctl->done[g], 1);
+        return;
+    }
+    if (tid < G - 1) {
+        while (ld_i(&ctl->done[tid]) == 0) {
+            if (__builtin_amdgcn_s_memtime() > deadline) __builtin_trap();
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    // ---- anchors and the hint mask of the image ----
     const float* sz = sizes + (size_t)img * L;
     float* hm = hint_mask + (size_t)img * L;
     for (int j = wave; j < K; j += 16) {
@@ -1483,7 +1539,7 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
     __syncthreads();
     if (tid == 0) {
         for (int j = 0; j < K; ++j) hm[s_anchor[j]] += 1.f;
-        if (info) { info[img * 2] = failed ? -1 : passes; info[img * 2 + 1] = s_events; }
+        if (info) { info[img * 2] = passes; info[img * 2 + 1] = s_events; }
     }
 }
 
@@ -1920,10 +1976,10 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
         DISCO_HIP_CHECK(set_dyn_lds_once(small_done, reinterpret_cast<const void*>(kmeans_small_kernel), MAX_SMEM));
         hipLaunchKernelGGL(kmeans_small_kernel, dim3(n), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
                            hint_mask, info, l, k);
-    } else if (small_ok && d == 64 && !channel_major && l > 512 && ws && ws_bytes >= kmeans_ws_bytes(n, l) && cdiv(l, 512) <= KC_MAXG &&
+    } else if (small_ok && d == 64 && !channel_major && l > 512 && ws && ws_bytes >= kmeans_ws_bytes(n, l) && cdiv(l, 512) <= KC_MAXG && l < KC_MAX_POINTS &&
                (long)n * cdiv(l, 512) <= num_cus_current() / 4 && coop_ok) {
         // several workgroups per image, all of them resident (they wait for each other): a quarter of the CUs at most, so that the launches
-        // of up to four concurrent forwards (runner.py pipelines two) always fit side by side; the flags start at zero
+        // of up to four concurrent forwards (runner.py pipelines two) always fit side by side; the exchange area starts at zero
         const int G = cdiv(l, 512);
         DISCO_HIP_CHECK(hipMemsetAsync(ws, 0, kmeans_ws_bytes(n, l), s));
         const size_t smem = (size_t)2 * 256 * KS_PITCH * sizeof(float);
