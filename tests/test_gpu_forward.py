@@ -888,6 +888,31 @@ def test_pipelined_batches_equal_the_plain_runs(synth_sd):
                 assert torch.equal(res[0], want[i % 3][0]) and torch.equal(res[1], want[i % 3][1]), (rnd, i)
 
 
+@pytest.mark.parametrize("shape", [(1, 512, 768), (3, 768, 512)])
+def test_pipelined_forwards_with_the_several_workgroup_kmeans(synth_sd, shape):
+    """--no_resize sizes (more than 512 tokens) take kmeans_coop_kernel: an image's workgroups wait for each other's words.  Issued over
+    two streams (ShardedColorizer.pipeline) two such launches and the other forward's persistent conv workgroups share the GPU; every
+    result must equal the one-stream forward bit for bit (tools/coop_soak.py runs the longer version)."""
+    from disentangledcolorization_amd.runner import ShardedColorizer
+    n, h, w = shape
+    m = _model(synth_sd, 8)
+    g_, a_ = synth.synth_inputs(n, h, w, seed=3, ab_scale=0.3)
+    g_, a_ = g_.cuda(), a_.cuda()
+    plain = ShardedColorizer.from_model(m, micro_batches=1, exact_fallback=False)
+    _seed(130); p_, m_ = plain.colorize(g_, a_, n, 0)
+    torch.cuda.synchronize()
+    want = (p_.clone(), m_.clone())
+    r = ShardedColorizer.from_model(m, micro_batches=1, exact_fallback=False)
+    r.pipeline = True
+    got = []
+    for _ in range(12):
+        _seed(130); got.append(r.colorize(g_, a_, n, 0))
+    r.wait()
+    torch.cuda.synchronize()
+    for i, res in enumerate(got):
+        assert torch.equal(res[0], want[0]) and torch.equal(res[1], want[1]), i
+
+
 def test_two_host_threads_share_one_context(synth_sd):
     """include/disco_hip.h, threading: a context's entry points serialise on a mutex inside the context, so several host threads may share one
     (their host-side issue takes turns, their streams overlap on the GPU).  Two threads, each on its own stream, run 25 forwards of their own
