@@ -53,7 +53,7 @@
 #define MX_QFMT 0       // operand format of the K = 64 correction MFMA: 0 = fp8 e4m3.  2 (fp6 e2m3) / 4 (fp4): SPEED EXPERIMENTS ONLY - the data stay fp8 bytes
 #endif
 #ifndef MX_ABL
-#define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk,
+#define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh; bit 4 = no output stores): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk,
                         // bit 2 = no PIXEL pieces after the first chunk, bit 3 = no WEIGHT pieces after the first chunk
 #endif
 
@@ -949,6 +949,9 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
         }
         // the stores of one 32 x 32 output block (its words were parked in the accumulator registers by the math below)
         auto store_block = [&](int mt, int nt) __attribute__((always_inline)) {
+#if MX_ABL & 16
+            return;                     // (ablation: the epilogue's math without its stores)
+#endif
             const int cob = (by_e * NT + wn * NTW + nt) * 32;
             {
                 // (elements are read by value: __builtin_bit_cast applied to a vector-element lvalue reads element 0)

@@ -29,6 +29,8 @@ SHAPES = [  # name, cin0, cin1, cout, h_in (logical), stride, up0
     ("s2 256->512 @64", 256, 0, 512, 64, 2, 0),
     ("64->2(32) @256", 64, 0, 2, 256, 1, 0),
     ("16->16 @256", 16, 0, 16, 256, 1, 0),
+    ("cat 16+16->16 @256", 16, 16, 16, 256, 1, 0),      # SpixelNet's conv0_1 ...
+    ("16->9(32) @256", 16, 0, 9, 256, 1, 0),             # ... and pred_mask0 (here with an activation-tensor output)
 ]
 
 
