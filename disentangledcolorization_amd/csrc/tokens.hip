@@ -895,8 +895,8 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
 //   assign   4 threads per point (a quarter of the centres each), the point's 64 features in REGISTERS for the whole kernel, the centres
 //            as ds_read_b128 broadcasts; the quarters of a point are neighbouring lanes and merge by shuffles under the order
 //            (distance, centre index) = the first minimum over all centres
-//   update   one WAVE per cluster, lane = feature: the members as ballot masks of the assignments (wave-uniform), their rows read eight
-//            at a time and added in ascending point order; the centre's shift as a chain over v_readlane'd lanes - no member list, no
+//   update   one WAVE per cluster, lane = feature: the members from ballot masks of the assignments into a wave-local list, their rows
+//            streamed from it sixteen deep and added in ascending point order; the centre's shift as a chain over v_readlane'd lanes - no member list, no
 //            sort, no cross-wave reduction; new centres go to the other of two centre buffers (no copy pass)
 //   stop     every thread sums the K shifts itself (same order), so the decision needs no third barrier
 // The arithmetic is kmeans_anchor_kernel's, expression by expression (fmaf distance chain over ascending features, first minimum, member
@@ -917,6 +917,7 @@ __global__ __launch_bounds__(1024) void kmeans_small_kernel(const float* __restr
     __shared__ float shift_part[KMAX];
     __shared__ int s_anchor[KMAX];
     __shared__ int s_events, s_any_empty;
+    __shared__ unsigned short mlist[16][KS_MAXL];       // per wave: the member list of the cluster it is summing
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* X = x + (size_t)img * L * 64;
     float* xs = dyn;
@@ -965,30 +966,44 @@ __global__ __launch_bounds__(1024) void kmeans_small_kernel(const float* __restr
             return sqrtf(qv);
         };
         for (int j = wave; j < K; j += 16) {
-            unsigned long long mk[4]; int m = 0;
+            // the members of cluster j, ascending, as the byte offsets of their rows: every member lane writes its own entry at its rank
+            // (ballot + popcount below the lane) into this wave's list - wave-local, no barrier - and the rows then stream from the list
+            // sixteen deep (walking the masks block by block, eight rows at a time, cost ~105 cycles per member: r05_kmeans_coop_phases.txt)
+            unsigned short* lst = mlist[wave];
+            int m = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int tt = b * 64 + lane;
                 const int av = tt < L ? asg[tt] : -1;
-                mk[b] = __ballot(av == j);
-                m += __popcll(mk[b]);
+                const unsigned long long mk = __ballot(av == j);
+                if (av == j) lst[m + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)tt;
+                m += __popcll(mk);
             }
+            m = __builtin_amdgcn_readfirstlane(m);
             if (m > 0) {
                 float sum = 0.f;
+                const char* xb = reinterpret_cast<const char*>(xs) + lane * 4;
+#pragma unroll 1
+                for (int i0 = 0; i0 < m; i0 += 64) {
+                    const int cc = min(64, m - i0);                                              // (scalar)
+                    const int ov = lane < cc ? (int)lst[i0 + lane] * (KS_PITCH * 4) : 0;         // ONE read: the next 64 members' row offsets
+                    float v[2][16];
+                    auto ld = [&](int buf, int base) __attribute__((always_inline)) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    unsigned long long mask = mk[b];
-                    while (mask) {                           // eight members' rows in flight, added in ascending point order
-                        float v[8]; bool ok[8];
+                        for (int u = 0; u < 16; ++u) v[buf][u] = *reinterpret_cast<const float*>(xb + __builtin_amdgcn_readlane(ov, base + u));
+                    };
+                    ld(0, 0);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            ok[u] = mask != 0ull;
-                            const int tt = b * 64 + (ok[u] ? __builtin_ctzll(mask) : 0);
-                            mask &= mask - 1ull;
-                            v[u] = xs[tt * KS_PITCH + lane];
+                    for (int gq = 0; gq < 4; ++gq) {
+                        if (gq * 16 >= cc) break;
+                        if (gq < 3 && (gq + 1) * 16 < cc) ld((gq + 1) & 1, (gq + 1) * 16);
+                        if ((gq + 1) * 16 <= cc) {
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) sum += v[gq & 1][u];
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) if (gq * 16 + u < cc) sum += v[gq & 1][u];
                         }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) if (ok[u]) sum += v[u];
                     }
                 }
                 sum = sum / (float)m;
