@@ -271,6 +271,61 @@ def test_encoder_tail_path_equals_the_tiled_one(H, synth_sd, n, hw):
     assert H.max_err(outs[1], want) < 2e-5
 
 
+_ATTN_AB = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gpu_helpers as H
+from test_gpu_ops import _attn_ab_run
+np.savez(sys.argv[1], **_attn_ab_run(H))
+"""
+
+_ATTN_AB_SHAPES = [(1, (32, 48)), (2, (32, 32)), (3, (16, 16)), (2, (9, 11)), (1, (8, 12)), (5, (7, 3)), (1, (1, 5)), (1, (40, 52))]
+
+
+def _attn_ab_run(H):
+    """Both encoder stacks' weights over token counts from 5 to 2 080 (ragged last key tiles and query tiles, counts below one half-tile of
+    keys, whole chunks + remainders): name -> output."""
+    from disentangledcolorization_amd import synth
+    sd = synth.synth_state_dict(130)
+    out = {}
+    for case, (n, (h, w)) in enumerate(_ATTN_AB_SHAPES):
+        l = h * w
+        x = torch.randn(n, l, 64, generator=g(31 * l + n))
+        pos = R.position_encoding(h, w).flatten(1).t().contiguous()
+        wts = _encoder_weights(sd, "wildpath" if case % 2 == 0 else "hintpath").to(H.DEV)
+        xd, pd = x.to(H.DEV), pos.to(H.DEV)
+        o = torch.empty_like(xd)
+        ws = torch.empty(n * l * 384 * 4 + 256 + (4 << 20), device=H.DEV, dtype=torch.uint8)
+        _ffi.check(_ffi.lib().disco_op_encoder_stack(_ffi.ptr(xd), _ffi.ptr(pd), _ffi.ptr(wts), _ffi.ptr(o), n, l,
+                                                     _ffi.ptr(ws), ws.numel(), H.stream()))
+        torch.cuda.synchronize()
+        out["o%d" % case] = o.cpu().numpy()
+    return out
+
+
+def test_attention_on_the_matrix_cores_matches_oracle_and_the_valu_kernel(H, synth_sd, tmp_path):
+    """attention_mfma_kernel (S^T = K Q^T on 32x32x2 fp32 MFMAs, P V on 4x4x1 ones with the S^T accumulators in place as the operand; the
+    default from 1 024 tokens on) forced at EVERY token count in a subprocess (DISCO_ATTN_MFMA=1), against attention_kernel forced at every
+    count (DISCO_ATTN_MFMA=0) and against the oracle's encoder stack: the same mathematics in another summation order."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / ("attn%s.npz" % mode))
+        subprocess.run([sys.executable, "-c", _ATTN_AB % (os.path.dirname(here), here), out], check=True,
+                       env=dict(os.environ, DISCO_ATTN_MFMA=mode), cwd=os.path.dirname(here))
+        res[mode] = np.load(out)
+    for case, (n, (h, w)) in enumerate(_ATTN_AB_SHAPES):
+        l = h * w
+        x = torch.randn(n, l, 64, generator=g(31 * l + n))
+        pos = R.position_encoding(h, w).flatten(1).t().contiguous()
+        want = R.encoder_stack(synth_sd, "wildpath" if case % 2 == 0 else "hintpath", x, pos[None].expand(n, -1, -1))
+        a, b = torch.from_numpy(res["1"]["o%d" % case]), torch.from_numpy(res["0"]["o%d" % case])
+        assert torch.isfinite(a).all()
+        assert (a - want).abs().max().item() < 2e-5, (case, n, l)
+        assert (a - b).abs().max().item() < 1e-5, (case, n, l)
+
+
 def _kmeans_gpu(H, x, sizes, init, fallback, k, d=64, channel_major=0):
     n, l = x.shape[0], (x.shape[2] if channel_major else x.shape[1])
     xd, sd_ = x.to(H.DEV).contiguous(), sizes.to(H.DEV).contiguous()

@@ -16,6 +16,7 @@ from disentangledcolorization_amd.model import AnchorColorProb  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--k", type=int, default=8)
+ap.add_argument("--min-tokens", type=int, default=0, help="only the points with at least this many tokens per image (h w / 256)")
 args = ap.parse_args()
 m = AnchorColorProb(n_clusters=args.k, enhanced=True).cuda().eval()
 m.sync_kmeans_events = False
@@ -23,6 +24,8 @@ m.range_checks = 0
 POINTS = [(1, 256, 256), (2, 256, 256), (4, 256, 256), (8, 256, 256), (16, 256, 256), (64, 256, 256), (128, 256, 256),
           (256, 128, 128), (1, 512, 768), (8, 512, 768), (16, 512, 512), (1, 1024, 1024), (1, 2048, 2048)]
 for n, h, w in POINTS:
+    if h * w // 256 < args.min_tokens:
+        continue
     g, a = synth.synth_inputs(n, h, w, seed=1, ab_scale=0.3)
     g, a = g.cuda(), a.cuda()
     reps = 10 if n * h * w <= 64 * 256 * 256 else 3
