@@ -57,6 +57,16 @@
                         // bit 2 = no PIXEL pieces after the first chunk, bit 3 = no WEIGHT pieces after the first chunk
 #endif
 
+#ifndef MX_DEFER
+#define MX_DEFER 0      // 1: deferred epilogue on the main tile (see DEFER in the kernel): A/B builds, tools/build_conv_variants.sh
+#endif
+#ifndef MX_DEFER_SLOT0
+#define MX_DEFER_SLOT0 1
+#endif
+#ifndef MX_DEFER_STEP
+#define MX_DEFER_STEP 2
+#endif
+
 #ifndef MX_EPI_INLINE
 #define MX_EPI_INLINE 1 // 1: an output block's stores are issued right behind its epilogue math (round 4); 0: all math, then all stores (round 3)
 #endif
@@ -189,6 +199,10 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     // its accumulator chain, and an LDS-DMA piece costs 60-180 issue cycles there (measured: three pieces per tap group were ~270 of a
     // group's ~560 cycles); in a wave of its own the issue runs next to the consumer's MFMAs.
     constexpr int NPROD = NB == 3 ? 4 : 0;
+    // DEFER (MX_DEFER builds): a tile's epilogue runs inside the NEXT tile's first chunk, block by block between its taps, from a second
+    // accumulator set - the main 8-wave stride-1 tile of the f16x3 / f16+fp6x2 arithmetics only (64 + 64 accumulator registers)
+    constexpr bool DEFER = MX_DEFER && NB == 2 && NJ == 1 && !NSRC2 && !GENC1 && !MASKED && STRIDE == 1 && TW == 32 && TH == 16 && NT == 2 && (AR == 2 || AR == 3);
+    constexpr int DEFER_SLOT0 = MX_DEFER_SLOT0, DEFER_STEP = MX_DEFER_STEP;
     constexpr int NDW = NPROD ? NPROD : NWAVE;                // waves that issue DMA
     constexpr int NTHR = (NWAVE + NPROD) * 64;
     constexpr int MT = G::MB / WM;
@@ -589,6 +603,10 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
         __builtin_amdgcn_s_setprio(2);                            // the consumers' MFMAs before the producers' address arithmetic
     } else issue(n, 0, 0, -1, 0, true);
 
+    // DEFER: the accumulators of the tile before the current one, waiting for their epilogue (n_prev: its image; -1: none)
+    f32x16 accP[MT][NTW];
+    int n_prev = -1;
+    const bool defer_ok = DEFER && !a.out_f32 && a.d2s_c == 0 && !a.res;       // plain activation-tensor outputs without a residual read
     for (;;) {
     MX_TL(1);                            // tile start
     f32x16 accs[NJ][MT][NTW];            // one accumulator set per image of the group (NJ = 1: per image)
@@ -603,294 +621,19 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     f32x16 (&acc)[MT][NTW] = accs[0];    // (the latency loop's name for its one set)
 
     const int next_n = n + NJ * img_step;       // the first image of the next group
-    // one chunk: wait for its DMA, barrier, then 9 taps with the next chunk's DMA issued in ninths between them.
-    // ISQ = false: H chunk, planes = channels 0-15 / 16-31 (fp16); a lane feeds k = 8 kh .. 8 kh + 7 of both planes to two
-    //              K = 16 MFMAs.  ISQ = true: Q chunk, planes = a8 / al8; lane half kh reads all 32 bytes of plane kh
-    //              (K half kh of one K = 64 MFMA: a8 meets wl8, al8 meets w8).
-    // The H and Q chunks of a 32-channel group run back to back in one loop iteration (no branch between the two bodies:
-    // a branch made the register allocator keep the accumulators in two places).
-    // KIND 3 (TAIL): an H chunk of which only plane 0 (16 channels) exists - the last, odd chunk of a two-source f16+fp8x2 layer whose
-    //              second source is a 16-channel fp16 tensor without q planes (HourGlass2 input: the gray image as the channels
-    //              (g_hi, g_lo, g_hi) against the weights (w_h, w_h, w_l): an exact three-product split in ONE K = 16 MFMA per tap
-    //              where a padded 32-channel chunk pair spent three).  Its second-plane DMA pieces and weight pieces are not issued.
-    // KIND 2 (X3): the f16x3 arithmetic of conv_mfma2.hip on this skeleton - planes = hi / lo of 16 channels, weight tile = w_hi / w_lo
-    //              fragments (conv3x3_pack_host's image), three K = 16 MFMAs per tap in conv_mfma2's order (w_lo a_hi, w_hi a_lo,
-    //              w_hi a_hi), so results are bit-identical to that kernel's
-    // NJ > 1: a STAGE = (chunk ck, image J of the group); the next stage is the same chunk of image J + 1 (pixels only) or, behind the
-    // group's last image, the next chunk of image 0 with its weights (into the other weight buffer, which the previous chunk left with its
-    // last stage)
-    auto chunk = [&](auto kind_tag, int ck, auto j_tag) {
-        constexpr int KIND = decltype(kind_tag)::value;
-        constexpr int J = decltype(j_tag)::value;
-        constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
-        f32x16 (&acc)[MT][NTW] = accs[J];
-        MX_TL(2);                        // chunk start
-        if (!(ck == 0 && J == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (GENC1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's share of the computed pixel tile has been written
-        MX_TL(3);                        // this chunk's DMA has landed (own pieces)
-        __builtin_amdgcn_s_barrier();
-        MX_TL(ISQ ? 5 : 4);              // barrier passed: taps of an H (4) / Q (5) chunk begin
-        const bool more = ck + 1 < nchunks;
-        constexpr bool new_chunk = J == NJ - 1;             // the next stage opens a chunk
-        const int dma_img = !new_chunk ? n + (J + 1) * img_step : (more ? n : (next_n < a.n ? next_n : n));
-        const int dma_ck = !new_chunk ? ck : (more ? ck + 1 : 0);
-        const char* sA = smem + buf * BUF_BYTES;
-        const char* sW = smem + (NJ == 1 ? buf : wbuf) * BUF_BYTES + A_BYTES;
-        buf ^= 1;
-        const int wnext = wbuf ^ 1;
-        if (NJ > 1 && new_chunk) wbuf = wnext;
-        // the tap ORDER is a property of the tile width alone (never of how the tile is split over waves): every instantiation
-        // that can serve a given layer shape accumulates in the same order, so a result does not depend on the batch size
-        constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
-        constexpr bool ROWREUSE = COLMAJOR && MT >= 2;        // M block mt at ky reads tile row mt + ky = what block mt + 1 read at ky - 1
-        const int asc = (NSRC2 && !X3 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
-        // this chunk's three column addresses inside the current buffer (the only per-chunk address arithmetic)
-        const int bufoff = (int)(sA - smem);
-        int ca0[3], ca1[3];
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            ca0[kx] = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
-            ca1[kx] = ISQ ? (ca0[kx] ^ 16) : ca0[kx] + PLANE_B;           // all other address terms are multiples of 32
-        }
-        int wo = w_off;
-        asm volatile("" : "+v"(wo));
-        i32x4 ra[MT][2];
-        i32x4 rb[NTW][2];
-#pragma unroll
-        for (int slot = 0; slot < 9; ++slot) {
-            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
-            const int tap = ky * 3 + kx;
-#if !(MX_ABL & 1)
-            issue(dma_img, dma_ck, buf, slot, wnext, new_chunk);
-#endif
-            if (GENC1) {
-                // the next chunk's pixel tile, a third per wave in taps 0, 3 and 6; in the tile's first chunk also the NEXT image's gray tile
-                // (into the other gray buffer: complete and visible from the next chunk's barrier on, needed in the tile's last chunk)
-                if (slot == 0 && ck == 0 && next_n < a.n) issue_gray(next_n, gbuf ^ 1);
-                if (slot % 3 == 0 && slot / 3 < GEN_PER_WAVE && (more || next_n < a.n))
-                    gen_c1((slot / 3) * NWAVE + wave, dma_ck, more ? gbuf : (gbuf ^ 1), buf);
-            }
-            const bool live = !MASKED || ((tmask >> tap) & 1u);
-            if (!ROWREUSE && !live) continue;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (ROWREUSE && ky > 0 && mt + 1 < MT) { ra[mt][0] = ra[mt + 1][0]; ra[mt][1] = ra[mt + 1][1]; continue; }
-#if MX_ABL & 2
-                if (slot > 0) continue;
-#endif
-                constexpr int RB = G::PITCH * 32;                           // bytes per tile row
-                const int rowc = (mt * G::ROWS_PER_MB * STRIDE + ky) * RB;   // compile-time constant: the ds_read's immediate offset
-                ra[mt][0] = *reinterpret_cast<const i32x4*>(smem + ca0[kx] + rowc);
-                if (!TAIL) ra[mt][1] = *reinterpret_cast<const i32x4*>(smem + ca1[kx] + rowc);
-            }
-            if (ROWREUSE && !live) continue;
-#if MX_ABL & 2
-            static_assert(true, "");
-#endif
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-#if MX_ABL & 2
-                if (slot > 0) continue;
-#endif
-                const int off = wo + nt * W_NB + tap * 2 * WBLK;
-                rb[nt][0] = *reinterpret_cast<const i32x4*>(sW + off);
-                if (!TAIL) rb[nt][1] = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
-            }
-            if ((slot + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    if (ISQ) {
-                        const i32x8 bw = {rb[nt][0][0], rb[nt][0][1], rb[nt][0][2], rb[nt][0][3], rb[nt][1][0], rb[nt][1][1], rb[nt][1][2], rb[nt][1][3]};
-                        const i32x8 ap = {ra[mt][0][0], ra[mt][0][1], ra[mt][0][2], ra[mt][0][3], ra[mt][1][0], ra[mt][1][1], ra[mt][1][2], ra[mt][1][3]};
-                        // fp6 slots carry their own E8M0 block scale (per pixel - or per output channel and tap - and 32 channels) in byte 24 =
-                        // dword 6 of the fragment, which the MFMA ignores as operand data: both scale operands of a lane come straight out of
-                        // its fragment registers
-                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], QFMT, QFMT, 0, Q6 ? rb[nt][1][2] : wsc[nt], 0, Q6 ? ra[mt][1][2] : asc);
-                    } else if (KIND == 2) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
-                    } else {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
-                        if (!TAIL) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
-                    }
-                }
-            // pin this tap's MFMAs here: without a use of the accumulators the optimiser sinks the whole (pure) MFMA chain of a
-            // chunk below its last tap, which hoists all 9 taps of fragment reads above it (~200 VGPRs, spills)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    float pin = acc[mt][nt][0];
-                    asm volatile("" : "+v"(pin));
-                    acc[mt][nt][0] = pin;
-                }
-        }
-    };
-    using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>; using KT = std::integral_constant<int, 3>;
-    if constexpr (NB == 3) {
-        // ---- the latency loop (see the template parameter NB) ---------------------------------------------------------------------
-        //     chunk s, tap t < 8:  read frags(t + 1) | MFMAs(t)
-        //     chunk s, tap 8:      wait for chunk s + 1 (own pieces; chunk s + 2's may stay in flight), own reads of chunk s returned,
-        //                          s_barrier; issue chunk s + 3 into chunk s's buffer; read frags(chunk s + 1, tap 0) | MFMAs(8)
-        // Buffer protocol: the barrier B(s+1) inside tap 8 of chunk s separates every wave's last read of chunk s's buffer from the first DMA
-        // write into it (chunk s + 3's, issued right behind the barrier) and every wave's DMA pieces of chunk s + 1 from the first read of
-        // them.  A tile's first chunk has its barrier at the top (the previous tile's epilogue lies in between and has waited for everything
-        // in flight).  The barrier skew and a chunk's first LDS latency run under the previous tap's MFMAs.
-        struct Frag { i32x4 a0, a1, b0, b1; };
-        constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;      // (the tap order of the tile width: as in the throughput loop)
-        auto slot_tap = [](int slot) { const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3; return ky * 3 + kx; };
-        auto slot_live = [&](int slot) -> bool { return !MASKED || ((tmask >> slot_tap(slot)) & 1u); };
-        auto load_frags = [&](auto kind_tag, int cb, int slot, Frag& f) __attribute__((always_inline)) {
-            constexpr bool ISQ = decltype(kind_tag)::value == 1;
-            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
-            const int tap = ky * 3 + kx;
-            int bufoff = cb * BUF_BYTES;
-            asm("" : "+s"(bufoff));                                  // an opaque scalar, added per read (no table of 9 addresses in registers)
-            const int c0 = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
-            const int c1 = ISQ ? (c0 ^ 16) : c0 + PLANE_B;
-            constexpr int RB = G::PITCH * 32;
-            const int rowc = ky * RB;                                  // (MT = 1: the wave's one M block; compile-time: the ds_read's immediate)
-            f.a0 = *reinterpret_cast<const i32x4*>(smem + c0 + rowc);
-            f.a1 = *reinterpret_cast<const i32x4*>(smem + c1 + rowc);
-            const char* sW = smem + bufoff + A_BYTES;
-            const int off = w_off + tap * 2 * WBLK;
-            f.b0 = *reinterpret_cast<const i32x4*>(sW + off);
-            f.b1 = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
-        };
-        // Taps go in GROUPS of three: the fragments of a group are read (12 ds_read_b128) while the previous group's MFMAs - 9 / 6 / 3 of
-        // them, back to back on the wave's one accumulator - run.  A wave alone on its SIMD pays for every instruction that stands between two
-        // MFMAs of one accumulator chain (MI355X_MICROARCH.md: +43 cycles for the first issue slot in such a gap, ~6 for each further one), so
-        // the chain is broken three times per chunk, not nine.
-        struct Grp { Frag t[3]; };
-        Grp pf;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) pf.t[i] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
-        auto load_group = [&](auto kind_tag, int cb, int g, Grp& f) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (slot_live(3 * g + i)) load_frags(kind_tag, cb, 3 * g + i, f.t[i]);
-        };
-        // FIRST / LAST: the tile's first / last chunk, as compile-time flags - with run-time branches the compiler's wait-count pass merges
-        // the paths and makes a group's MFMA run wait for LDS reads it does not use
-        auto chunk_lat = [&](auto kind_tag, auto next_tag, auto first_tag, auto last_tag) {
-            constexpr int KIND = decltype(kind_tag)::value;
-            constexpr bool ISQ = KIND == 1;
-            constexpr bool pf_valid = !decltype(first_tag)::value, last = decltype(last_tag)::value;
-            MX_TL(2);
-            Grp cur = pf;
-            if constexpr (!pf_valid) {
-                MX_TL(3);
-                __builtin_amdgcn_s_barrier();                     // B(s) of the tile's first chunk: the producers have seen it land
-                load_group(kind_tag, l_cbuf, 0, cur);
-            }
-            MX_TL(ISQ ? 5 : 4);
-            const int nbuf = l_cbuf == NB - 1 ? 0 : l_cbuf + 1;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                Grp nxt = cur;
-                if (g < 2) load_group(kind_tag, l_cbuf, g + 1, nxt);
-                else if constexpr (!last) {
-                    // B(s + 1): every fragment read of this chunk has returned (its buffer is the producers' from here on); behind it the next
-                    // chunk is complete in LDS
-                    MX_TL(10);
-                    // (the builtin, not an asm: the compiler's wait-count pass then KNOWS that this chunk's reads have returned; behind an opaque
-                    // asm it believed them outstanding next to the 12 new ones - more than the 4-bit counter can express - and made the
-                    // MFMA run below wait for the new reads)
-                    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
-                    __builtin_amdgcn_s_barrier();
-                    MX_TL(11);
-                    load_group(next_tag, nbuf, 0, pf);
-                }
-                // this group's fragments have returned (the next group's 12 reads may stay in flight): ONE wait in front of the run, none inside
-                // it - an s_waitcnt between two MFMAs of the chain is an issue slot like any other
-                if (g < 2) __builtin_amdgcn_s_waitcnt(0xcc7f);        // lgkmcnt(12)
-                else if constexpr (last) __builtin_amdgcn_s_waitcnt(0xc07f);
-                // (the scheduler otherwise sinks the reads into the MFMA run)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (!slot_live(3 * g + i)) continue;
-                    const Frag& f = cur.t[i];
-                    if (ISQ) {
-                        const i32x8 bw = {f.b0[0], f.b0[1], f.b0[2], f.b0[3], f.b1[0], f.b1[1], f.b1[2], f.b1[3]};
-                        const i32x8 ap = {f.a0[0], f.a0[1], f.a0[2], f.a0[3], f.a1[0], f.a1[1], f.a1[2], f.a1[3]};
-                        acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[0][0], QFMT, QFMT, 0, Q6 ? f.b1[2] : wsc[0], 0, Q6 ? f.a1[2] : asc0);
-                    } else if (KIND == 2) {
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b1), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a1), acc[0][0], 0, 0, 0);
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
-                    } else {
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b1), __builtin_bit_cast(f16x8, f.a1), acc[0][0], 0, 0, 0);
-                    }
-                }
-                {
-                    float pin = acc[0][0][0];                  // (pins this group's MFMAs here: see the throughput loop)
-                    asm volatile("" : "+v"(pin));
-                    acc[0][0][0] = pin;
-                }
-                cur = nxt;
-            }
-            l_cbuf = nbuf;
-        };
-        using Yes = std::true_type; using No = std::false_type;
-        if constexpr (X3) {
-            if (nchunks == 1) chunk_lat(K3{}, K3{}, Yes{}, Yes{});
-            else {
-                chunk_lat(K3{}, K3{}, Yes{}, No{});
-                for (int ck = 1; ck + 1 < nchunks; ++ck) chunk_lat(K3{}, K3{}, No{}, No{});
-                chunk_lat(K3{}, K3{}, No{}, Yes{});
-            }
-        } else {
-            // (H, Q) pairs: nchunks is even
-            chunk_lat(KH{}, KQ{}, Yes{}, No{});
-            for (int ck = 2; ck < nchunks; ck += 2) {
-                chunk_lat(KQ{}, KH{}, No{}, No{});
-                chunk_lat(KH{}, KQ{}, No{}, No{});
-            }
-            chunk_lat(KQ{}, KH{}, No{}, Yes{});
-        }
-    } else {
-        using J0 = std::integral_constant<int, 0>;
-        // every image of the group through one chunk
-        auto stages = [&](auto kind_tag, int ck) __attribute__((always_inline)) {
-            chunk(kind_tag, ck, J0{});
-            if constexpr (NJ > 1) chunk(kind_tag, ck, std::integral_constant<int, 1>{});
-            if constexpr (NJ > 2) chunk(kind_tag, ck, std::integral_constant<int, 2>{});
-            if constexpr (NJ > 3) chunk(kind_tag, ck, std::integral_constant<int, 3>{});
-        };
-        if constexpr (X3) {
-            for (int ck = 0; ck < nchunks; ++ck) stages(K3{}, ck);
-        } else if constexpr (XQ) {
-            for (int ck = 0; ck < nchunks; ck += 5) {
-#pragma unroll 1
-                for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h, J0{});     // H, L, H, L: the same code, other weights
-                chunk(KQ{}, ck + 4, J0{});
-            }
-        } else {
-            for (int ck = 0; ck + 1 < nchunks; ck += 2) {
-                stages(KH{}, ck);
-                stages(KQ{}, ck + 1);
-            }
-            if constexpr (NSRC2 && AR == 0) {
-                if (nchunks & 1) chunk(KT{}, nchunks - 1, J0{});
-            }
-        }
-    }
-
-    MX_TL(6);                            // taps done
     // ---- epilogue: bias (+res) -> activation -> BN affine -> split into the output planes -> store ------------------------
     // All stores go through ONE buffer descriptor over the output tensor (hi [+ lo] [+ q] planes are one allocation): the
     // per-lane part of an address is a 32-bit pixel offset per M block, everything that depends on the channel group, the
     // image and the plane is a scalar offset, and out-of-tile pixels get an out-of-range offset (the hardware drops the
     // store) - no 64-bit address arithmetic, no predication.
     // (NJ > 1: once per image of the group, from its accumulator set)
-    auto epilogue_of = [&](auto j_tag) {
+    // BLK < 0: all blocks of accumulator set J of the tile just finished (image n + J img_step).  BLK >= 0 (DEFER): output block BLK (= nt MT + mt)
+    // of the PARKED accumulators of the previous tile (image n_prev), called from inside the current tile's first chunk - activation-tensor mode,
+    // no wait for the DMA in flight
+    auto epilogue_of = [&](auto j_tag, auto blk_tag) {
     constexpr int J = decltype(j_tag)::value;
-    f32x16 (&acc)[MT][NTW] = accs[J];
+    constexpr int BLK = decltype(blk_tag)::value;
+    f32x16 (&acc)[MT][NTW] = *[&]() -> f32x16 (*)[MT][NTW] { if constexpr (BLK >= 0) return &accP; else return &accs[J]; }();
 #if MX_ABL & 32
     {
         // ablation: NO epilogue (no math, no stores; the DMA wait stays) - an upper bound of what ANY scheme that hides the epilogue under the
@@ -907,7 +650,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
         return;
     }
 #endif
-    const int n_out = n + J * img_step;
+    const int n_out = BLK >= 0 ? n_prev : n + J * img_step;
     int by_e = by, oy0_e = oy0, ox0_e = ox0;
     typedef const __attribute__((address_space(3))) float lds_cfloat;
     lds_cfloat* par_e = (lds_cfloat*)s_par;            // LDS address space: ds_read, not flat loads
@@ -1019,7 +762,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
         // 64 B/clk: ~2 000 cycles per 512 x 64 tile, profiles/r04_conv_timeline_before.txt "stores") while the VALU does the next block -
         // round 3 parked all four blocks and stored them in a phase of its own, with the waves idle behind the store queue.
         // (NJ > 1: a group's further images have nothing new in flight but the previous image's stores)
-        if (J == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (J == 0 && BLK < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         // ---- phase 1: math ----
         // Everything the hot (activation-tensor) modes do per element is branch-free and packed where the ISA has a packed form:
@@ -1040,6 +783,7 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
         for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                if (BLK >= 0 && nt * MT + mt != BLK) continue;
                 if constexpr (MODE != 2) {
                     f32x2 x[8];                              // pair p = elements 2p, 2p+1; 4-channel group g4 = p >> 1 (c = 8 g4 + 4 kh + 0..3)
 #pragma unroll
@@ -1319,17 +1063,322 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     // two-source (concat-on-read) layers only ever write plain activation tensors (the launchers refuse anything else): their
     // instantiations carry ONE epilogue, which keeps them under the register budget without scratch memory (round 2: 59-87 SGPR
     // spills through 32 B/lane of scratch in the instantiation that serves inConv.inConv.0 and both `combine` layers)
-    if constexpr (NSRC2) epilogue(std::integral_constant<int, 0>{});
+    if constexpr (NSRC2 || BLK >= 0) epilogue(std::integral_constant<int, 0>{});
     else if (a.out_f32) epilogue(std::integral_constant<int, 2>{});
     else if (a.d2s_c > 0) epilogue(std::integral_constant<int, 1>{});
     else epilogue(std::integral_constant<int, 0>{});
 #endif
     };
-    epilogue_of(std::integral_constant<int, 0>{});
-    if constexpr (NJ > 1) epilogue_of(std::integral_constant<int, 1>{});
-    if constexpr (NJ > 2) epilogue_of(std::integral_constant<int, 2>{});
-    if constexpr (NJ > 3) epilogue_of(std::integral_constant<int, 3>{});
-    dma_waited = true;
+    // one chunk: wait for its DMA, barrier, then 9 taps with the next chunk's DMA issued in ninths between them.
+    // ISQ = false: H chunk, planes = channels 0-15 / 16-31 (fp16); a lane feeds k = 8 kh .. 8 kh + 7 of both planes to two
+    //              K = 16 MFMAs.  ISQ = true: Q chunk, planes = a8 / al8; lane half kh reads all 32 bytes of plane kh
+    //              (K half kh of one K = 64 MFMA: a8 meets wl8, al8 meets w8).
+    // The H and Q chunks of a 32-channel group run back to back in one loop iteration (no branch between the two bodies:
+    // a branch made the register allocator keep the accumulators in two places).
+    // KIND 3 (TAIL): an H chunk of which only plane 0 (16 channels) exists - the last, odd chunk of a two-source f16+fp8x2 layer whose
+    //              second source is a 16-channel fp16 tensor without q planes (HourGlass2 input: the gray image as the channels
+    //              (g_hi, g_lo, g_hi) against the weights (w_h, w_h, w_l): an exact three-product split in ONE K = 16 MFMA per tap
+    //              where a padded 32-channel chunk pair spent three).  Its second-plane DMA pieces and weight pieces are not issued.
+    // KIND 2 (X3): the f16x3 arithmetic of conv_mfma2.hip on this skeleton - planes = hi / lo of 16 channels, weight tile = w_hi / w_lo
+    //              fragments (conv3x3_pack_host's image), three K = 16 MFMAs per tap in conv_mfma2's order (w_lo a_hi, w_hi a_lo,
+    //              w_hi a_hi), so results are bit-identical to that kernel's
+    // NJ > 1: a STAGE = (chunk ck, image J of the group); the next stage is the same chunk of image J + 1 (pixels only) or, behind the
+    // group's last image, the next chunk of image 0 with its weights (into the other weight buffer, which the previous chunk left with its
+    // last stage)
+    auto chunk = [&](auto kind_tag, int ck, auto j_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr int J = decltype(j_tag)::value;
+        constexpr bool ISQ = KIND == 1, TAIL = KIND == 3;
+        f32x16 (&acc)[MT][NTW] = accs[J];
+        MX_TL(2);                        // chunk start
+        if (!(ck == 0 && J == 0 && dma_waited)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (GENC1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's share of the computed pixel tile has been written
+        MX_TL(3);                        // this chunk's DMA has landed (own pieces)
+        __builtin_amdgcn_s_barrier();
+        MX_TL(ISQ ? 5 : 4);              // barrier passed: taps of an H (4) / Q (5) chunk begin
+        const bool more = ck + 1 < nchunks;
+        constexpr bool new_chunk = J == NJ - 1;             // the next stage opens a chunk
+        const int dma_img = !new_chunk ? n + (J + 1) * img_step : (more ? n : (next_n < a.n ? next_n : n));
+        const int dma_ck = !new_chunk ? ck : (more ? ck + 1 : 0);
+        const char* sA = smem + buf * BUF_BYTES;
+        const char* sW = smem + (NJ == 1 ? buf : wbuf) * BUF_BYTES + A_BYTES;
+        buf ^= 1;
+        const int wnext = wbuf ^ 1;
+        if (NJ > 1 && new_chunk) wbuf = wnext;
+        // the tap ORDER is a property of the tile width alone (never of how the tile is split over waves): every instantiation
+        // that can serve a given layer shape accumulates in the same order, so a result does not depend on the batch size
+        constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;
+        constexpr bool ROWREUSE = COLMAJOR && MT >= 2;        // M block mt at ky reads tile row mt + ky = what block mt + 1 read at ky - 1
+        const int asc = (NSRC2 && !X3 && ((ck >> 1) << 5) >= c_src0) ? asc1 : asc0;
+        // this chunk's three column addresses inside the current buffer (the only per-chunk address arithmetic)
+        const int bufoff = (int)(sA - smem);
+        int ca0[3], ca1[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            ca0[kx] = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
+            ca1[kx] = ISQ ? (ca0[kx] ^ 16) : ca0[kx] + PLANE_B;           // all other address terms are multiples of 32
+        }
+        int wo = w_off;
+        asm volatile("" : "+v"(wo));
+        i32x4 ra[MT][2];
+        i32x4 rb[NTW][2];
+#pragma unroll
+        for (int slot = 0; slot < 9; ++slot) {
+            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
+            const int tap = ky * 3 + kx;
+#if !(MX_ABL & 1)
+            issue(dma_img, dma_ck, buf, slot, wnext, new_chunk);
+#endif
+            if (GENC1) {
+                // the next chunk's pixel tile, a third per wave in taps 0, 3 and 6; in the tile's first chunk also the NEXT image's gray tile
+                // (into the other gray buffer: complete and visible from the next chunk's barrier on, needed in the tile's last chunk)
+                if (slot == 0 && ck == 0 && next_n < a.n) issue_gray(next_n, gbuf ^ 1);
+                if (slot % 3 == 0 && slot / 3 < GEN_PER_WAVE && (more || next_n < a.n))
+                    gen_c1((slot / 3) * NWAVE + wave, dma_ck, more ? gbuf : (gbuf ^ 1), buf);
+            }
+            const bool live = !MASKED || ((tmask >> tap) & 1u);
+            if (!ROWREUSE && !live) continue;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (ROWREUSE && ky > 0 && mt + 1 < MT) { ra[mt][0] = ra[mt + 1][0]; ra[mt][1] = ra[mt + 1][1]; continue; }
+#if MX_ABL & 2
+                if (slot > 0) continue;
+#endif
+                constexpr int RB = G::PITCH * 32;                           // bytes per tile row
+                const int rowc = (mt * G::ROWS_PER_MB * STRIDE + ky) * RB;   // compile-time constant: the ds_read's immediate offset
+                ra[mt][0] = *reinterpret_cast<const i32x4*>(smem + ca0[kx] + rowc);
+                if (!TAIL) ra[mt][1] = *reinterpret_cast<const i32x4*>(smem + ca1[kx] + rowc);
+            }
+            if (ROWREUSE && !live) continue;
+#if MX_ABL & 2
+            static_assert(true, "");
+#endif
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+#if MX_ABL & 2
+                if (slot > 0) continue;
+#endif
+                const int off = wo + nt * W_NB + tap * 2 * WBLK;
+                rb[nt][0] = *reinterpret_cast<const i32x4*>(sW + off);
+                if (!TAIL) rb[nt][1] = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
+            }
+            if ((slot + (wave >= NWAVE / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if (ISQ) {
+                        const i32x8 bw = {rb[nt][0][0], rb[nt][0][1], rb[nt][0][2], rb[nt][0][3], rb[nt][1][0], rb[nt][1][1], rb[nt][1][2], rb[nt][1][3]};
+                        const i32x8 ap = {ra[mt][0][0], ra[mt][0][1], ra[mt][0][2], ra[mt][0][3], ra[mt][1][0], ra[mt][1][1], ra[mt][1][2], ra[mt][1][3]};
+                        // fp6 slots carry their own E8M0 block scale (per pixel - or per output channel and tap - and 32 channels) in byte 24 =
+                        // dword 6 of the fragment, which the MFMA ignores as operand data: both scale operands of a lane come straight out of
+                        // its fragment registers
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[mt][nt], QFMT, QFMT, 0, Q6 ? rb[nt][1][2] : wsc[nt], 0, Q6 ? ra[mt][1][2] : asc);
+                    } else if (KIND == 2) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
+                    } else {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][0]), __builtin_bit_cast(f16x8, ra[mt][0]), acc[mt][nt], 0, 0, 0);
+                        if (!TAIL) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, rb[nt][1]), __builtin_bit_cast(f16x8, ra[mt][1]), acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            // pin this tap's MFMAs here: without a use of the accumulators the optimiser sinks the whole (pure) MFMA chain of a
+            // chunk below its last tap, which hoists all 9 taps of fragment reads above it (~200 VGPRs, spills)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    float pin = acc[mt][nt][0];
+                    asm volatile("" : "+v"(pin));
+                    acc[mt][nt][0] = pin;
+                }
+            if constexpr (DEFER && J == 0) {
+                // the previous tile's epilogue, one output block behind each of the first taps of this tile's first chunk: its VALU work and
+                // stores run next to the MFMAs of this wave's SIMD partner and of its own next taps
+                if (ck == 0 && n_prev >= 0) {
+                    if (slot == DEFER_SLOT0) epilogue_of(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                    if (slot == DEFER_SLOT0 + DEFER_STEP && MT * NTW > 1) epilogue_of(std::integral_constant<int, 0>{}, std::integral_constant<int, (MT * NTW > 1 ? 1 : 0)>{});
+                    if (slot == DEFER_SLOT0 + 2 * DEFER_STEP && MT * NTW > 2) epilogue_of(std::integral_constant<int, 0>{}, std::integral_constant<int, (MT * NTW > 2 ? 2 : 0)>{});
+                    if (slot == DEFER_SLOT0 + 3 * DEFER_STEP && MT * NTW > 3) epilogue_of(std::integral_constant<int, 0>{}, std::integral_constant<int, (MT * NTW > 3 ? 3 : 0)>{});
+                }
+            }
+        }
+        if constexpr (DEFER && J == 0) { if (ck == 0) n_prev = -1; }
+    };
+    using KH = std::integral_constant<int, 0>; using KQ = std::integral_constant<int, 1>; using K3 = std::integral_constant<int, 2>; using KT = std::integral_constant<int, 3>;
+    if constexpr (NB == 3) {
+        // ---- the latency loop (see the template parameter NB) ---------------------------------------------------------------------
+        //     chunk s, tap t < 8:  read frags(t + 1) | MFMAs(t)
+        //     chunk s, tap 8:      wait for chunk s + 1 (own pieces; chunk s + 2's may stay in flight), own reads of chunk s returned,
+        //                          s_barrier; issue chunk s + 3 into chunk s's buffer; read frags(chunk s + 1, tap 0) | MFMAs(8)
+        // Buffer protocol: the barrier B(s+1) inside tap 8 of chunk s separates every wave's last read of chunk s's buffer from the first DMA
+        // write into it (chunk s + 3's, issued right behind the barrier) and every wave's DMA pieces of chunk s + 1 from the first read of
+        // them.  A tile's first chunk has its barrier at the top (the previous tile's epilogue lies in between and has waited for everything
+        // in flight).  The barrier skew and a chunk's first LDS latency run under the previous tap's MFMAs.
+        struct Frag { i32x4 a0, a1, b0, b1; };
+        constexpr bool COLMAJOR = STRIDE == 1 && G::ROWS_PER_MB == 1;      // (the tap order of the tile width: as in the throughput loop)
+        auto slot_tap = [](int slot) { const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3; return ky * 3 + kx; };
+        auto slot_live = [&](int slot) -> bool { return !MASKED || ((tmask >> slot_tap(slot)) & 1u); };
+        auto load_frags = [&](auto kind_tag, int cb, int slot, Frag& f) __attribute__((always_inline)) {
+            constexpr bool ISQ = decltype(kind_tag)::value == 1;
+            const int ky = COLMAJOR ? slot % 3 : slot / 3, kx = COLMAJOR ? slot / 3 : slot % 3;
+            const int tap = ky * 3 + kx;
+            int bufoff = cb * BUF_BYTES;
+            asm("" : "+s"(bufoff));                                  // an opaque scalar, added per read (no table of 9 addresses in registers)
+            const int c0 = (ISQ ? colQ[kx] : colH[kx]) + bufoff;
+            const int c1 = ISQ ? (c0 ^ 16) : c0 + PLANE_B;
+            constexpr int RB = G::PITCH * 32;
+            const int rowc = ky * RB;                                  // (MT = 1: the wave's one M block; compile-time: the ds_read's immediate)
+            f.a0 = *reinterpret_cast<const i32x4*>(smem + c0 + rowc);
+            f.a1 = *reinterpret_cast<const i32x4*>(smem + c1 + rowc);
+            const char* sW = smem + bufoff + A_BYTES;
+            const int off = w_off + tap * 2 * WBLK;
+            f.b0 = *reinterpret_cast<const i32x4*>(sW + off);
+            f.b1 = *reinterpret_cast<const i32x4*>(sW + off + WBLK);
+        };
+        // Taps go in GROUPS of three: the fragments of a group are read (12 ds_read_b128) while the previous group's MFMAs - 9 / 6 / 3 of
+        // them, back to back on the wave's one accumulator - run.  A wave alone on its SIMD pays for every instruction that stands between two
+        // MFMAs of one accumulator chain (MI355X_MICROARCH.md: +43 cycles for the first issue slot in such a gap, ~6 for each further one), so
+        // the chain is broken three times per chunk, not nine.
+        struct Grp { Frag t[3]; };
+        Grp pf;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pf.t[i] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+        auto load_group = [&](auto kind_tag, int cb, int g, Grp& f) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (slot_live(3 * g + i)) load_frags(kind_tag, cb, 3 * g + i, f.t[i]);
+        };
+        // FIRST / LAST: the tile's first / last chunk, as compile-time flags - with run-time branches the compiler's wait-count pass merges
+        // the paths and makes a group's MFMA run wait for LDS reads it does not use
+        auto chunk_lat = [&](auto kind_tag, auto next_tag, auto first_tag, auto last_tag) {
+            constexpr int KIND = decltype(kind_tag)::value;
+            constexpr bool ISQ = KIND == 1;
+            constexpr bool pf_valid = !decltype(first_tag)::value, last = decltype(last_tag)::value;
+            MX_TL(2);
+            Grp cur = pf;
+            if constexpr (!pf_valid) {
+                MX_TL(3);
+                __builtin_amdgcn_s_barrier();                     // B(s) of the tile's first chunk: the producers have seen it land
+                load_group(kind_tag, l_cbuf, 0, cur);
+            }
+            MX_TL(ISQ ? 5 : 4);
+            const int nbuf = l_cbuf == NB - 1 ? 0 : l_cbuf + 1;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                Grp nxt = cur;
+                if (g < 2) load_group(kind_tag, l_cbuf, g + 1, nxt);
+                else if constexpr (!last) {
+                    // B(s + 1): every fragment read of this chunk has returned (its buffer is the producers' from here on); behind it the next
+                    // chunk is complete in LDS
+                    MX_TL(10);
+                    // (the builtin, not an asm: the compiler's wait-count pass then KNOWS that this chunk's reads have returned; behind an opaque
+                    // asm it believed them outstanding next to the 12 new ones - more than the 4-bit counter can express - and made the
+                    // MFMA run below wait for the new reads)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
+                    __builtin_amdgcn_s_barrier();
+                    MX_TL(11);
+                    load_group(next_tag, nbuf, 0, pf);
+                }
+                // this group's fragments have returned (the next group's 12 reads may stay in flight): ONE wait in front of the run, none inside
+                // it - an s_waitcnt between two MFMAs of the chain is an issue slot like any other
+                if (g < 2) __builtin_amdgcn_s_waitcnt(0xcc7f);        // lgkmcnt(12)
+                else if constexpr (last) __builtin_amdgcn_s_waitcnt(0xc07f);
+                // (the scheduler otherwise sinks the reads into the MFMA run)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (!slot_live(3 * g + i)) continue;
+                    const Frag& f = cur.t[i];
+                    if (ISQ) {
+                        const i32x8 bw = {f.b0[0], f.b0[1], f.b0[2], f.b0[3], f.b1[0], f.b1[1], f.b1[2], f.b1[3]};
+                        const i32x8 ap = {f.a0[0], f.a0[1], f.a0[2], f.a0[3], f.a1[0], f.a1[1], f.a1[2], f.a1[3]};
+                        acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, ap, acc[0][0], QFMT, QFMT, 0, Q6 ? f.b1[2] : wsc[0], 0, Q6 ? f.a1[2] : asc0);
+                    } else if (KIND == 2) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b1), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a1), acc[0][0], 0, 0, 0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
+                    } else {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b0), __builtin_bit_cast(f16x8, f.a0), acc[0][0], 0, 0, 0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.b1), __builtin_bit_cast(f16x8, f.a1), acc[0][0], 0, 0, 0);
+                    }
+                }
+                {
+                    float pin = acc[0][0][0];                  // (pins this group's MFMAs here: see the throughput loop)
+                    asm volatile("" : "+v"(pin));
+                    acc[0][0][0] = pin;
+                }
+                cur = nxt;
+            }
+            l_cbuf = nbuf;
+        };
+        using Yes = std::true_type; using No = std::false_type;
+        if constexpr (X3) {
+            if (nchunks == 1) chunk_lat(K3{}, K3{}, Yes{}, Yes{});
+            else {
+                chunk_lat(K3{}, K3{}, Yes{}, No{});
+                for (int ck = 1; ck + 1 < nchunks; ++ck) chunk_lat(K3{}, K3{}, No{}, No{});
+                chunk_lat(K3{}, K3{}, No{}, Yes{});
+            }
+        } else {
+            // (H, Q) pairs: nchunks is even
+            chunk_lat(KH{}, KQ{}, Yes{}, No{});
+            for (int ck = 2; ck < nchunks; ck += 2) {
+                chunk_lat(KQ{}, KH{}, No{}, No{});
+                chunk_lat(KH{}, KQ{}, No{}, No{});
+            }
+            chunk_lat(KQ{}, KH{}, No{}, Yes{});
+        }
+    } else {
+        using J0 = std::integral_constant<int, 0>;
+        // every image of the group through one chunk
+        auto stages = [&](auto kind_tag, int ck) __attribute__((always_inline)) {
+            chunk(kind_tag, ck, J0{});
+            if constexpr (NJ > 1) chunk(kind_tag, ck, std::integral_constant<int, 1>{});
+            if constexpr (NJ > 2) chunk(kind_tag, ck, std::integral_constant<int, 2>{});
+            if constexpr (NJ > 3) chunk(kind_tag, ck, std::integral_constant<int, 3>{});
+        };
+        if constexpr (X3) {
+            for (int ck = 0; ck < nchunks; ++ck) stages(K3{}, ck);
+        } else if constexpr (XQ) {
+            for (int ck = 0; ck < nchunks; ck += 5) {
+#pragma unroll 1
+                for (int h = 0; h < 4; ++h) chunk(KH{}, ck + h, J0{});     // H, L, H, L: the same code, other weights
+                chunk(KQ{}, ck + 4, J0{});
+            }
+        } else {
+            for (int ck = 0; ck + 1 < nchunks; ck += 2) {
+                stages(KH{}, ck);
+                stages(KQ{}, ck + 1);
+            }
+            if constexpr (NSRC2 && AR == 0) {
+                if (nchunks & 1) chunk(KT{}, nchunks - 1, J0{});
+            }
+        }
+    }
+
+    MX_TL(6);                            // taps done
+    using AllBlocks = std::integral_constant<int, -1>;
+    bool parked = false;
+    if constexpr (DEFER) {
+        // not the workgroup's last tile: park the sums; their epilogue runs inside the next tile's first chunk
+        if (defer_ok && next_n < a.n) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) accP[i][j] = accs[0][i][j];
+            n_prev = n;
+            parked = true;
+        }
+    }
+    if (!parked) {
+        epilogue_of(std::integral_constant<int, 0>{}, AllBlocks{});
+        if constexpr (NJ > 1) epilogue_of(std::integral_constant<int, 1>{}, AllBlocks{});
+        if constexpr (NJ > 2) epilogue_of(std::integral_constant<int, 2>{}, AllBlocks{});
+        if constexpr (NJ > 3) epilogue_of(std::integral_constant<int, 3>{}, AllBlocks{});
+    }
+    dma_waited = !parked;
     MX_TL(9);                            // stores issued
     gbuf ^= 1;
     n = next_n;

@@ -676,190 +676,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
-// ---- attention on the matrix cores: long token sequences (--no_resize sizes; transformer2d.py:52-60 through nn.MultiheadAttention) ----
-// attention_kernel above spends ~17 VALU issue slots per score (8 packed FMAs for the two contractions, max, exp, sums) and is VALU-bound;
-// at 16 384 tokens (2048 x 2048 input) the two stacks are a third of the forward.  Here both contractions run on fp32 MFMAs and the VALU keeps
-// max / subtract / exp / row sum (~7 slots per score):
-//   * S^T = K Q^T per 32-key x 32-query tile as four v_mfma_f32_32x32x2_f32 (d_head = 8 = 4 x K 2): rows = keys, columns = queries, so a lane
-//     (column = lane % 32, half = lane / 32) holds ONE query's scores against the 16 keys 8 (r / 4) + 4 half + r % 4, r = its register index.
-//   * P V as v_mfma_f32_4x4x1_16B_f32: 16 independent 4 x 4 x 1 products per instruction, block b = lanes 4 b .. 4 b + 3.  With A = P (a lane's
-//     own probability of key r: the S^T accumulator register IN PLACE, no movement between the accumulator and the operand layout) and B = V of
-//     that key (dims 4 h + lane % 4), block b accumulates O[queries 4 (b % 8) .. + 3][dims 4 h .. + 3] over the keys of half b / 8: every one of the
-//     256 multiply-adds of an instruction is a useful one, where a 16 x 16 x 4 or 32 x 32 x 2 tile would carry d_head = 8 in 16 / 32 output columns
-//     (tools/mfma_4x4x1_probe.hip pins the layout and this data flow; profiles/r05_mfma_4x4x1_probe.txt).  32 instructions of 8 cycles per tile
-//     next to the 4 x 64 of S^T: 0.375 matrix-pipe cycles per score and SIMD.
-//   * K chunks sit in LDS as [half][key] float4 (dims {half, 2 + half, 4 + half, 6 + half}: one conflict-free ds_read_b128 per tile), V chunks
-//     TRANSPOSED, [dim][key] with rows 8 floats apart in bank phase: a lane's V operands of 4 consecutive keys are one ds_read_b128 (8 per tile,
-//     shared by the wave's QW query tiles).  The next chunk's global loads are in flight under the current chunk's tiles.
-//   * online softmax per (query, key half): running maximum in the log2 domain (q carries log2 e, p = v_exp_f32(s - m)); the accumulators are
-//     rescaled only when some lane's maximum moved (wave-uniform branch; the factors reach the 4 x 4 blocks through DPP quad broadcasts); the two
-//     key halves of a query merge at the end with one cross-half shuffle.
-// Same mathematics as attention_kernel in another summation order: results agree to fp32 rounding (~1e-7 relative), not bit for bit, so the
-// choice between the two depends on the token count ALONE (never on the batch size): an image's result does not depend on its batch.
-#ifndef AM_ABL
-#define AM_ABL 0            // diagnostic builds (timing only, results wrong): bit 0 = no P V MFMAs, bit 1 = no softmax arithmetic, bit 2 = no K Q^T MFMAs
-#endif
-constexpr int AM_KCH = 256;               // keys per staged chunk
-constexpr int AM_VTS = AM_KCH + 8;        // floats per row of the transposed V chunk
-
-template <int SEL>
-__device__ __forceinline__ float quad_bcast(float x) {     // lane (l & ~3) + SEL's value, in every lane of the quad
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), SEL * 0x55, 0xf, 0xf, false));
-}
-
-// QW: 32-query tiles per wave (2: the K / V fragments of a key tile serve 64 queries; 1: twice the workgroups for small grids)
-// NW: waves per workgroup = how many share a staged chunk (4; 2 where a grid of four-wave workgroups would leave CUs idle)
-template <int QW, int NW>
-__global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                             const float* __restrict__ v, float* out, int L) {
-    __shared__ float4 sK[2][AM_KCH];
-    __shared__ __attribute__((aligned(16))) float sVT[8][AM_VTS];
-    const int head = blockIdx.y, img = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qn = lane & 31, hk = lane >> 5, j4 = lane & 3;
-    const size_t base = (size_t)img * L * 64 + head * 8;
-    const int q0 = (blockIdx.x * NW + wave) * (32 * QW);
-    const bool active = q0 < L;                               // (wave-uniform; an idle wave still stages its share of every chunk)
-    constexpr int NTHR = 64 * NW, KPT = AM_KCH / NTHR;        // keys per thread and chunk
-    constexpr float LOG2E = 1.4426950408889634f;
-    float qb[QW][4];
-#pragma unroll
-    for (int w = 0; w < QW; ++w) {
-        const int qi = min(q0 + 32 * w + qn, L - 1);          // clamp: the extra lanes compute a duplicate that is not stored
-        const float4 a = *reinterpret_cast<const float4*>(q + base + (size_t)qi * 64);
-        const float4 b = *reinterpret_cast<const float4*>(q + base + (size_t)qi * 64 + 4);
-        qb[w][0] = (hk ? a.y : a.x) * LOG2E; qb[w][1] = (hk ? a.w : a.z) * LOG2E;
-        qb[w][2] = (hk ? b.y : b.x) * LOG2E; qb[w][3] = (hk ? b.w : b.z) * LOG2E;
-    }
-    float m[QW], l[QW];
-    f32x4 o[QW][2];
-#pragma unroll
-    for (int w = 0; w < QW; ++w) {
-        m[w] = -INFINITY; l[w] = 0.f;
-        o[w][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[w][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // the chunk in flight: thread t carries keys c0 + t + i NTHR (zeros beyond L: a masked key's p = 0 must not meet a NaN)
-    float4 pk0[KPT], pk1[KPT], pv0[KPT], pv1[KPT];
-    auto fetch = [&](int c0) {
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int key = c0 + tid + i * NTHR;
-            const float4 z = {0.f, 0.f, 0.f, 0.f};
-            pk0[i] = pk1[i] = pv0[i] = pv1[i] = z;
-            if (key < L) {
-                pk0[i] = *reinterpret_cast<const float4*>(k + base + (size_t)key * 64);
-                pk1[i] = *reinterpret_cast<const float4*>(k + base + (size_t)key * 64 + 4);
-                pv0[i] = *reinterpret_cast<const float4*>(v + base + (size_t)key * 64);
-                pv1[i] = *reinterpret_cast<const float4*>(v + base + (size_t)key * 64 + 4);
-            }
-        }
-    };
-    fetch(0);
-    for (int c0 = 0; c0 < L; c0 += AM_KCH) {
-        __syncthreads();                                      // every wave has read the previous chunk
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int kk = tid + i * NTHR;
-            sK[0][kk] = float4{pk0[i].x, pk0[i].z, pk1[i].x, pk1[i].z};
-            sK[1][kk] = float4{pk0[i].y, pk0[i].w, pk1[i].y, pk1[i].w};
-            sVT[0][kk] = pv0[i].x; sVT[1][kk] = pv0[i].y; sVT[2][kk] = pv0[i].z; sVT[3][kk] = pv0[i].w;
-            sVT[4][kk] = pv1[i].x; sVT[5][kk] = pv1[i].y; sVT[6][kk] = pv1[i].z; sVT[7][kk] = pv1[i].w;
-        }
-        __syncthreads();
-        if (c0 + AM_KCH < L) fetch(c0 + AM_KCH);
-        if (!active) continue;
-        const int nk = min(AM_KCH, L - c0);
-        for (int t0 = 0; t0 < nk; t0 += 32) {
-            const float4 kf = sK[hk][t0 + qn];
-            float4 vf[4][2];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) vf[q4][h] = *reinterpret_cast<const float4*>(&sVT[4 * h + j4][t0 + 8 * q4 + 4 * hk]);
-#pragma unroll
-            for (int w = 0; w < QW; ++w) {
-                f32x16 s;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#if AM_ABL & 4
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[e] = kf.x * qb[w][e & 3];
-#else
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qb[w][0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qb[w][1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qb[w][2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qb[w][3], s, 0, 0, 0);
-#endif
-                if (t0 + 32 > nk) {                           // the sequence's last, partial tile (wave-uniform)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (t0 + 8 * (r >> 2) + 4 * hk + (r & 3) >= nk) s[r] = -INFINITY;
-                }
-#if !(AM_ABL & 2)
-                float tm = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-                for (int r = 3; r < 15; r += 2) tm = fmaxf(fmaxf(tm, s[r]), s[r + 1]);
-                tm = fmaxf(tm, s[15]);
-                const float mn = fmaxf(m[w], tm);
-                if (__ballot(mn > m[w]) != 0ull) {
-                    // some lane's maximum moved: rescale (alpha = 1 where it did not; a half that has seen no key yet keeps m = -inf, and 0)
-                    const float alpha = __builtin_amdgcn_exp2f(m[w] - (mn == -INFINITY ? 0.f : mn));
-                    l[w] *= alpha;
-                    const float a0 = quad_bcast<0>(alpha), a1 = quad_bcast<1>(alpha), a2 = quad_bcast<2>(alpha), a3 = quad_bcast<3>(alpha);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) { o[w][h][0] *= a0; o[w][h][1] *= a1; o[w][h][2] *= a2; o[w][h][3] *= a3; }
-                    m[w] = mn;
-                }
-                const float mu = m[w] == -INFINITY ? 0.f : m[w];
-                float ls = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[r] = __builtin_amdgcn_exp2f(s[r] - mu);
-                    ls += s[r];
-                }
-                l[w] += ls;
-#else
-                l[w] += s[0];
-#endif
-#if AM_ABL & 1
-                o[w][0][0] += s[3] + s[7] + vf[0][0].x; o[w][1][1] += s[5] + s[12] + vf[3][1].w;
-#else
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v0 = e == 0 ? vf[q4][0].x : (e == 1 ? vf[q4][0].y : (e == 2 ? vf[q4][0].z : vf[q4][0].w));
-                        const float v1 = e == 0 ? vf[q4][1].x : (e == 1 ? vf[q4][1].y : (e == 2 ? vf[q4][1].z : vf[q4][1].w));
-                        o[w][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(s[4 * q4 + e], v0, o[w][0], 0, 0, 0);
-                        o[w][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(s[4 * q4 + e], v1, o[w][1], 0, 0, 0);
-                    }
-                }
-#endif
-            }
-        }
-    }
-    if (!active) return;
-    // merge the two key halves of every query (lanes l and l ^ 32), normalise, store: lane (quad g = (lane / 4) % 8, j4, half) holds
-    // O[q0 + 32 w + 4 g + i][4 h + j4], i = register, and writes the dims of h = its half
-#pragma unroll
-    for (int w = 0; w < QW; ++w) {
-        const float mt = fmaxf(m[w], __shfl_xor(m[w], 32));
-        const float a = m[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m[w] - mt);
-        float lt = l[w] * a;
-        lt += __shfl_xor(lt, 32);
-        const float f = a / lt;
-        const float f0 = quad_bcast<0>(f), f1 = quad_bcast<1>(f), f2 = quad_bcast<2>(f), f3 = quad_bcast<3>(f);
-        const float fi[4] = {f0, f1, f2, f3};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float x0 = o[w][0][i] * fi[i], x1 = o[w][1][i] * fi[i];
-            x0 += __shfl_xor(x0, 32); x1 += __shfl_xor(x1, 32);
-            const int qi = q0 + 32 * w + 4 * ((lane >> 2) & 7) + i;
-            if (qi < L) out[base + (size_t)qi * 64 + 4 * hk + j4] = hk ? x1 : x0;
-        }
-    }
-}
-
 // ---- k-means + anchors: one workgroup per image ------------------------------------------------------------------
 // Lloyd iterations exactly as clusterkit.py:112-208 (first-minimum assignment, empty clusters take fallback rows in
 // cluster order, stop on (sum of centre shifts)^2 < 1e-4 or 20 passes, assignment of the last distance pass) followed
@@ -2066,15 +1882,8 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         if (dbg) (*dbg)(qkv, (size_t)3 * T * 64 * 4);
         // from attention_mfma_min_tokens() tokens on: both contractions on the matrix cores.  The choice depends on the token count alone.
         if (l >= attention_mfma_min_tokens()) {
-            const long cus = num_cus_current();
-            const float *qp = qkv, *kp = qkv + (size_t)T * 64, *vp = qkv + (size_t)2 * T * 64;
-            // the largest workgroup (and most queries per K / V fragment) that still gives every CU two workgroups
-            if ((long)cdiv(l, 256) * N_HEAD * n >= 2 * cus)
-                hipLaunchKernelGGL((attention_mfma_kernel<2, 4>), dim3(cdiv(l, 256), N_HEAD, n), dim3(256), 0, s, qp, kp, vp, att, l);
-            else if ((long)cdiv(l, 128) * N_HEAD * n >= 2 * cus)
-                hipLaunchKernelGGL((attention_mfma_kernel<1, 4>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, qp, kp, vp, att, l);
-            else
-                hipLaunchKernelGGL((attention_mfma_kernel<1, 2>), dim3(cdiv(l, 64), N_HEAD, n), dim3(128), 0, s, qp, kp, vp, att, l);
+            const int rc = launch_attention_mfma(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s);
+            if (rc) return rc;
         } else
         // (beyond one workgroup per CU the two forms run the same: n = 2 ... 16 images measured with the threshold at 1x, 2x, 5x, 9x the CU count)
         if ((long)cdiv(l, 64) * N_HEAD * n < num_cus_current())
