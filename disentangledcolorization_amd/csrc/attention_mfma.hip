@@ -43,7 +43,7 @@ __device__ __forceinline__ float quad_bcast(float x) {     // lane (l & ~3) + SE
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), SEL * 0x55, 0xf, 0xf, false));
 }
 
-// QW: 32-query tiles per wave (2: the K / V fragments of a key tile serve 64 queries; 1: twice the workgroups for small grids)
+// QW: 32-query tiles per wave (the launcher takes 1: the QW = 2 form shares the K / V fragments of a key tile between 64 queries but runs two waves per SIMD)
 // NW: waves per workgroup = how many share a staged chunk of 128 NW keys (4; 2 where a grid of four-wave workgroups would leave CUs idle)
 //
 // Schedule.  MFMA and VALU instructions of a SIMD share one issue port, and two waves running the same code ask for the same pipe at the same
@@ -285,14 +285,16 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
 
 // softmax(q k^T) v per (image, head); q, k, v, out: (n, l, 64) fp32, head h in columns 8 h .. 8 h + 7; q pre-scaled by 1 / sqrt(8)
 int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s) {
-    const long cus = num_cus_current();
-    // the largest workgroup (and most queries per K / V fragment) that still gives every CU two workgroups; below that the waves of a
-    // workgroup split the keys of 32 queries (four times the waves per query).  DISCO_ATTN_FORM = 1 / 2 / 3 forces a form (measurements)
+    // One 32-query tile per wave (126 VGPRs: four waves per SIMD; the QW = 2 form - 216 VGPRs, two waves per SIMD - measured 5-25 % slower at every
+    // size, profiles/r05_attn_mfma_ab.txt "forms").  Two forms: (2) workgroups of four query tiles sharing the staged chunks; (3) the four waves of
+    // a workgroup split the KEYS of one query tile (four times the waves per query: what one image of up to 2 048 tokens needs to fill the GPU).
+    // The forms differ in their summation order (fp32 rounding), so the choice depends on the TOKEN COUNT ALONE - never on the batch size: an
+    // image's result does not depend on the batch it is part of (test_batch_of_64_at_512_crosses_the_addressing_limit caught a grid-size rule).
+    // Up to 2 048 tokens form 3 (one image: 24 / 33 us per layer at 1 024 / 1 536 tokens against 33 / 42 in form 2; eight images at 1 536: 113
+    // against 97 - still under attention_kernel's 138), beyond it form 2.  DISCO_ATTN_FORM = 2 / 3 forces a form (measurements only).
     static const int forced = [] { const char* e = std::getenv("DISCO_ATTN_FORM"); return e ? atoi(e) : 0; }();
-    const int form = forced ? forced : ((long)cdiv(l, 256) * N_HEAD * n >= 2 * cus ? 1 : ((long)cdiv(l, 128) * N_HEAD * n >= 2 * cus ? 2 : 3));
-    if (form == 1)
-        hipLaunchKernelGGL((attention_mfma_kernel<2, 4, false>), dim3(cdiv(l, 256), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l);
-    else if (form == 2)
+    const int form = forced ? forced : (l > 2048 ? 2 : 3);
+    if (form == 2)
         hipLaunchKernelGGL((attention_mfma_kernel<1, 4, false>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l);
     else
         hipLaunchKernelGGL((attention_mfma_kernel<1, 4, true>), dim3(cdiv(l, 32), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l);

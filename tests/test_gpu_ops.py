@@ -326,6 +326,28 @@ def test_attention_on_the_matrix_cores_matches_oracle_and_the_valu_kernel(H, syn
         assert (a - b).abs().max().item() < 1e-5, (case, n, l)
 
 
+@pytest.mark.parametrize("hw", [(16, 16), (32, 32), (32, 48), (48, 48), (64, 64)])
+def test_encoder_stack_result_does_not_depend_on_the_batch(H, synth_sd, hw):
+    """An image's tokens come out of the stack bit for bit the same alone and as one of 9 images - at 256 tokens (attention_kernel, whose
+    query tiling follows the grid size) and at 1 024 ... 4 096 (attention_mfma_kernel, whose form follows the token count alone: a rule by
+    grid size gave different roundings to the same image in a batch of 64 and alone)."""
+    h, w = hw
+    l = h * w
+    x = torch.randn(9, l, 64, generator=g(5 * l))
+    pos = R.position_encoding(h, w).flatten(1).t().contiguous()
+    wts = _encoder_weights(synth_sd, "wildpath").to(H.DEV)
+    outs = []
+    for n in (1, 9):
+        xd, pd = x[:n].contiguous().to(H.DEV), pos.to(H.DEV)
+        out = torch.empty_like(xd)
+        ws = torch.empty(n * l * 384 * 4 + 256 + (4 << 20), device=H.DEV, dtype=torch.uint8)
+        _ffi.check(_ffi.lib().disco_op_encoder_stack(_ffi.ptr(xd), _ffi.ptr(pd), _ffi.ptr(wts), _ffi.ptr(out), n, l,
+                                                     _ffi.ptr(ws), ws.numel(), H.stream()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
 def _kmeans_gpu(H, x, sizes, init, fallback, k, d=64, channel_major=0):
     n, l = x.shape[0], (x.shape[2] if channel_major else x.shape[1])
     xd, sd_ = x.to(H.DEV).contiguous(), sizes.to(H.DEV).contiguous()

@@ -18,6 +18,8 @@ python $R/tools/profile_layers.py > $O/final_layers.txt 2>&1
 python $R/tools/operating_points.py > $O/operating_points.txt 2>&1
 python $R/tools/profile_layers.py --batch 1 > $O/final_layers_n1.txt 2>&1
 python $R/tools/kmeans_latency.py > $O/kmeans_latency.txt 2>&1
+(cd $R && tools/build/mfma_4x4x1_probe) > $O/mfma_4x4x1_probe.txt 2>&1
+{ echo "== attention_kernel (DISCO_ATTN_MFMA=0)"; DISCO_ATTN_MFMA=0 python $R/tools/attn_ab.py 2>&1 | grep tokens; echo "== attention_mfma_kernel (default from 1 024 tokens)"; python $R/tools/attn_ab.py 2>&1 | grep tokens; } > $O/attn_final.txt 2>&1
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/final_kernel_stats.csv
 # keep the merged output small: drop the raw traces
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
