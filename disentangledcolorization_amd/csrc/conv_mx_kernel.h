@@ -53,7 +53,7 @@
 #define MX_QFMT 0       // operand format of the K = 64 correction MFMA: 0 = fp8 e4m3.  2 (fp6 e2m3) / 4 (fp4): SPEED EXPERIMENTS ONLY - the data stay fp8 bytes
 #endif
 #ifndef MX_ABL
-#define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh; bit 4 = no output stores): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk,
+#define MX_ABL 0        // diagnostic builds (tools/build_ablations.sh; bit 4 = no output stores, bit 5 = no epilogue, bit 6 = the latency loop on half the chunks): bit 0 = no LDS-DMA after the first chunk, bit 1 = fragments read once per chunk,
                         // bit 2 = no PIXEL pieces after the first chunk, bit 3 = no WEIGHT pieces after the first chunk
 #endif
 
@@ -263,7 +263,14 @@ __global__ __launch_bounds__((WM * WN + (NB == 3 ? 4 : 0)) * 64, 2) void conv3x3
     MX_TL(12);                           // kernel entry
 #endif
     const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+#if MX_ABL & 64
+    // ablation (timing only): the latency loop walks HALF of a long accumulation chain - what a launch would take if two workgroups per tile each
+    // summed half of the chunks ("Next" (i)); results wrong by design
+    const int nchunks_full = XQ ? (a.c_in >> 6) * 5 : a.c_in >> 4;
+    const int nchunks = (NB == 3 && nchunks_full >= 16) ? nchunks_full >> 1 : nchunks_full;
+#else
     const int nchunks = XQ ? (a.c_in >> 6) * 5 : a.c_in >> 4;    // two chunks (H, Q) per 32 input channels; XQ: H L H L Q per 64; X3: one per 16
+#endif
 
     int bid = blockIdx.x;
     int tx, ty, by;
