@@ -62,7 +62,10 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
     __shared__ float4 sK[2][KCH];
     __shared__ __attribute__((aligned(16))) float sVT[8][VTS];
     const int head = blockIdx.y, img = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (a scalar: the tile addresses of the key-split form stay in SGPRs - 166 -> 126 VGPRs, four waves per SIMD there as well: eight images of
+    // 1 536 tokens 111 -> 105 us per layer, sixteen of 1 024: 105 -> 97)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qn = lane & 31, hk = lane >> 5, j4 = lane & 3;
     const size_t base = (size_t)img * L * 64 + head * 8;
     const int q0 = (KS ? blockIdx.x : blockIdx.x * NW + wave) * (32 * QW);
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
         if (wave > 0) return;
 #pragma unroll
         for (int w = 0; w < QW; ++w)
+#pragma unroll 1
             for (int u = 1; u < NW; ++u) {
                 const float* d = xch + ((size_t)((u - 1) * QW + w) * 10) * 64 + lane;
                 const float mo = d[0], lo = d[64];
