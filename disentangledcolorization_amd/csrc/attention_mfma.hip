@@ -12,7 +12,7 @@ namespace disco {
 namespace {
 
 // ---- attention on the matrix cores: long token sequences (--no_resize sizes; transformer2d.py:52-60 through nn.MultiheadAttention) ----
-// attention_kernel above spends ~17 VALU issue slots per score (8 packed FMAs for the two contractions, max, exp, sums) and is VALU-bound;
+// attention_kernel (tokens.hip: fewer than 1 024 tokens) spends ~17 VALU issue slots per score (8 packed FMAs for the two contractions, max, exp, sums) and is VALU-bound;
 // at 16 384 tokens (2048 x 2048 input) the two stacks are a third of the forward.  Here both contractions run on fp32 MFMAs and the VALU keeps
 // max / subtract / exp / row sum (~7 slots per score):
 //   * S^T = K Q^T per 32-key x 32-query tile as four v_mfma_f32_32x32x2_f32 (d_head = 8 = 4 x K 2): rows = keys, columns = queries, so a lane
@@ -43,15 +43,17 @@ __device__ __forceinline__ float quad_bcast(float x) {     // lane (l & ~3) + SE
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), SEL * 0x55, 0xf, 0xf, false));
 }
 
-// QW: 32-query tiles per wave (the launcher takes 1: the QW = 2 form shares the K / V fragments of a key tile between 64 queries but runs two waves per SIMD)
-// NW: waves per workgroup = how many share a staged chunk of 128 NW keys (4; 2 where a grid of four-wave workgroups would leave CUs idle)
+// QW: 32-query tiles per wave (the launcher takes 1: the QW = 2 form shares the K / V fragments of a key tile between 64 queries but needs 216
+//     VGPRs = two waves per SIMD, and measured 5-25 % slower than four waves of one tile each)
+// NW: waves per workgroup = how many share a staged chunk of 128 NW keys (the launcher takes 4)
 //
-// Schedule.  MFMA and VALU instructions of a SIMD share one issue port, and two waves running the same code ask for the same pipe at the same
-// time (measured: the first version, tile after tile, ran at the SUM of its three parts - profiles/r05_attn_mfma_ab.txt "ablations"), so the
-// overlap is built into the instruction stream of ONE wave: step t issues the four K Q^T MFMAs of tile t + 1 (64 cycles each, one issue slot)
-// with tile t's subtract / exp / add between them, then tile t's 32 P V MFMAs (8 cycles each) with the row maxima of tile t + 1 between them;
-// two named score sets alternate (static indexing).  A tile's mask (the sequence's last, partial tile) and the running-maximum update with its
-// rare rescale run between the steps.
+// Schedule.  MFMA and VALU instructions of a SIMD share one issue port, and waves running the same code ask for the same pipe at the same
+// time: the first version (tile after tile) ran at nearly the SUM of its three parts (profiles/r05_attn_mfma_ab.txt, the AM_ABL builds).
+// The instruction stream is software-pipelined - step t issues the four K Q^T MFMAs of tile t + 1 (64 cycles each, one issue slot) with tile
+// t's subtract / exp / add between them, then tile t's 32 P V MFMAs (8 cycles each) and the row maxima of tile t + 1; two named score sets
+// alternate (static indexing); a tile's mask (the sequence's last, partial tile) and the running-maximum update with its rare rescale run
+// between the steps - which by itself measured +-0 against the plain order (939 vs 943 us per layer at 16 384 tokens); what pays is
+// occupancy: 126 VGPRs, four waves per SIMD (851 us), which this form keeps because a tile's scores die into the P V operands in place.
 // KS: the waves of a workgroup split the KEYS of 32 QW queries (wave u takes the key tiles u, u + NW, ... of every chunk) and merge their partial
 // (maximum, sum, O) through LDS at the end: NW times the waves per query where the plain form cannot fill the GPU (one image)
 template <int QW, int NW, bool KS>
