@@ -74,6 +74,9 @@ __global__ __launch_bounds__(256) void upfeat_kernel(const float* __restrict__ t
 // TOK_LDS (round 5, grids that do not fill the GPU): the nine token rows are fetched ONCE, with one vector load per thread, into LDS and read
 // from there as broadcasts.  The scalar loads of the other variant are issued trip by trip (576 floats do not fit the 102 SGPRs), so a
 // workgroup alone on its CU sits out eight scalar-cache round trips one after the other: 38 us for the 256 cells of one 256 x 256 image.
+// (accesses of different types to one byte array: may_alias types, so that type-based alias analysis has no say in their order either)
+typedef f16x8 __attribute__((may_alias)) f16x8_a;
+typedef uint4 __attribute__((may_alias)) uint4_a;
 template <bool TOK_LDS>
 __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restrict__ tok, const float* __restrict__ prob, int prob_rep,
                                                           f16* out_act, long out_plane, long q_off, int sexp, unsigned int* sat_out,
@@ -119,13 +122,24 @@ __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restric
     unsigned char* tr = s_tr[wave];
     const float sc = ldexpf(1.f, sexp), qls = ldexpf(1.f, MX_LO_SHIFT);
     // dense store of the 2 KiB in `tr` (4 rows x 16 pixels x 32 bytes) to plane base `dst` (byte address of pixel 0 of the image's block)
+    // The lanes of a wave exchange data through `tr` without a barrier instruction (LDS operations of a wave execute in order) - which the
+    // COMPILER has to be told: for one thread the writes (tr + 32 lane + ...) and the reads (tr + 1024 h2 + 16 lane) provably do not overlap, so it
+    // may interleave them.  It did, the moment qa / ql left scratch memory (a ds_read_b128 of the row image between the two ds_write_b128 that
+    // complete it: pred_colors wrong by 0.97, caught by the output hashes of tools/small_batch_latency.py); before that the order held by luck.
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto store_rows = [&](unsigned char* dst) {
+        wave_sync();                       // the row image is complete
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-            const uint4 v = *reinterpret_cast<const uint4*>(tr + h2 * 1024 + lane * 16);
+            const uint4 v = *reinterpret_cast<const uint4_a*>(tr + h2 * 1024 + lane * 16);
             const int row = cy * 16 + wave * 4 + h2 * 2 + (lane >> 5);
             *reinterpret_cast<uint4*>(dst + ((long)row * W + cx * 16) * 32 + (lane & 31) * 16) = v;
         }
+        wave_sync();                       // ... and read before it is rewritten
     };
     unsigned char* const base = reinterpret_cast<unsigned char*>(out_act);
     uint2 qa[4], ql[4];                                                     // a8 / al8 of the current 32-channel block (8 channels per trip)
@@ -153,14 +167,14 @@ __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restric
         for (int j = 0; j < 8; ++j) { v[j] = acc[j] * sc; h[j] = (f16)v[j]; lo[j] = v[j] - (float)h[j]; l[j] = (f16)lo[j]; }
         const int blk = hb >> 1, half = hb & 1;
         // (LDS operations of a wave execute in order: a row image is complete when store_rows reads it, and read before it is rewritten)
-        *reinterpret_cast<f16x8*>(tr + lane * 32 + half * 16) = h;
+        *reinterpret_cast<f16x8_a*>(tr + lane * 32 + half * 16) = h;
         if (half == 0) lpark = l;
         else {
             unsigned char* hb_base = base + (((long)img * nblk + blk) * HW) * 32;
             store_rows(hb_base);
             if (out_plane) {
-                *reinterpret_cast<f16x8*>(tr + lane * 32) = lpark;
-                *reinterpret_cast<f16x8*>(tr + lane * 32 + 16) = l;
+                *reinterpret_cast<f16x8_a*>(tr + lane * 32) = lpark;
+                *reinterpret_cast<f16x8_a*>(tr + lane * 32 + 16) = l;
                 store_rows(hb_base + out_plane * 2);
             }
         }
@@ -168,14 +182,18 @@ __global__ __launch_bounds__(256) void upfeat_cell_kernel(const float* __restric
             uint2 a, b;
             b.x = pack_fp8x4(lo[0] * qls, lo[1] * qls, lo[2] * qls, lo[3] * qls, &sat); b.y = pack_fp8x4(lo[4] * qls, lo[5] * qls, lo[6] * qls, lo[7] * qls, &sat);
             a.x = pack_fp8x4(v[0], v[1], v[2], v[3], &sat); a.y = pack_fp8x4(v[4], v[5], v[6], v[7], &sat);
-            qa[hb & 3] = a; ql[hb & 3] = b;
+            // (statically indexed: `qa[hb & 3] = a` put both arrays into scratch memory - 48 bytes per lane written and read back per pixel next to
+            // the 256 bytes of output)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((hb & 3) == k) { qa[k] = a; ql[k] = b; }
             if ((hb & 3) == 3) {
                 unsigned char* qb = base + q_off + (((long)img * (nblk >> 1) + (blk >> 1)) * 2) * HW * 32;
-                *reinterpret_cast<uint4*>(tr + lane * 32) = uint4{qa[0].x, qa[0].y, qa[1].x, qa[1].y};
-                *reinterpret_cast<uint4*>(tr + lane * 32 + 16) = uint4{qa[2].x, qa[2].y, qa[3].x, qa[3].y};
+                *reinterpret_cast<uint4_a*>(tr + lane * 32) = uint4{qa[0].x, qa[0].y, qa[1].x, qa[1].y};
+                *reinterpret_cast<uint4_a*>(tr + lane * 32 + 16) = uint4{qa[2].x, qa[2].y, qa[3].x, qa[3].y};
                 store_rows(qb);
-                *reinterpret_cast<uint4*>(tr + lane * 32) = uint4{ql[0].x, ql[0].y, ql[1].x, ql[1].y};
-                *reinterpret_cast<uint4*>(tr + lane * 32 + 16) = uint4{ql[2].x, ql[2].y, ql[3].x, ql[3].y};
+                *reinterpret_cast<uint4_a*>(tr + lane * 32) = uint4{ql[0].x, ql[0].y, ql[1].x, ql[1].y};
+                *reinterpret_cast<uint4_a*>(tr + lane * 32 + 16) = uint4{ql[2].x, ql[2].y, ql[3].x, ql[3].y};
                 store_rows(qb + HW * 32);
             }
         }
