@@ -1,9 +1,14 @@
 #!/usr/bin/env python
 """Headline benchmark: colorized 256x256 images/s of the DISCO hot path on N MI355X (BASELINE.json).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps 10 --warmup 3 [--config 2|3|5a|5b]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+Either launch works: started WITHOUT a launcher's environment (no WORLD_SIZE) and with --gpus N > 1, bench.py starts its own N ranks
+(one process per GPU, LOCAL_RANK -> device, RCCL rendezvous on 127.0.0.1 and a free port - the launch convention of the reference's
+main/utils_train.py:221-241 `init_dist`, which reads RANK / WORLD_SIZE the same way), passes rank 0's single JSON line through and
+exits with the first failing rank's code (the other ranks are stopped by PID, so a dead rank cannot leave the job hanging in a collective).
 
 One step = one forward of AnchorColorProb (test mode, K=8 clustering anchors, all six outputs produced) over a
 batch of 64 synthetic 256x256 L-channel images per GPU (BASELINE config 2), inputs resident in HBM, followed —
@@ -107,6 +112,9 @@ def fake_forward(gray, ab, T, idx, pos, fstream, fbases, want, out=None):
     mask = torch.zeros(n, h * w)
     mask.scatter_add_(1, torch.as_tensor(idx if idx is not None else pos, dtype=torch.long), torch.ones(n, d.shape[1]))
     mask = mask.reshape(n, 1, h, w)
+    if int(T) > 0:         # --diverse: three colorizations per image, image-major (model.py:148-159)
+        pred = torch.stack([pred * (1.0 - 0.25 * t) for t in range(3)], 1).flatten(0, 1)
+        mask = mask.repeat_interleave(3, 0)
     if out is not None:
         out[2].copy_(pred); out[5].copy_(mask)
         return out, (np.zeros(n, np.int32) if want else None)
@@ -222,8 +230,74 @@ def other_single_gpu_configs(model, sd, precision, sync):
     return out
 
 
+# The BASELINE.json configurations bench.py can time by name (--config).  "2" is the headline (the metric is quoted on it: weak scaling,
+# 64 images per GPU); the others fix the GLOBAL batch BASELINE names and shard it over however many GPUs run (strong scaling in --gpus).
+#   per_gpu / global_batch: images; k: anchors; T: sampled_T (> 0 = --diverse: three colorizations per image); random_hint
+CONFIGS = {
+    "2": dict(per_gpu=64, global_batch=0, k=8, T=0, random_hint=False, scaling="weak",
+              workload="BASELINE config 2: batch=64/GPU synthetic 256x256 L-channel, K=8 clustering anchors, forward only, synthetic checkpoint of the DISCO layout"),
+    "3": dict(per_gpu=0, global_batch=512, k=8, T=0, random_hint=False, scaling="strong",
+              workload="BASELINE config 3: global batch=512 synthetic 256x256 L-channel sharded over the GPUs (64 per GPU on 8), K=8 clustering anchors, "
+                       "synthetic checkpoint of the DISCO layout (the real one is not available offline), packed all-gather inside the timed region"),
+    "5a": dict(per_gpu=0, global_batch=256, k=16, T=1, random_hint=False, scaling="strong",
+               workload="BASELINE config 5 (a): global batch=256 synthetic 256x256 sharded over the GPUs, --diverse (three colorizations per image = 768 outputs), "
+                        "K=16 clustering anchors"),
+    "5b": dict(per_gpu=0, global_batch=256, k=16, T=0, random_hint=True, scaling="strong",
+               workload="BASELINE config 5 (b): global batch=256 synthetic 256x256 sharded over the GPUs, random_hint with K=16 host-drawn anchor positions per image "
+                        "(Python `random`, seed 130, global image order)"),
+}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, fake):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves - one process per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in its environment (what torch.distributed.run would set; the reference's init_dist, main/utils_train.py:221-241,
+    reads the same variables), rendezvous on 127.0.0.1 (the container hostname may not resolve) and a free port.  Every rank inherits this
+    process's stdout: only rank 0 writes to it (the one JSON line).  Returns the exit code: 0, or the first failing rank's - the remaining
+    ranks are terminated by PID when one dies, so a failure never turns into a hang inside a collective."""
+    import subprocess
+    if not fake and os.environ.get("DISCO_DIST_BACKEND", "nccl") == "nccl":
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench: --gpus %d asks for %d devices, this node shows %d (RCCL wants one device per rank)" % (n, n, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()), WORLD_SIZE=str(n),
+               LOCAL_WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("bench: rank %d exited with code %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr)
+                    for q in live:
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS), help="the BASELINE.json configuration to time (default 2: the one the metric is quoted on); "
+                    "3 / 5a / 5b fix the global batch (512 / 256 / 256) and shard it over --gpus")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -250,6 +324,9 @@ def main():
         from disentangledcolorization_amd.model import default_precision
         args.precision = default_precision()
     fake = os.environ.get("DISCO_BENCH_FAKE") == "1"
+    cfg = CONFIGS[args.config]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, fake))
 
     # stdout carries exactly one JSON line: native libraries (RCCL's version banner, HIP runtime notices) write to fd 1
     # directly, so fd 1 points at stderr until the result is printed
@@ -259,8 +336,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher's WORLD_SIZE is %d (run `python bench.py --gpus N` without a launcher, or "
+                         "torch.distributed.run --nproc-per-node N with the same N)" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # DISCO_DIST_BACKEND=gloo (tests/test_gpu_dist.py): several ranks on ONE GPU - real forwards, streams and events on device tensors, the
     # collectives on gloo (RCCL wants a device per rank): the multi-rank code path on a single-GPU test box
@@ -278,17 +356,21 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     sync = (lambda: None) if fake else torch.cuda.synchronize
+    if fake and os.environ.get("DISCO_BENCH_FAIL_RANK") == str(rank):      # tests/test_dist_gloo.py: a rank that dies after the rendezvous
+        os._exit(7)
 
     from disentangledcolorization_amd import synth
     from disentangledcolorization_amd.runner import ShardedColorizer, shard_bounds
 
-    n_global = args.global_batch if args.global_batch > 0 else args.batch * world
+    K, T = cfg["k"], cfg["T"]
+    rep_out = 3 if T > 0 else 1
+    n_global = args.global_batch if args.global_batch > 0 else (cfg["global_batch"] or args.batch * world)
     lo, hi = shard_bounds(n_global, world, rank)
     gray_all, ab_all = synth.synth_inputs(n_global, args.size, args.size, seed=5)
     gray, ab = gray_all[lo:hi].to(dev), ab_all[lo:hi].to(dev)    # inputs resident in HBM before timing
     model = sd = None
     if fake:
-        runner = ShardedColorizer(fake_forward, n_clusters=8, micro_batches=1 if args.pipeline else args.micro, exact_fallback=False)
+        runner = ShardedColorizer(fake_forward, n_clusters=K, random_hint=cfg["random_hint"], micro_batches=1 if args.pipeline else args.micro, exact_fallback=False)
         # the timed loop's real configuration - steps pipelined over two (host stand-in) streams, results written in place, the packed
         # all-gather enqueued asynchronously behind each forward - so that the gloo tests run the code an 8-GPU node will run
         runner.out_capable = True
@@ -297,8 +379,8 @@ def main():
     else:
         from disentangledcolorization_amd.model import AnchorColorProb
         sd = synth.synth_state_dict(130)
-        model = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, n_clusters=8,
-                                enhanced=True, precision=args.precision, init_weights=False)
+        model = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, n_clusters=K,
+                                random_hint=cfg["random_hint"], enhanced=True, precision=args.precision, init_weights=False)
         model.load_state_dict(sd)
         model = model.cuda().eval()
         model.set_profiling(0)                    # the timed loop is the product: no event pairs around the launches
@@ -308,13 +390,14 @@ def main():
         runner.pipeline = bool(args.pipeline)
 
     def seed():
-        np.random.seed(130); torch.manual_seed(130)
+        import random
+        np.random.seed(130); torch.manual_seed(130); random.seed(130)
 
     def step():
         # batch k's all-gather is enqueued behind its forward and overlaps with batch k+1's convolutions; everything is
         # complete at the synchronize() that closes the timed region
         seed()
-        return runner.colorize(gray, ab, n_global, 0, gather=True, async_gather=True)
+        return runner.colorize(gray, ab, n_global, T, gather=True, async_gather=True)
 
     # initialisation (untimed, not counted as warm-up): the first forward creates the native context (weight fold / pack /
     # upload / calibration) and sizes the workspace; a second one lets clocks and the caching allocator settle
@@ -353,9 +436,9 @@ def main():
     if model is not None:
         exact = ShardedColorizer.from_model(model, exact_fallback=True, force_gather=force)
         seed()
-        p_exact, m_exact = exact.colorize(gray, ab, n_global, 0, gather=True)
+        p_exact, m_exact = exact.colorize(gray, ab, n_global, T, gather=True)
         sync()
-        events = int(exact.last_events.sum())
+        events = 0 if exact.last_events is None else int(exact.last_events.sum())      # (random hints: no k-means, no draws)
         same = bool(torch.equal(p_exact, last[0]) and torch.equal(m_exact, last[1]))
         from disentangledcolorization_amd import _ffi
         import ctypes
@@ -374,7 +457,7 @@ def main():
         single = ShardedColorizer.from_model(model, micro_batches=1, exact_fallback=False)
         for it in range(1 + prof_steps):           # the first one settles the clocks after the synchronised check above
             seed()
-            p_prof, m_prof = single.colorize(gray, ab, n_global, 0, gather=False)
+            p_prof, m_prof = single.colorize(gray, ab, n_global, T, gather=False)
             sync()
             if it == 0:
                 continue
@@ -385,7 +468,7 @@ def main():
                 stage_ms[name] = stage_ms.get(name, 0.0) + sms
         model.set_profiling(0)
         lo_r, hi_r = shard_bounds(n_global, world, rank)
-        if not (torch.equal(p_prof, last[0][lo_r:hi_r]) and torch.equal(m_prof, last[1][lo_r:hi_r])):
+        if not (torch.equal(p_prof, last[0][lo_r * rep_out:hi_r * rep_out]) and torch.equal(m_prof, last[1][lo_r * rep_out:hi_r * rep_out])):
             raise SystemExit("bench: the profiled single-stream forward differs from the timed one")
 
     if rank == 0:
@@ -393,7 +476,8 @@ def main():
         out = {
             "metric": "colorized 256x256 images/sec", "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if args.global_batch == 0 and cfg["scaling"] == "weak" else "strong",
             "vs_baseline": None,
             "dtype": {"mx6": "f16x3 (fp16 hi/lo split, 3 MFMA products) for SpixelNet+ColorProbNet; f16+fp6x2 (fp16 main product + two fp6 e2m3 "
                              "correction products in one K=64 MFMA) for HourGlass2; fp32 accumulate",
@@ -404,9 +488,8 @@ def main():
                       "mx8all": "f16+fp8x2 (fp16 main product + two fp8 e4m3 correction products), fp32 accumulate - not anchor-safe",
                       "f16x3": "f16x3 (fp16 hi/lo split operands, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: batch=64/GPU synthetic 256x256 L-channel, K=8 clustering anchors, "
-                                   "forward only, synthetic checkpoint of the DISCO layout", "images_per_gpu": args.batch,
-                       "global_batch": n_global, "image_size": args.size,
+            "config": {"workload": cfg["workload"], "name": args.config, "images_per_gpu": hi - lo,
+                       "global_batch": n_global, "colorizations_per_step": n_global * rep_out, "n_clusters": K, "image_size": args.size,
                        "parallelism": "batch-sharded x%d, one packed all-gather of pred_colors+hint_mask" % world,
                        "issue": "steps pipelined over 2 HIP streams, staggered" if args.pipeline else "%d staggered micro-batches per step" % args.micro},
             "kmeans_events": events, "fp8_saturated_elements": sat, "result_checksum": "%08x" % checksum,
@@ -433,12 +516,12 @@ def main():
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
             }
             out["stage_ms_per_step"] = {k: round(v / prof_steps, 3) for k, v in stage_ms.items()}        # of the profiled single-stream forwards
-            if world == 1 and not args.no_latency:
+            if world == 1 and not args.no_latency and args.config == "2":
                 # the reference's own call pattern is one image per forward (main/colorizer/inference.py:93-109): its latency, NOT `value`
                 out["single_image_latency_ms"] = single_image_latency(model, gray[:1].contiguous(), ab[:1].contiguous(), sync)
-            if world == 1 and not args.no_other_configs and args.batch == 64 and args.size == 256 and args.global_batch == 0:
+            if world == 1 and not args.no_other_configs and args.config == "2" and args.batch == 64 and args.size == 256 and args.global_batch == 0:
                 out["other_configs"] = other_single_gpu_configs(model, sd, args.precision, sync)
-            if world == 1 and args.alt and not args.no_alt and args.precision == "mx6":
+            if world == 1 and args.alt and not args.no_alt and args.precision == "mx6" and args.config == "2":
                 # the opt-in arithmetic on the same inputs, timed the same way (NOT `value`: DESIGN.md section 2 says why it is opt-in)
                 out["opt_in_precision"] = measure_alt("x2q", sd, gray, ab, n_global, args, sync)
             if world == 1 and not args.no_cpu_baseline:

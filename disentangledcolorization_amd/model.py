@@ -407,7 +407,7 @@ class AnchorColorProb(nn.Module):
 
     @torch.no_grad()
     def forward_once(self, input_grays, input_colors, test_mode=True, sampled_T=0, init_idx=None, hint_pos=None,
-                     fallback_stream=None, fallback_bases=None, want_events=True, out=None):
+                     fallback_stream=None, fallback_bases=None, want_events=True, out=None, range_check=True):
         """ONE native forward with every host-side draw supplied by the caller; consumes no generator state.
         init_idx (n,K) k-means rows / hint_pos (n,K) random-hint tokens; fallback_stream: the values successive
         torch.randint(L,(1,)) calls would return (a prefix of the reference's global draw stream), fallback_bases (n,):
@@ -417,7 +417,9 @@ class AnchorColorProb(nn.Module):
         and may re-calibrate and re-run the batch with a warning; set range_checks = 0 before the first forward for a strictly
         asynchronous start, e.g. on ranks whose inputs are known to lie in the calibrated range).
         out: optional preallocated (pal, ref, pred, affinity, spix, mask) tensors to write into (sampled_T = 0 only; runner.py hands
-        slices of the whole batch's outputs to its micro-batches instead of concatenating their results)."""
+        slices of the whole batch's outputs to its micro-batches instead of concatenating their results).
+        range_check=False: this call neither reads the clamp counter nor counts as one of the first forwards (runner.py under a
+        process group: the ranks check and re-calibrate TOGETHER, ShardedColorizer._collective_range_check)."""
         test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
         dev = gray.device
         n, _, H, W = gray.shape
@@ -444,7 +446,7 @@ class AnchorColorProb(nn.Module):
                 o, e = self.forward_once(gray[i:j], ab[i:j], test_mode, sampled_T, None if init_idx is None else init_idx[i:j],
                                          None if hint_pos is None else hint_pos[i:j], fallback_stream,
                                          None if fallback_bases is None else fallback_bases[i:j], want_events,
-                                         None if out is None else tuple(t[i:j] for t in out))
+                                         None if out is None else tuple(t[i:j] for t in out), range_check)
                 parts.append(o); evs.append(e)
             outs = out if out is not None else tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
             return outs, (np.concatenate(evs) if want_events and not self.random_hint else (np.zeros(n, np.int32) if want_events else None))
@@ -508,7 +510,7 @@ class AnchorColorProb(nn.Module):
                 if want_events and int(events.max()) > MF:
                     raise _ffi.DiscoError("k-means used more than %d empty-cluster draws" % MF)
                 self._keep = (init_idx, rows, events)
-            left = self._range_checks_left.get(id(ctx), self.range_checks)
+            left = self._range_checks_left.get(id(ctx), self.range_checks) if range_check else 0
             if left > 0:
                 self._range_checks_left = {id(ctx): left - 1}
                 clamped = self._read_clamp_counter()

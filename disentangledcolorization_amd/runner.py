@@ -28,6 +28,8 @@ import torch.distributed as dist
 # micro-batch i + 1 starts behind this many MFMA conv launches of micro-batch i (of 69 per forward: SpixelNet 18, ColorProbNet 27,
 # HourGlass2 24); $DISCO_STAGGER_CONVS overrides (0 = off: the micro-batches start together), profiles/r03_stagger_sweep.txt
 STAGGER_CONVS = int(os.environ.get("DISCO_STAGGER_CONVS", "26"))
+# images a collective re-calibration gathers over all ranks (AnchorColorProb.calibrate takes at most 64)
+CAL_IMAGES = 64
 
 
 class _HostStream:
@@ -98,8 +100,18 @@ class ShardedColorizer:
     as long as no empty-cluster event occurs (bench.py checks that after its timed loop)."""
 
     def __init__(self, forward_fn, n_clusters=8, random_hint=False, sp_size=16, group=None, micro_batches=1,
-                 exact_fallback=True, max_fallback=None, force_gather=False):
+                 exact_fallback=True, max_fallback=None, force_gather=False, virtual_rank=None):
         self.forward_fn = forward_fn
+        # virtual_rank = (world, rank): compute the share rank `rank` of `world` has of a global batch WITHOUT a process group - the global
+        # draws, the slice at its global offset, the local forward - on the one GPU a test box has (tests/test_gpu_forward.py checks rank 7
+        # of 8 of BASELINE configs 3 and 5 against the oracle that way).  No collective exists in this mode: gather=False and
+        # exact_fallback=False only (the caller checks the event counts with forward_once).
+        self.virtual_rank = None if virtual_rank is None else (int(virtual_rank[0]), int(virtual_rank[1]))
+        if self.virtual_rank is not None and not (0 <= self.virtual_rank[1] < self.virtual_rank[0]):
+            raise ValueError("virtual_rank = (world, rank) with 0 <= rank < world")
+        # the collective range check of the first forwards (from_model): the model whose clamp counter is read, and how many checks are left
+        self._range_model = None
+        self._range_left = 0
         self.k, self.random_hint, self.sp = n_clusters, random_hint, sp_size
         self.group = group
         # micro_batches > 1: the local shard is cut into that many slices, each issued on its own HIP stream, so the
@@ -135,22 +147,63 @@ class ShardedColorizer:
         self.last_events = None     # per-image empty-cluster draws of the GLOBAL batch of the latest exact forward
 
     @classmethod
-    def from_model(cls, model, group=None, micro_batches=1, exact_fallback=None, force_gather=False):
-        fn = lambda g, a, T, idx, pos, fs, fb, want, out=None: model.forward_once(g, a, True, T, idx, pos, fs, fb, want, out)
+    def from_model(cls, model, group=None, micro_batches=1, exact_fallback=None, force_gather=False, virtual_rank=None):
         exact = model.sync_kmeans_events if exact_fallback is None else exact_fallback
-        r = cls(fn, model.hint_num, model.random_hint, model.sp_size, group, micro_batches, exact, model.max_fallback(), force_gather)
+        r = cls(None, model.hint_num, model.random_hint, model.sp_size, group, micro_batches, exact, model.max_fallback(), force_gather, virtual_rank)
+        # Under a process group the model's OWN range check stays out of the way (range_check=False per call - the caller's model object is
+        # not modified): it would re-calibrate a rank on ITS shard (activation exponents are a per-context property, and an exponent moves
+        # pred_colors at the 1e-5 level), so the result of an image could depend on how many ranks share the batch.  The check is made
+        # COLLECTIVELY instead (_collective_range_check): the clamp counts of the first `model.range_checks` batches are summed over the
+        # ranks, and when any rank clamped, every rank calibrates on the SAME images (an all-gather of a few from every shard) and runs its
+        # shard again - all contexts stay identical.
+        r.forward_fn = lambda g, a, T, idx, pos, fs, fb, want, out=None: model.forward_once(g, a, True, T, idx, pos, fs, fb, want, out,
+                                                                                            range_check=not r._collective())
+        r._range_model = model if hasattr(model, "saturation_count") and hasattr(model, "calibrate") else None
+        r._range_left = int(getattr(model, "range_checks", 0))
         r.out_capable = True
         r._out_channels = (313, 2 if getattr(model, "hint2regress", False) else 313)
         if hasattr(model, "set_progress_event"):
             r.progress_fn = model.set_progress_event
             r.stagger_convs = STAGGER_CONVS
-        # Under a process group the automatic range check is OFF: it would re-calibrate a rank on ITS shard (activation exponents are a
-        # per-context property, and an exponent moves pred_colors at the 1e-5 level), so the result of an image could depend on how many
-        # ranks share the batch.  Every rank keeps the load-time calibration (the same on all of them); a caller whose data lie outside it
-        # calls model.calibrate() with the SAME images on every rank and watches model.saturation_count().
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and hasattr(model, "range_checks"):
-            model.range_checks = 0
         return r
+
+    def _collective(self):
+        """More than one rank shares the batch: range checks and calibration are collective."""
+        return self.virtual_rank is None and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _collective_range_check(self, gray_local):
+        """One of the first batches of a model under a process group: sum the ranks' fp8 clamp counts; if any rank clamped, every rank
+        calibrates on the same images - CAL_IMAGES // world from every shard (a rank with fewer repeats its first, an empty shard sends
+        zeros: ranges only widen, so padding is harmless), all-gathered - and the caller runs its shard again.  Returns True then.
+        Costs one host synchronisation and one 8-byte all-reduce per checked batch (the model's own check costs the same sync at world 1)."""
+        model = self._range_model
+        if model is None or self._range_left <= 0 or not self._collective():
+            return False
+        self._range_left -= 1
+        world = dist.get_world_size(self.group)
+        sx = _Sx(gray_local.device)
+        with sx.on(self._last_stream if self._last_stream is not None else sx.current()):
+            mine = int(model.saturation_count()) if gray_local.shape[0] else 0         # (synchronises the forward's stream)
+        host = dist.get_backend(self.group) == "gloo"
+        t = torch.tensor([mine], dtype=torch.int64, device="cpu" if host else gray_local.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        total = int(t.item())
+        if total == 0:
+            return False
+        per = max(1, CAL_IMAGES // world)
+        H, W = gray_local.shape[2:]
+        send = gray_local.new_zeros((per, 1, H, W))
+        m = min(per, gray_local.shape[0])
+        if m:
+            send[:m] = gray_local[:m]
+            send[m:] = gray_local[:1]
+        recv = gray_local.new_empty((world * per, 1, H, W))
+        all_gather_into(recv, send, group=self.group)
+        import warnings
+        warnings.warn("%d fp8 activation values were clamped across the %d ranks: this batch is outside the ranges the contexts were calibrated on; "
+                      "every rank re-calibrates on the same %d images and runs its shard again" % (total, world, world * per))
+        model.calibrate(recv)
+        return True
 
     # ---- local forward (optionally as micro-batches on separate streams) ----------------------------------------
     def _forward_local(self, gray, ab, sampled_T, idx, pos, fstream, fbases, want):
@@ -254,6 +307,8 @@ class ShardedColorizer:
         return full, None
 
     def world(self):
+        if self.virtual_rank is not None:
+            return self.virtual_rank
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.group), dist.get_rank(self.group)
         return 1, 0
@@ -283,6 +338,8 @@ class ShardedColorizer:
         complete after wait() - a pipelined caller issues the next batch's forward meanwhile, so the xGMI transfer of
         batch k hides under the convolutions of batch k+1."""
         world, rank = self.world()
+        if self.virtual_rank is not None and (gather or self.exact_fallback):
+            raise ValueError("a virtual rank has no peers: gather=False and exact_fallback=False only")
         lo, hi = shard_bounds(n_global, world, rank)
         if gray_local.shape[0] != hi - lo:
             raise ValueError("rank %d expects %d images, got %d" % (rank, hi - lo, gray_local.shape[0]))
@@ -301,11 +358,14 @@ class ShardedColorizer:
                                        None if pos is None else pos[lo:hi], fstream, fbases, want)
 
         MF = self.max_fallback
-        if self.random_hint:
-            out, _ = run(None, None, False)
-        elif not self.exact_fallback:
-            out, _ = run(peek_randint(l, MF), None, False)
-        else:
+
+        def compute():
+            """The local forward(s) of this batch -> (outputs, per-image event counts of the GLOBAL batch or None).  Consumes no generator
+            state (the draws above are made once; the fallback stream is peeked), so it can run again after a re-calibration."""
+            if self.random_hint:
+                return run(None, None, False)[0], None
+            if not self.exact_fallback:
+                return run(peek_randint(l, MF), None, False)[0], None
             stream = peek_randint(l, 2 * MF)
             check = zlib.crc32(idx.tobytes()) ^ zlib.crc32(stream[:MF].tobytes())
             bases = np.zeros(n_global, np.int64)
@@ -336,6 +396,13 @@ class ShardedColorizer:
                         fixed.append(t)
                     out = tuple(fixed)
                     ev = ev.copy(); ev[sel] = e2
+            return out, events
+
+        self._last_stream = None
+        out, events = compute()
+        if self._collective_range_check(gray_local):
+            out, events = compute()
+        if events is not None:
             for _ in range(int(events.sum())):      # every rank consumes what the reference's single process would have
                 torch.randint(l, (1,))
             self.last_events = events

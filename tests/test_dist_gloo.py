@@ -233,6 +233,128 @@ def test_bench_distributed_scaffolding_on_gloo():
     assert lines[2]["config"]["global_batch"] == 6 and lines[2]["value"] > 0
 
 
+class _RangeModel:
+    """The slice of AnchorColorProb that ShardedColorizer.from_model touches, with a calibration STATE: `limit` = the largest |gray| the
+    'context' covers.  A forward clamps (counts) every image beyond it and - like the fp8 planes - returns something else for it;
+    calibrate(images) widens the limit to their maximum.  range_checks = 3 like the product."""
+    sp_size, hint_num, random_hint, sync_kmeans_events, hint2regress = 16, 4, False, False, False
+
+    def __init__(self):
+        self.range_checks, self.limit, self.sat, self.calibrated_on, self.own_checks = 3, 1.0, 0, [], 0
+
+    def max_fallback(self):
+        return 16
+
+    def forward_once(self, g, a, test_mode, T, idx, pos, fs, fb, want, out=None, range_check=True):
+        self.own_checks += int(range_check)
+        (o, ev) = _fake_forward(g, a, T, idx, pos, fs, fb, want)
+        over = g.abs().flatten(1).amax(1) > self.limit
+        self.sat += int(over.sum())
+        pred = torch.where(over.reshape(-1, 1, 1, 1), torch.full_like(o[2], -7.0), o[2])
+        return (None, None, pred, None, None, o[5]), ev
+
+    def saturation_count(self):
+        v, self.sat = self.sat, 0
+        return v
+
+    def calibrate(self, images):
+        self.calibrated_on.append(images.clone())
+        self.limit = max(self.limit, float(images.abs().max()))
+
+
+def _range_worker(rank, world, port, q):
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_global = 5
+    gray, ab = _inputs(n_global)
+    gray = gray.clamp(-1, 1)
+    gray[4] *= 3.0                     # the LAST image (rank 1's shard) lies outside the load-time range
+    lo, hi = shard_bounds(n_global, world, rank)
+    m = _RangeModel()
+    sc = ShardedColorizer.from_model(m, exact_fallback=False)
+    assert m.range_checks == 3, "from_model must not modify the caller's model"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _seed()
+        pred, mask = sc.colorize(gray[lo:hi], ab[lo:hi], n_global, 0)
+    q.put((rank, pred.contiguous().numpy(), m.limit, [c.numpy() for c in m.calibrated_on], len(w), m.own_checks, sc._range_left))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_range_check_is_collective_under_a_process_group():
+    """Advisor finding of round 5: from_model used to switch the model's range check OFF under a process group (and mutate the caller's
+    model); an out-of-range batch then clamped silently.  Now the first batches are checked TOGETHER: rank 1's shard clamps, rank 0's
+    does not - both ranks must re-calibrate on the SAME gathered images (identical contexts afterwards), run their shards again, and return
+    the result an all-covering calibration gives; the model's own per-rank check stays out of it."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_range_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(timeout=60)
+    gray, ab = _inputs(5)
+    gray = gray.clamp(-1, 1); gray[4] *= 3.0
+    _seed()
+    idx, _ = global_draws(5, 16, 4, False)
+    want = _fake_forward(gray, ab, 0, idx, None, peek_randint(16, 16), None, False)[0][2].numpy()
+    for rank, pred, limit, cal, nwarn, own, left in got:
+        assert np.array_equal(pred, want), "rank %d returned a clamped result" % rank
+        assert abs(limit - float(gray.abs().max())) < 1e-6 and nwarn == 1 and own == 0 and left == 2
+        assert len(cal) == 1 and cal[0].shape[0] == 64 and np.array_equal(cal[0], got[0][3][0]), "every rank calibrates on the same images"
+
+
+def _plain_bench(args, extra_env=None):
+    """`python bench.py ...` with NO launcher environment (what the driver runs): returns (parsed JSON line, stderr)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(DISCO_BENCH_FAKE="1", **(extra_env or {}))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + list(args), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    return r
+
+
+@pytest.mark.parametrize("config", ["2", "3", "5a", "5b"])
+def test_bench_starts_its_own_ranks(config):
+    """The driver's command is plain `python bench.py --gpus N ...` (no torch.distributed.run): bench.py must start its N ranks itself,
+    print exactly ONE JSON line, report the world size the BACKEND saw, and - for the named BASELINE configurations with a fixed global
+    batch (3: 512 images K=8; 5a: 256 images --diverse K=16; 5b: 256 images random_hint K=16) - give the same result checksum on 2 ranks
+    as on 1 (shards of the same global batch, draws in global image order)."""
+    common = ["--steps", "2", "--warmup", "1", "--size", "64", "--batch", "3", "--no-cpu-baseline", "--config", config]
+    two = _plain_bench(["--gpus", "2"] + common)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, two.stdout
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["world_size_seen_by_backend"] == 2 and d2["steps"] == 2 and d2["warmup"] == 1
+    assert d2["config"]["name"] == config and ("config %s" % config[0]) in d2["config"]["workload"]
+    want_global = {"2": 6, "3": 512, "5a": 256, "5b": 256}[config]
+    assert d2["config"]["global_batch"] == want_global
+    assert d2["config"]["colorizations_per_step"] == want_global * (3 if config == "5a" else 1)
+    assert d2["config"]["n_clusters"] == (8 if config in "23" else 16)
+    assert d2["scaling"] == ("weak" if config == "2" else "strong")
+    if config != "2":
+        one = _plain_bench(["--gpus", "1"] + common)
+        assert one.returncode == 0, one.stderr[-3000:]
+        d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+        assert d1["n_gpus"] == 1 and d1["result_checksum"] == d2["result_checksum"]
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """A rank that dies must end the job with its exit code instead of leaving the others in a collective: world 2 with a launcher
+    environment that disagrees (WORLD_SIZE given by the parent = bench.py does not launch; --gpus 2 vs WORLD_SIZE 1 is refused)."""
+    env = dict(os.environ, DISCO_BENCH_FAKE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="31999")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+    # ... and a rank failing inside a self-launched job: an impossible shard request (DISCO_BENCH_FAIL_RANK makes that rank exit 7 after init)
+    r = _plain_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "32", "--batch", "2", "--no-cpu-baseline"], {"DISCO_BENCH_FAIL_RANK": "1"})
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_shard_bounds_cover_batch():
     for n in (1, 7, 64, 513):
         for world in (1, 2, 3, 8):

@@ -15,7 +15,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(extra_env, launcher, args=("--gpus", "1", "--batch", "4")):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     cmd = launcher + [os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + list(args)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -44,9 +45,23 @@ def test_world_2_on_one_gpu_with_device_tensors(n_global):
     ones (9 + 8: padded and unpacked); the result checksum must equal the single-process run of the same global batch."""
     plain = _bench({}, [sys.executable], ("--gpus", "1", "--global-batch", str(n_global)))
     port = 35600 + os.getpid() % 1000 + n_global
-    two = _bench({"DISCO_DIST_BACKEND": "gloo"},
-                 [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                  "--master-port", str(port)], ("--gpus", "2", "--global-batch", str(n_global)))
+    # the two ways an N-rank bench is started: through torch.distributed.run (17) and - the driver's command - as plain
+    # `python bench.py --gpus 2`, which starts its own ranks (16)
+    launcher = [sys.executable] if n_global == 16 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                        "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    two = _bench({"DISCO_DIST_BACKEND": "gloo"}, launcher, ("--gpus", "2", "--global-batch", str(n_global)))
     assert two["n_gpus"] == 2 and two["world_size_seen_by_backend"] == 2 and two["kmeans_events"] == 0
     assert two["config"]["global_batch"] == n_global
     assert two["result_checksum"] == plain["result_checksum"]
+
+
+@pytest.mark.parametrize("config,batch", [("3", 24), ("5a", 6), ("5b", 6)])
+def test_named_configs_on_two_ranks_equal_one_rank(config, batch):
+    """bench.py --config 3 / 5a / 5b (BASELINE's 8-GPU configurations by name) with the global batch cut down to what a test can afford:
+    two self-launched ranks sharing cuda:0 must give the single-process checksum - K = 8 / --diverse K = 16 (three colorizations per image,
+    packed gather of 3 rows per image) / random_hint K = 16 (`random` draws in global image order)."""
+    one = _bench({}, [sys.executable], ("--gpus", "1", "--config", config, "--global-batch", str(batch)))
+    two = _bench({"DISCO_DIST_BACKEND": "gloo"}, [sys.executable], ("--gpus", "2", "--config", config, "--global-batch", str(batch)))
+    assert two["world_size_seen_by_backend"] == 2 and two["config"]["name"] == config and two["kmeans_events"] == 0
+    assert two["config"]["colorizations_per_step"] == batch * (3 if config == "5a" else 1)
+    assert one["result_checksum"] == two["result_checksum"]
