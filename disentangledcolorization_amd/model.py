@@ -80,7 +80,7 @@ class SpixelSeg(nn.Module):
         raise NotImplementedError("training is outside the MI355X hot path")
 
     def _drop_ctx(self):
-        if getattr(self, "_ctx", None) is not None:
+        if getattr(self, "_ctx", None) is not None and self.__dict__.get("_dp_origin") is None:     # (a replica shares its origin's context)
             _ffi.lib().disco_destroy(self._ctx)
         self._ctx = None
 
@@ -100,8 +100,22 @@ class SpixelSeg(nn.Module):
         except Exception:
             pass
 
+    def _replicate_for_data_parallel(self):
+        """main/spixelseg/inference.py:50-51 wraps the model in nn.DataParallel on a multi-GPU host and calls it with batch 1: the one replica
+        (on the module's own device) forwards on its origin's native context; see AnchorColorProb._replicate_for_data_parallel."""
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_dp_origin"] = self.__dict__.get("_dp_origin") or self
+        return replica
+
     @torch.no_grad()
     def forward(self, input_grays):
+        origin = self.__dict__.get("_dp_origin")
+        if origin is not None:
+            home = next(origin.parameters()).device
+            if input_grays.device != home:
+                raise NotImplementedError("nn.DataParallel scattered a batch onto %s, but the native context of SpixelSeg lives on %s: "
+                                          "one process per GPU for batches over several GPUs (INTEGRATION.md section 5)" % (input_grays.device, home))
+            return origin.forward(input_grays)
         if not input_grays.is_cuda:
             raise _ffi.DiscoError("SpixelSeg needs CUDA/HIP tensors: the HIP path has no CPU fallback")
         dev = input_grays.device
@@ -205,7 +219,9 @@ class AnchorColorProb(nn.Module):
         return out
 
     def _drop_ctx(self):
-        if getattr(self, "_ctx", None) is not None:
+        # a DataParallel replica shares its origin's context (its __dict__ is a copy of the origin's, handle included): it must
+        # never destroy it - replicas are rebuilt and garbage-collected on every DataParallel.forward
+        if getattr(self, "_ctx", None) is not None and self.__dict__.get("_dp_origin") is None:
             _ffi.lib().disco_destroy(self._ctx)
         self._ctx = None
 
@@ -363,6 +379,9 @@ class AnchorColorProb(nn.Module):
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, input_grays, input_colors, test_mode=False, sampled_T=0):
+        origin = self._replica_origin(input_grays)
+        if origin is not None:
+            return origin.forward_with_draws(input_grays, input_colors, test_mode, sampled_T)
         return self.forward_with_draws(input_grays, input_colors, test_mode, sampled_T)
 
     def train(self, mode=True):
@@ -372,10 +391,30 @@ class AnchorColorProb(nn.Module):
         return super().train(False)
 
     def _replicate_for_data_parallel(self):
-        raise NotImplementedError(
-            "nn.DataParallel cannot replicate the native context of AnchorColorProb (its replicas carry no parameters). "
-            "Run one process per GPU and shard the batch with disentangledcolorization_amd.runner.ShardedColorizer, or pin "
-            "the process to one GPU (HIP_VISIBLE_DEVICES); see INTEGRATION.md.")
+        """main/colorizer/inference.py:76-82 wraps the model in nn.DataParallel whenever the host shows more than one GPU - always, on an
+        8 x MI355X node - and calls it with batch 1 (:93,108-109): DataParallel.scatter then yields ONE chunk and replicates the module
+        onto device_ids[:1] only, the device the module lives on.  A replica is a copy of __dict__ with empty `_parameters`, so it
+        could never rebuild a native context of its own; instead it keeps a reference to its origin and forwards on the ORIGIN's context
+        (and the origin's workspace and range-check bookkeeping).  A replica that is actually CALLED on another device - batch > 1 on a
+        multi-GPU host - raises and names the supported way (_replica_origin)."""
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_dp_origin"] = self.__dict__.get("_dp_origin") or self
+        return replica
+
+    def _replica_origin(self, like):
+        """None for an ordinary module; for a DataParallel replica: the module it was replicated from, after checking that the call is on
+        the device that module (and its native context) lives on."""
+        origin = self.__dict__.get("_dp_origin")
+        if origin is None:
+            return None
+        home = next(origin.parameters()).device
+        if like.device != home:
+            raise NotImplementedError(
+                "nn.DataParallel scattered a batch onto %s, but the native context of AnchorColorProb lives on %s (its replicas carry no "
+                "parameters and share that one context). Batches over several GPUs: one process per GPU with "
+                "disentangledcolorization_amd.runner.ShardedColorizer (INTEGRATION.md section 5); batch 1 - the reference's inference.py - "
+                "works under DataParallel as it is." % (like.device, home))
+        return origin
 
     def _check_inputs(self, input_grays, input_colors, test_mode):
         test_mode = bool(test_mode)
@@ -420,6 +459,10 @@ class AnchorColorProb(nn.Module):
         slices of the whole batch's outputs to its micro-batches instead of concatenating their results).
         range_check=False: this call neither reads the clamp counter nor counts as one of the first forwards (runner.py under a
         process group: the ranks check and re-calibrate TOGETHER, ShardedColorizer._collective_range_check)."""
+        origin = self._replica_origin(input_grays)
+        if origin is not None:
+            return origin.forward_once(input_grays, input_colors, test_mode, sampled_T, init_idx, hint_pos, fallback_stream, fallback_bases,
+                                       want_events, out, range_check)
         test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
         dev = gray.device
         n, _, H, W = gray.shape
@@ -535,6 +578,9 @@ class AnchorColorProb(nn.Module):
         number of fallback draws the reference would have made, in image order.  With sync_kmeans_events = False there is
         no host synchronisation: every image reads fallback rows from the start of the stream and nothing is consumed -
         exact only while no empty-cluster event occurs (check `last_kmeans_events()` / bench.py's `kmeans_events`)."""
+        origin = self._replica_origin(input_grays)
+        if origin is not None:
+            return origin.forward_with_draws(input_grays, input_colors, test_mode, sampled_T, init_idx, hint_pos)
         test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
         n, _, H, W = gray.shape
         l = (H // self.sp_size) * (W // self.sp_size)

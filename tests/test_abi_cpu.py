@@ -132,18 +132,46 @@ def test_product_never_imports_oracle():
                 assert not pat.search(open(os.path.join(root, f)).read()), f
 
 
-def test_dataparallel_and_train_are_refused_with_a_pointer_to_the_runner():
-    """inference.py:76-82 wraps the model in nn.DataParallel on multi-GPU hosts; its replicas carry no parameters, so the
-    native context cannot be rebuilt there: the replication hook must fail loudly and name the supported way.  train()
-    raises like INTEGRATION.md says (eval() stays a no-op)."""
-    from disentangledcolorization_amd.model import AnchorColorProb
+def test_dataparallel_replicas_share_the_native_context_and_train_is_refused():
+    """inference.py:76-82 wraps the model in nn.DataParallel on multi-GPU hosts (spixelseg/inference.py:50-51 likewise) and calls it with
+    batch 1: the wrapper must construct, a replica (a __dict__ copy with empty `_parameters`) must keep its origin, share - and never
+    destroy - the origin's native context, and refuse only when it is CALLED on another device than the origin's.  train() raises like
+    INTEGRATION.md says (eval() stays a no-op)."""
+    import gc
+    from disentangledcolorization_amd.model import AnchorColorProb, SpixelSeg
+    from disentangledcolorization_amd import _ffi
 
     m = AnchorColorProb(n_clusters=8, enhanced=True, init_weights=False)
     assert m.eval() is m
     with pytest.raises(NotImplementedError, match="inference only"):
         m.train()
-    with pytest.raises(NotImplementedError, match="ShardedColorizer"):
-        torch.nn.DataParallel(m).module._replicate_for_data_parallel()
+    for mod in (m, SpixelSeg()):
+        dp = torch.nn.DataParallel(mod)                 # constructs (on a CPU-only host it forwards to .module)
+        assert dp.module is mod and dp.eval() is dp
+        destroyed = []
+        mod._ctx = "sentinel-handle"                    # what a live context would be: the replica must carry it and leave it alone
+        real = _ffi.lib
+        try:
+            _ffi.lib = lambda: type("L", (), {"disco_destroy": staticmethod(lambda h: destroyed.append(h))})
+            r = mod._replicate_for_data_parallel()
+            r2 = r._replicate_for_data_parallel()       # a replica of a replica still points at the module that owns the context
+            assert r._dp_origin is mod and r2._dp_origin is mod and r._ctx == "sentinel-handle" and not r._parameters
+            r._drop_ctx()
+            del r, r2
+            gc.collect()
+            assert destroyed == [], "a replica destroyed the shared context"
+            mod._drop_ctx()
+            assert destroyed == ["sentinel-handle"]
+        finally:
+            _ffi.lib = real
+        # replicated the way DataParallel does (parameters re-attached as plain attributes), then called off the origin's device: refused
+        r = mod._replicate_for_data_parallel()
+        x = torch.zeros(1, 1, 32, 32, device="meta")
+        with pytest.raises(NotImplementedError, match="one process per GPU"):
+            r(x) if isinstance(mod, SpixelSeg) else r(x, torch.zeros(1, 2, 32, 32, device="meta"), True, 0)
+        with pytest.raises(_ffi.DiscoError, match="no CPU fallback"):      # on the origin's own device the call goes through to the origin
+            xc = torch.zeros(1, 1, 32, 32)
+            r(xc) if isinstance(mod, SpixelSeg) else r(xc, torch.zeros(1, 2, 32, 32), True, 0)
 
 
 def test_mx_weight_pack_and_fp8_codec(lib):

@@ -974,3 +974,43 @@ def test_small_batches_fork_spixelnet_onto_a_side_stream(synth_sd):
                 assert torch.equal(smalls[j][k], big[k][i:i + 2]), (i, k)
     finally:
         m.range_checks = saved
+
+
+@pytest.mark.parametrize("T", [0, 2])
+def test_unmodified_inference_flow_under_dataparallel(synth_sd, T):
+    """main/colorizer/inference.py:76-82,93,108-109 UNMODIFIED on a multi-GPU host: `nn.DataParallel(model).cuda()`, strict load on
+    `.module`, `.eval()`, then batch-1 calls `color_model(gray, ab, True, sampled_T)`.  With more than one device id DataParallel.forward
+    scatters (one chunk for batch 1), REPLICATES the module onto device_ids[:1] and runs the replica; a test box has one GPU, so the second
+    device id is the first one again - the code path is the multi-GPU one (scatter / replicate / parallel_apply / gather).  The replica forwards
+    on its origin's native context: results bit for bit those of the plain call, no context rebuilt or destroyed on the way."""
+    k = 16 if T else 8
+    m = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=False, learning_pos=False,
+                        n_clusters=k, random_hint=False, hint2regress=False, enhanced=True, init_weights=False)
+    dp = torch.nn.DataParallel(m).cuda()
+    m.load_state_dict(synth_sd)                     # load_checkpoint(path, model_without_dp), utils_train.py:151
+    dp.eval()
+    gray, ab = synth.synth_inputs(1, 256, 256, seed=77)
+    gray, ab = gray.cuda(non_blocking=True), ab.cuda(non_blocking=True)
+    _seed(9)
+    want = m(gray, ab, True, T)
+    torch.cuda.synchronize()
+    handle = m._ctx.value
+    dp.device_ids = [0, 0]                          # "device_count() > 1": forward takes the replicate path
+    for _ in range(3):                              # replicas are rebuilt (and collected) on every call
+        _seed(9)
+        got = dp(gray, ab, True, T)
+        torch.cuda.synchronize()
+        assert len(got) == 6
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and torch.equal(a, b)
+    import gc
+    gc.collect()
+    assert m._ctx is not None and m._ctx.value == handle, "the shared context was rebuilt or dropped"
+    _seed(9)
+    again = m(gray, ab, True, T)                    # ... and is still alive after the replicas are gone
+    torch.cuda.synchronize()
+    assert torch.equal(again[2], want[2])
+    # a replica that is CALLED on another device than the origin's is refused with a pointer to the runner
+    r = m._replicate_for_data_parallel()
+    with pytest.raises(NotImplementedError, match="ShardedColorizer"):
+        r(gray.cpu(), ab.cpu(), True, T)
