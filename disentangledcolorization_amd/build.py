@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdisco_hip.so")
-SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.hip", "conv_mx_ar1.hip", "conv_mx_ar2.hip", "conv_mx_ar3.hip", "conv_direct.hip", "color.hip", "spixel.hip", "pool.hip", "tokens.hip", "attention_mfma.hip", "diag.hip"]
+SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.hip", "conv_mx_ar1.hip", "conv_mx_ar2.hip", "conv_mx_ar3.hip", "conv_direct.hip", "color.hip", "spixel.hip", "pool.hip", "tokens.hip", "attention.hip", "kmeans.hip", "anchor_colors.hip", "attention_mfma.hip", "diag.hip"]
 # per-file extra flags
 # -fno-slp-vectorize: the SLP vectoriser forms v_pk_*_f32 with op_sel (the low result half takes the HIGH dword of a source), and on this part
 # that form returns a wrong low half while other waves of the CU issue MFMAs (tools/pk_fault_repro.hip, profiles/r03_pk_fma_op_sel_fault.txt;

@@ -374,6 +374,7 @@ size_t encoder_ws_bytes(int n, int l);
 // packed: the weights' B-fragment image for the 16-row tail kernel (launch_encoder_pack of the same `weights`), or null: 64-row tiles at every size
 // attention_mfma.hip: softmax(q k^T) v on the fp32 matrix cores (long token sequences; launch_encoder_stack picks it by the token count alone)
 int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s);
+int launch_attention_valu(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s);      // attention.hip
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
                          void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg = nullptr, const float* packed = nullptr);
 size_t encoder_packed_floats();
