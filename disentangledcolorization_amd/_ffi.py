@@ -71,6 +71,8 @@ SIGNATURES = {
     "disco_forward": (_I, [_P, C.POINTER(ForwardArgs)]),
     "disco_calibrate": (_I, [_P, _P, _I, _I, _I]),
     "disco_saturation_count": (_I, [_P, _P, C.POINTER(C.c_uint64)]),
+    "disco_kmeans_fallback_count": (_I, [_P, _P, C.POINTER(C.c_uint64)]),
+    "disco_op_kmeans_fallbacks": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int)]),
     "disco_calibration_count": (_I, [_P]),
     "disco_enhance_arithmetic": (_I, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "disco_calibration_entry": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(_I)]),

@@ -1122,7 +1122,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
                 if (P.ok() && mf) P.rc = staged_h2d(c, d_fb, a->h_fallback_rows, (size_t)n * mf * 4, s);
                 // inference clusters the wild-path tokens (model.py:140-141); the validation forward clusters the pooled
                 // GT colours (N,2,h,w) (model.py:169-171)
-                if (P.ok()) P.rc = test ? launch_kmeans_anchors(enc, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s, 64, 0, km_ws, km_bytes)
+                if (P.ok()) P.rc = test ? launch_kmeans_anchors(enc, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s, 64, 0, km_ws, km_bytes, c->d_sat + 1)
                                         : launch_kmeans_anchors(spix_ab, sizes, d_idx, mf ? d_fb : nullptr, mf, d_assign, d_anchor, a->d_hint_mask, d_info, n, L, K, s, 2, 1);
             }
         }
@@ -1625,6 +1625,18 @@ int disco_saturation_count(disco_ctx* c, void* stream, uint64_t* count) {
     return DISCO_OK;
 }
 
+int disco_kmeans_fallback_count(disco_ctx* c, void* stream, uint64_t* count) {
+    if (!c || !count || !c->finalized) { set_error("disco_kmeans_fallback_count: bad argument"); return DISCO_EINVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
+    unsigned int v = 0;
+    DISCO_HIP_CHECK(hipSetDevice(c->device));
+    DISCO_HIP_CHECK(hipMemcpyAsync(&v, c->d_sat + 1, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DISCO_HIP_CHECK(hipMemsetAsync(c->d_sat + 1, 0, 4, (hipStream_t)stream));
+    DISCO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *count = v;
+    return DISCO_OK;
+}
+
 int disco_calibration_count(disco_ctx* c) {
     if (!c) return 0;
     std::lock_guard<std::mutex> lk(c->mu);          // (a calibration on another host thread rewrites these tables)
@@ -2074,6 +2086,18 @@ int disco_op_kmeans_anchors_ws(const float* d_x, const float* d_sizes, const int
     if (!d_x || !d_sizes || !d_init_idx || !d_assign || !d_anchor || !d_hint_mask) { set_error("null argument"); return DISCO_EINVAL; }
     return launch_kmeans_anchors(d_x, d_sizes, d_init_idx, d_fallback_rows, max_fallback, d_assign, d_anchor, d_hint_mask, d_info,
                                  n, l, k, (hipStream_t)stream, d, channel_major, d_ws, ws_bytes);
+}
+
+int disco_op_kmeans_fallbacks(const void* d_ws, int n, int l, void* stream, int* count) {
+    if (!d_ws || !count || n <= 0 || l <= 0) { set_error("disco_op_kmeans_fallbacks: bad argument"); return DISCO_EINVAL; }
+    *count = 0;
+    if (kmeans_ws_bytes(n, l) == 0) return DISCO_OK;
+    std::vector<int> st((size_t)n);
+    DISCO_HIP_CHECK(hipMemcpy2DAsync(st.data(), sizeof(int), static_cast<const unsigned char*>(d_ws) + kmeans_state_offset(), kmeans_image_stride(),
+                                     sizeof(int), (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DISCO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int v : st) *count += (v >> 30) & 1;
+    return DISCO_OK;
 }
 
 static int gamut_device(float** out) {

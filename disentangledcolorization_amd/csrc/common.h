@@ -402,8 +402,11 @@ int launch_nearest_bin(const float* ab_nchw, const float* q_to_ab, int32_t* labe
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,
                           int l, int k, hipStream_t s, int d = 64, int channel_major = 0,   // x: (n,l,d) or (n,d,l)
-                          void* ws = nullptr, size_t ws_bytes = 0);   // ws: kmeans_ws_bytes(n, l) of scratch lets images of more than 512 tokens run on several workgroups
+                          void* ws = nullptr, size_t ws_bytes = 0,   // ws: kmeans_ws_bytes(n, l) of scratch lets images of more than 512 tokens run on several workgroups
+                          unsigned int* fallback_counter = nullptr);   // device counter: += 1 per image that the several-workgroup kernel gave up and the one-workgroup kernel computed
 size_t kmeans_ws_bytes(int n, int l);
+size_t kmeans_state_offset();      // of an image's admission word inside its kmeans_image_stride() bytes of scratch (bit 30 set: the image fell back)
+size_t kmeans_image_stride();
 int launch_hint_mask_from_pos(const int32_t* pos, float* hint_mask, int n, int l, int k, hipStream_t s);
 // hint[t] = W[:, :64] src + m W[:, 64+label] + m W[:, 377]           (labels, W (64,378))
 //         = W[:, :64] src + m a W[:, 64] + m b W[:, 65] + m W[:, 66]  (hint2regress: colors (n,2,l), W (64,67))

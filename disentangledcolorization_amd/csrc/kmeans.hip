@@ -242,6 +242,9 @@ __global__ __launch_bounds__(1024) void kmeans_anchor_kernel(const float* __rest
 constexpr int KS_PITCH = 65;       // point rows in LDS (floats): odd, conflict-free both by row and by column
 constexpr int KS_CP = 68;          // centre rows: 16-byte aligned, consecutive rows on different banks
 constexpr int KS_MAXL = 256;
+// kmeans_coop_kernel's admission word (one per image, in its scratch): workgroups arrived so far | KC_ABORT once the image has been given
+// up over there (kmeans_tiled_kernel, launched behind it, then computes the image)
+constexpr int KC_ABORT = 1 << 30;
 __global__ __launch_bounds__(1024) void kmeans_small_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
                                                             const int32_t* __restrict__ init_idx, const int32_t* __restrict__ fallback,
                                                             int max_fallback, int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
@@ -413,7 +416,8 @@ __global__ __launch_bounds__(1024) void kmeans_small_kernel(const float* __restr
 __global__ __launch_bounds__(1024) void kmeans_tiled_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
                                                             const int32_t* __restrict__ init_idx, const int32_t* __restrict__ fallback,
                                                             int max_fallback, int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
-                                                            int32_t* info, int L, int K) {
+                                                            int32_t* info, int L, int K, const int* coop_state, long coop_stride,
+                                                            unsigned int* fallback_counter) {
     extern __shared__ float dyn[];          // 2 x [256][KS_PITCH]: the tile being worked on and the one being written
     __shared__ __attribute__((aligned(16))) float cen[2][KMAX * KS_CP];
     __shared__ int asg[2][KS_MAXL];         // the tiles' assignments (double-buffered like the tiles)
@@ -422,6 +426,12 @@ __global__ __launch_bounds__(1024) void kmeans_tiled_kernel(const float* __restr
     __shared__ int s_anchor[KMAX];
     __shared__ int s_events, s_any_empty;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // launched BEHIND kmeans_coop_kernel as its safety net (coop_state != null): this image runs here only if its workgroups over there
+    // could not be admitted together (or gave up): the same additions in the same order, so the result is the one they would have produced
+    if (coop_state) {
+        if (!(coop_state[(size_t)img * coop_stride] & KC_ABORT)) return;
+        if (tid == 0 && fallback_counter) atomicAdd(fallback_counter, 1u);
+    }
     const float* X = x + (size_t)img * L * 64;
     int32_t* assign = assign_out + (size_t)img * L;
     for (int u = tid; u < K * 64; u += 1024) cen[0][(u >> 6) * KS_CP + (u & 63)] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
@@ -618,25 +628,40 @@ __global__ __launch_bounds__(1024) void kmeans_tiled_kernel(const float* __restr
 // streams every member's row from L2 in order) was built too: bit-identical, but at 16 rows in flight per wave an L2 row costs ~270
 // cycles per member against ~70 from LDS - 264 us per pass at 16 384 tokens; it would need a ring of ~64 rows per cluster in flight
 // (LDS-DMA + a second wave per cluster for the list polls) to win.
-// The workgroups of an image spin on each other's words, so they must all be resident: the launcher takes this kernel only while n x G
-// fits a quarter of the CUs, and every spin is bounded by a deadline (5e9 shader cycles from kernel entry); a wave that runs into it
-// TRAPS - the launch fails loudly (hipErrorLaunchFailure), never returns a wrong clustering.
+// The workgroups of an image spin on each other's words, so they must all be RESIDENT TOGETHER.  The launcher takes this kernel only while
+// n x G fits a quarter of the CUs - but that is a heuristic, not a guarantee (other streams' persistent conv workgroups, other contexts or
+// processes on the GPU, CU masks), so residency is PROVEN before anything is exchanged (round 6; the first form trusted the heuristic and
+// trapped after 5e9 cycles - a sticky hipErrorLaunchFailure that ends a serving process):
+//   admission   every workgroup adds itself to the image's `state` word and waits until all G have arrived = all G hold a CU at the same
+//               time, and workgroups are never descheduled: from then on every spin below ends.  A workgroup that waits longer than
+//               KC_ADMIT_CYCLES gives the IMAGE up: it CASes KC_ABORT into the word (possible only while the count is below G: an image is
+//               either committed or aborted, never both); late arrivals see the bit in the value their add returns and leave at once - CUs
+//               held by half-arrived images are released, which is what unblocks a set of launches that got in each other's way.
+//   safety net  kmeans_tiled_kernel is launched right behind, gated per image on KC_ABORT: an image that was not admitted is computed
+//               there, on one workgroup - bit-identical by construction, no host involvement, no error, a few hundred microseconds lost.
+//   backstop    the spins of an ADMITTED image still carry a deadline (1e9 cycles; an image takes < 10 ms): running into it can only mean a
+//               bug or a hardware fault, and it degrades the same way - the wave sets KC_ABORT, stops waiting (every later poll returns at
+//               once, every loop is bounded by the 20-pass limit) and the safety net recomputes the image.
+// DISCO_KMEANS_COOP_INJECT (tests/test_gpu_ops.py): 1 = workgroup 0 of every image never arrives (the others time out in admission);
+// 2 = workgroup 0 leaves right after admission (the others run into the backstop).
 constexpr int KC_MAXG = 64;
-struct KmCoopCtl { int done[KC_MAXG]; int pad[4]; };
+constexpr unsigned long long KC_ADMIT_CYCLES = 6000000ull;        // 2.5-5 ms of shader clock
+constexpr unsigned long long KC_BACKSTOP_CYCLES = 1000000000ull;  // 0.4-0.8 s
+struct KmCoopCtl { int done[KC_MAXG]; int state; int pad[3]; };
 // per image: the running member sums and the pass's new centres, [KMAX][64] 8-byte words {value, tag} each, + the flags
 constexpr size_t KC_IMG_BYTES = ((size_t)(2 * KMAX * 64) * 8 + sizeof(KmCoopCtl) + 255) & ~(size_t)255;
 constexpr int KC_MAX_POINTS = 1 << 18;
 __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restrict__ x, const float* __restrict__ sizes,
                                                            const int32_t* __restrict__ init_idx, const int32_t* __restrict__ fallback,
                                                            int max_fallback, int32_t* assign_out, int32_t* anchor_out, float* hint_mask,
-                                                           int32_t* info, int L, int K, int G, unsigned char* scratch) {
+                                                           int32_t* info, int L, int K, int G, unsigned char* scratch, int inject) {
     extern __shared__ float dyn[];          // 2 x [256][KS_PITCH]: this workgroup's two tiles, resident
     __shared__ __attribute__((aligned(16))) float cen[2][KMAX * KS_CP];
     __shared__ int asg[2][KS_MAXL];
     __shared__ int cnt[KMAX];
     __shared__ float shift_part[KMAX];
     __shared__ int s_anchor[KMAX];
-    __shared__ int s_events, s_any_empty, s_stop;
+    __shared__ int s_events, s_any_empty, s_stop, s_admit;
     __shared__ int cntblk[KMAX][8];             // members of cluster j in 64-point block b of this workgroup's 512 points; then their start in order[]
     __shared__ int seg[KMAX][2];                // cluster j's segment of order[]: start (as a byte offset into order), count
     __shared__ int order[512];                  // this workgroup's points sorted by (cluster, point), as the byte offsets of their rows in dyn
@@ -662,16 +687,43 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
     auto st_i = [](int* ptr, int v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     auto ld_i = [](const int* ptr) -> int { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     // (s_memtime - the shader clock - not s_memrealtime: this runs inside every poll iteration)
-    const unsigned long long deadline = __builtin_amdgcn_s_memtime() + 5000000000ull;     // 2-4 s
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long deadline = t_entry + KC_BACKSTOP_CYCLES;
+    // ---- admission: thread 0 registers this workgroup and waits for the image's other workgroups (the others load the tiles meanwhile) ----
+    if (tid == 0) {
+        int ok = 0;
+        if (!(inject == 1 && g == 0)) {
+            const int before = __hip_atomic_fetch_add(&ctl->state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!(before & KC_ABORT)) {
+                for (;;) {
+                    int v = ld_i(&ctl->state);
+                    if (v & KC_ABORT) break;
+                    if (v == G) { ok = 1; break; }                  // committed: all G are here, and nobody can abort from G
+                    if (__builtin_amdgcn_s_memtime() - t_entry > KC_ADMIT_CYCLES) {
+                        // give the image up - unless it commits at this very moment (then the exchange fails and we look again)
+                        if (__hip_atomic_compare_exchange_strong(&ctl->state, &v, v | KC_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+                        continue;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        }
+        s_admit = ok;
+    }
     // this wave polls one word per lane until every taking-part lane's tag equals `want` under `mask`; a lane with !mine takes no part.
-    // A wave that runs into the deadline TRAPS.
+    // A wave that runs into the backstop deadline gives the image up (KC_ABORT: kmeans_tiled_kernel recomputes it) and stops waiting.
+    bool gave_up = false;
+    auto give_up = [&]() {
+        if (!gave_up && lane == 0) __hip_atomic_fetch_or(&ctl->state, KC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        gave_up = true;
+    };
     auto poll = [&](const u64* ptr, bool mine, unsigned want, unsigned mask) -> u64 {
         u64 w = 0;
         for (;;) {
             if (mine) w = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const bool ok = !mine || (((unsigned)(w >> 32)) & mask) == want;
             if (__ballot(!ok) == 0ull) break;
-            if (__builtin_amdgcn_s_memtime() > deadline) __builtin_trap();
+            if (gave_up || __builtin_amdgcn_s_memtime() > deadline) { give_up(); break; }
             __builtin_amdgcn_s_sleep(1);
         }
         return w;
@@ -688,6 +740,8 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
     for (int u = tid; u < K * 64; u += 1024) cen[0][(u >> 6) * KS_CP + (u & 63)] = X[(size_t)init_idx[img * K + (u >> 6)] * 64 + (u & 63)];
     if (tid == 0) { s_events = 0; s_any_empty = 0; s_stop = 0; }
     __syncthreads();
+    if (!s_admit) return;                       // the image was given up (here or by a sibling): nothing has been exchanged yet
+    if (inject == 2 && g == 0) return;          // (fault injection: an admitted workgroup that vanishes)
     const int t = tid >> 2, q = tid & 3;
     const int KQ = (K + 3) >> 2;
     int cur = 0, passes = 0;
@@ -823,7 +877,7 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
                 if (u == 0) s_stop = (int)((unsigned)(w >> 32) & 1u);
             }
             __syncthreads();
-            stop = s_stop;
+            stop = s_stop | (p >= 20);          // (the last workgroup's stop bit says the same at pass 20; spelled out so that a wave that gave up ends too)
         } else {
             __syncthreads();
             if (s_any_empty) {
@@ -865,7 +919,10 @@ __global__ __launch_bounds__(1024) void kmeans_coop_kernel(const float* __restri
     }
     if (tid < G - 1) {
         while (ld_i(&ctl->done[tid]) == 0) {
-            if (__builtin_amdgcn_s_memtime() > deadline) __builtin_trap();
+            if (__builtin_amdgcn_s_memtime() > deadline) {      // backstop: give the image up, kmeans_tiled_kernel recomputes it
+                __hip_atomic_fetch_or(&ctl->state, KC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -1030,9 +1087,12 @@ __global__ void hint_mask_from_pos_kernel(const int32_t* pos, float* hint_mask, 
 
 size_t kmeans_ws_bytes(int n, int l) { return l > 512 ? (size_t)n * KC_IMG_BYTES : 0; }
 
+size_t kmeans_state_offset() { return (size_t)(2 * KMAX * 64) * 8 + offsetof(KmCoopCtl, state); }
+size_t kmeans_image_stride() { return KC_IMG_BYTES; }
+
 int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* init_idx, const int32_t* fallback_rows,
                           int max_fallback, int32_t* assign, int32_t* anchor, float* hint_mask, int32_t* info, int n,
-                          int l, int k, hipStream_t s, int d, int channel_major, void* ws, size_t ws_bytes) {
+                          int l, int k, hipStream_t s, int d, int channel_major, void* ws, size_t ws_bytes, unsigned int* fallback_counter) {
     if (k < 1 || k > KMAX) { set_error("kmeans: K=%d outside [1,%d]", k, KMAX); return DISCO_ESHAPE; }
     if (k > l) { set_error("kmeans: K=%d larger than %d tokens", k, l); return DISCO_ESHAPE; }
     if (d < 1 || d > 64) { set_error("kmeans: %d features outside [1,64]", d); return DISCO_ESHAPE; }
@@ -1072,14 +1132,23 @@ int launch_kmeans_anchors(const float* x, const float* sizes, const int32_t* ini
         const size_t smem = (size_t)2 * 256 * KS_PITCH * sizeof(float);
         static std::atomic<int> coop_done[DISCO_MAX_DEVICES];
         DISCO_HIP_CHECK(set_dyn_lds_once(coop_done, reinterpret_cast<const void*>(kmeans_coop_kernel), MAX_SMEM));
+        const char* inj = std::getenv("DISCO_KMEANS_COOP_INJECT");          // fault injection (tests); read per launch, this path only
         hipLaunchKernelGGL(kmeans_coop_kernel, dim3(n * G), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
-                           hint_mask, info, l, k, G, static_cast<unsigned char*>(ws));
+                           hint_mask, info, l, k, G, static_cast<unsigned char*>(ws), inj ? atoi(inj) : 0);
+        DISCO_LAUNCH_CHECK("kmeans_coop_kernel");
+        // the safety net, in stream order: an image whose workgroups were not admitted together (KC_ABORT in its state word) is computed
+        // here on one workgroup; the others return at once (one workgroup per image reading one word: ~2 us of a >= 4 ms forward)
+        static std::atomic<int> net_done[DISCO_MAX_DEVICES];
+        DISCO_HIP_CHECK(set_dyn_lds_once(net_done, reinterpret_cast<const void*>(kmeans_tiled_kernel), MAX_SMEM));
+        hipLaunchKernelGGL(kmeans_tiled_kernel, dim3(n), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
+                           hint_mask, info, l, k, reinterpret_cast<const int*>(static_cast<unsigned char*>(ws) + kmeans_state_offset()),
+                           (long)(KC_IMG_BYTES / sizeof(int)), fallback_counter);
     } else if (small_ok && d == 64 && !channel_major) {
         const size_t smem = (size_t)2 * 256 * KS_PITCH * sizeof(float);
         static std::atomic<int> tiled_done[DISCO_MAX_DEVICES];
         DISCO_HIP_CHECK(set_dyn_lds_once(tiled_done, reinterpret_cast<const void*>(kmeans_tiled_kernel), MAX_SMEM));
         hipLaunchKernelGGL(kmeans_tiled_kernel, dim3(n), dim3(1024), smem, s, x, sizes, init_idx, fallback_rows, max_fallback, assign, anchor,
-                           hint_mask, info, l, k);
+                           hint_mask, info, l, k, (const int*)nullptr, 0L, (unsigned int*)nullptr);
     } else
     if (l <= KM_LDS_TOKENS) rc = launch(kmeans_anchor_kernel<true, false>, 0, (size_t)l * (d + 1) * sizeof(float) + lists + best);
     else if (l <= KM_LIST_TOKENS) rc = launch(kmeans_anchor_kernel<false, false>, 1, tile + lists + best);

@@ -317,6 +317,16 @@ class AnchorColorProb(nn.Module):
             return 0
         return self._read_clamp_counter()
 
+    def kmeans_fallback_count(self):
+        """Images since the previous call whose k-means left the several-workgroup kernel (more than 512 tokens: the --no_resize sizes) for the
+        one-workgroup kernel because their workgroups could not be resident together (disco_kmeans_fallback_count).  Results are identical
+        either way; one device synchronisation on the current stream."""
+        if self._ctx is None:
+            return 0
+        cnt = C.c_uint64(0)
+        _ffi.check(_ffi.lib().disco_kmeans_fallback_count(self._ctx, _ffi.current_stream(), C.byref(cnt)))
+        return int(cnt.value)
+
     def set_profiling(self, level=1):
         """0 off, 1 per-stage hipEvents, 2 additionally an event pair around every MFMA conv launch."""
         self._profiling = int(level)

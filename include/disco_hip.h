@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 10
+#define DISCO_ABI_VERSION 11
 
 #define DISCO_OK 0
 #define DISCO_EINVAL (-1)       /* bad argument / null pointer */
@@ -166,6 +166,11 @@ int disco_workspace_bytes(disco_ctx *ctx, int n, int h, int w, int sampled_T, si
  * counter is read on `stream` (one synchronisation) and reset.  Non-zero means some activation exceeded ~14x the range the
  * calibration pass saw: the affected correction products lose accuracy (results degrade towards plain-fp16 operands). */
 int disco_saturation_count(disco_ctx *ctx, void *stream, uint64_t *count);
+/* Images (since the previous call) whose k-means left the several-workgroup kernel for the one-workgroup kernel because their
+ * workgroups could not be resident together - the GPU was shared with other work in a way the launch heuristic did not foresee
+ * (ABI 11; replaces models/clusterkit.py:49-58, a per-image loop that cannot hang: neither can this).  Results are identical either
+ * way; a non-zero count only says that those images took a few hundred microseconds longer.  Synchronises `stream`. */
+int disco_kmeans_fallback_count(disco_ctx *ctx, void *stream, uint64_t *count);
 /* Widen the fp8 scales of an mx8 context with the activation ranges of the caller's own images: d_gray device fp32 (n,1,h,w),
  * n <= 64, h and w multiples of 16.  Blocking (synchronises the device first: no forward of this context may be in flight).
  * Calibrations accumulate (a tensor's recorded max |x| only grows), so results of later forwards change at the 1e-5 level only
@@ -357,10 +362,14 @@ int disco_op_kmeans_anchors(const float *d_x, const float *d_sizes, const int32_
                             int channel_major, void *stream);
 /* ... with caller-owned scratch (round 5): point sets of more than 512 points of 64 row-major features then run on SEVERAL workgroups
  * per image (ceil(l / 512), all resident: taken while n * ceil(l / 512) fits a quarter of the CUs) - the member sums travel down the
- * workgroups as a pipeline in ascending point order, so assignments, pass counts and events are those of the one-workgroup form.  A
- * workgroup that waits longer than 2 s for its predecessor traps: the launch fails (never seen).  Sizes: disco_op_kmeans_workspace_bytes
- * (0 when the shape does not use scratch). */
+ * workgroups as a pipeline in ascending point order, so assignments, pass counts and events are those of the one-workgroup form.
+ * Residency is PROVEN per image before anything is exchanged (an admission count in the scratch); an image whose workgroups do not
+ * all arrive within a few milliseconds - or that runs into the 1e9-cycle backstop later - is given up there and computed by the
+ * one-workgroup kernel launched right behind, bit-identical by construction (ABI 11: no trap, no error, no host involvement).
+ * disco_op_kmeans_fallbacks counts the images of the LAST call on `d_ws` that went that way (synchronises `stream`).
+ * Sizes: disco_op_kmeans_workspace_bytes (0 when the shape does not use scratch). */
 size_t disco_op_kmeans_workspace_bytes(int n, int l);
+int disco_op_kmeans_fallbacks(const void *d_ws, int n, int l, void *stream, int *count);
 int disco_op_kmeans_anchors_ws(const float *d_x, const float *d_sizes, const int32_t *d_init_idx,
                                const int32_t *d_fallback_rows, int max_fallback, int32_t *d_assign,
                                int32_t *d_anchor, float *d_hint_mask, int32_t *d_info, int n, int l, int k, int d,

@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.disco_abi_version() == 10
+    assert lib.disco_abi_version() == 11
 
 
 def test_native_layout_matches_python_spec(lib):

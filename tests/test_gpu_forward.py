@@ -1014,3 +1014,31 @@ def test_unmodified_inference_flow_under_dataparallel(synth_sd, T):
     r = m._replicate_for_data_parallel()
     with pytest.raises(NotImplementedError, match="ShardedColorizer"):
         r(gray.cpu(), ab.cpu(), True, T)
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 768)])
+def test_forward_survives_a_kmeans_that_cannot_be_co_resident(synth_sd, monkeypatch, shape):
+    """The --no_resize forward (1 536 tokens: k-means on three workgroups per image) with workgroup 0 of every image kept out
+    (DISCO_KMEANS_COOP_INJECT=1): the forward must return the undisturbed result - the images are re-clustered by the one-workgroup kernel -
+    report them through kmeans_fallback_count(), and leave the context usable.  Round 5's kernel trapped here (hipErrorLaunchFailure)."""
+    n, H, W = shape
+    m = _model(synth_sd, 8)
+    gray, ab = synth.synth_inputs(n, H, W, seed=H + W + 1)
+    gray, ab = gray.cuda(), ab.cuda()
+    monkeypatch.delenv("DISCO_KMEANS_COOP_INJECT", raising=False)
+    _seed(130)
+    want = m(gray, ab, True, 0)
+    torch.cuda.synchronize()
+    assert m.kmeans_fallback_count() == 0
+    monkeypatch.setenv("DISCO_KMEANS_COOP_INJECT", "1")
+    _seed(130)
+    got = m(gray, ab, True, 0)
+    torch.cuda.synchronize()
+    assert m.kmeans_fallback_count() == n
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    monkeypatch.delenv("DISCO_KMEANS_COOP_INJECT")
+    _seed(130)
+    again = m(gray, ab, True, 0)
+    torch.cuda.synchronize()
+    assert m.kmeans_fallback_count() == 0 and torch.equal(again[2], want[2]) and torch.equal(again[5], want[5])

@@ -474,6 +474,95 @@ def test_kmeans_small_kernel_equals_the_general_one(H, tmp_path):
     assert some_events > 0
 
 
+def _kmeans_coop_call(H, x, sizes, init, fallback, k, stream=None):
+    """disco_op_kmeans_anchors_ws with scratch on `stream` (asynchronous); returns the device buffers + a closure that reads the result and
+    the number of images that fell back to the one-workgroup kernel."""
+    n, l = x.shape[:2]
+    st = stream or torch.cuda.current_stream()
+    with torch.cuda.stream(st):
+        xd, sd_ = x.to(H.DEV).contiguous(), sizes.to(H.DEV).contiguous()
+        idx = torch.as_tensor(np.asarray(init), dtype=torch.int32).to(H.DEV)
+        fb = torch.as_tensor(np.asarray(fallback), dtype=torch.int32).to(H.DEV)
+        assign = torch.empty(n, l, dtype=torch.int32, device=H.DEV); anchor = torch.empty(n, k, dtype=torch.int32, device=H.DEV)
+        mask = torch.empty(n, l, device=H.DEV); info = torch.empty(n, 2, dtype=torch.int32, device=H.DEV)
+        wsb = _ffi.lib().disco_op_kmeans_workspace_bytes(n, l)
+        assert wsb > 0
+        ws = torch.empty(wsb, dtype=torch.uint8, device=H.DEV)
+    keep = (xd, sd_, idx, fb, ws)
+
+    def launch():
+        _ffi.check(_ffi.lib().disco_op_kmeans_anchors_ws(_ffi.ptr(xd), _ffi.ptr(sd_), _ffi.ptr(idx), _ffi.ptr(fb), fb.shape[1], _ffi.ptr(assign),
+                                                         _ffi.ptr(anchor), _ffi.ptr(mask), _ffi.ptr(info), n, l, k, 64, 0, _ffi.ptr(ws), wsb,
+                                                         C.c_void_p(st.cuda_stream)))
+
+    def read():
+        cnt = C.c_int(-1)
+        _ffi.check(_ffi.lib().disco_op_kmeans_fallbacks(_ffi.ptr(ws), n, l, C.c_void_p(st.cuda_stream), C.byref(cnt)))
+        return (assign.cpu(), anchor.cpu(), mask.cpu(), info.cpu()), cnt.value, keep
+    return launch, read
+
+
+@pytest.mark.parametrize("inject", [1, 2])
+def test_kmeans_coop_degrades_to_the_one_workgroup_kernel_instead_of_trapping(H, monkeypatch, inject):
+    """kmeans_coop_kernel's workgroups wait for each other.  Round 5 bounded the wait with a deadline that TRAPPED (a sticky
+    hipErrorLaunchFailure: the end of a serving process).  Now residency is proven per image before anything is exchanged, and an image
+    whose workgroups do not all arrive (inject 1: workgroup 0 never registers) or that loses one later (inject 2: workgroup 0 leaves after
+    admission; the others run into the backstop) is computed by kmeans_tiled_kernel right behind: the SAME assignments, anchors, hint mask,
+    pass counts and events, no error, the context alive.  (clusterkit.py:49-58 is a per-image loop that cannot hang; neither can this.)"""
+    import time
+    cases = [c for c in _km_ab_inputs() if c[0].shape[1] > 512][:2 if inject == 2 else 4]
+    for x, sizes, init, fallback, k in cases:
+        n = x.shape[0]
+        monkeypatch.delenv("DISCO_KMEANS_COOP_INJECT", raising=False)
+        launch, read = _kmeans_coop_call(H, x, sizes, init, fallback, k)
+        launch()
+        want, fell, _ = read()
+        assert fell == 0, "an undisturbed launch must be admitted"
+        monkeypatch.setenv("DISCO_KMEANS_COOP_INJECT", str(inject))
+        launch2, read2 = _kmeans_coop_call(H, x, sizes, init, fallback, k)
+        t0 = time.perf_counter()
+        launch2()
+        got, fell, _ = read2()
+        dt = time.perf_counter() - t0
+        assert fell == n, "every image must have been handed to the one-workgroup kernel (%d of %d)" % (fell, n)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        assert dt < (0.2 if inject == 1 else 3.0), "the admission time-out is milliseconds, the backstop under a second: took %.3f s" % dt
+        monkeypatch.delenv("DISCO_KMEANS_COOP_INJECT")
+        launch()                                            # the context is alive and the several-workgroup kernel still works
+        again, fell, _ = read()
+        assert fell == 0 and all(torch.equal(a, b) for a, b in zip(again, want))
+
+
+def test_kmeans_coop_launches_that_oversubscribe_the_gpu_do_not_deadlock(H):
+    """The advisor's scenario: each launch passes the 'a quarter of the CUs' heuristic, but EIGHT of them on eight streams ask for twice the
+    CUs the GPU has - launches can end up partially resident, each waiting for workgroups the others keep off the CUs.  The first form of
+    the kernel spun there until its 5e9-cycle deadline and trapped.  With admission, half-arrived images give their CUs back and are
+    computed by the one-workgroup kernel: every launch returns the undisturbed result, whatever the interleaving was."""
+    x, sizes, init, fallback, k = [c for c in _km_ab_inputs() if c[0].shape[1] == 1536][0]
+    reps = 21                                           # 21 images x 3 workgroups = 63 of the 64 a launch may take
+    xs = x[:1].repeat(reps, 1, 1) + torch.arange(reps).reshape(-1, 1, 1) * 1e-3
+    szs, ini, fbk = sizes[:1].repeat(reps, 1), np.repeat(init[:1], reps, 0), np.repeat(fallback[:1], reps, 0)
+    launch, read = _kmeans_coop_call(H, xs, szs, ini, fbk, k)
+    launch()
+    want, fell, _ = read()
+    assert fell == 0
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    calls = [_kmeans_coop_call(H, xs, szs, ini, fbk, k, st) for st in streams]
+    torch.cuda.synchronize()
+    total = 0
+    for _ in range(5):
+        for launch_i, _r in calls:
+            launch_i()
+        for _l, read_i in calls:
+            got, fell, _ = read_i()
+            total += fell
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    print("oversubscribed coop launches: %d of %d images fell back to the one-workgroup kernel" % (total, 5 * 8 * reps))
+
+
 @pytest.mark.parametrize("t", [0, 1, 2])
 def test_select_colors_golden(H, comp, t):
     prob = torch.from_numpy(comp["samp_prob"])
