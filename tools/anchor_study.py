@@ -14,12 +14,17 @@ another order.  This tool measures, image by image, on the same inputs and the s
 and reports  rate(H != A)  next to  rate(B != A)  and  rate(C != A),  plus the overlap: of the images H decides differently from A,
 how many does the fp32 control B or the fp64 evaluation C ALSO decide differently (= images that are near-ties for every implementation).
 
-Two stages, because the CPU variants cost minutes and do not depend on the kernels:
-    python tools/anchor_study.py cpu --out gpurun_out/anchor_study_cpu.npz [--sets 256x256:2048,512x512:512,768x512:512] [--workers 8]
-    python tools/anchor_study.py hip --cpu profiles/r06_anchor_study_cpu.npz --out profiles/r06_anchor_mismatch.json
-The hip stage (seconds) is re-run whenever a kernel source changes: its JSON carries bench.py's source_hash() and feeds the bench line's
-`anchor_mismatch_rate`.  Only the encoder half of the oracle runs (segnet + repnet + pooling + wild path + k-means): the anchors do not
-depend on the rest."""
+    G  the oracle's code on torch-ROCm tensors, MIOpen off (im2col + rocBLAS gemm convolutions): exact fp32 in a third order, on the GPU
+    D  the same in fp64
+
+Workers write one small file per (set, chunk of 16 images, variant) as they go (tools/anchor_study.sh starts eight CPU workers and one GPU
+worker side by side); `report` merges what exists:
+    python tools/anchor_study.py run --variants A --part 3/8 --threads 32 --dir gpurun_out/anchor_study
+    python tools/anchor_study.py run --variants HGD --dir gpurun_out/anchor_study
+    python tools/anchor_study.py report --dir profiles/r06_anchor_study --out profiles/r06_anchor_mismatch.json
+The H files are re-made whenever a kernel source changes (seconds); the report's JSON carries bench.py's source_hash() and feeds the
+bench line's `anchor_mismatch_rate`.  Only the encoder half of the oracle runs (segnet + repnet + pooling + wild path + k-means): the
+anchors do not depend on the rest."""
 import argparse
 import json
 import os
@@ -57,64 +62,90 @@ def chunk_inputs(set_id, chunk, h, w):
     return gray, ab, idx, fb
 
 
-def oracle_anchors(oracle, R, gray, ab, idx, fb):
-    """(anchor (n,K) int, hint_mask (n,L), passes, events) of the oracle's encoder half."""
-    aff, feats, src, pos, spix_ab, sizes = oracle.tokens(gray, ab)
-    enc = R.encoder_stack(oracle.sd, "wildpath", src, pos)
-    mask, info = oracle.anchors(enc.float(), sizes.float(), idx, [list(r) for r in fb])
-    return info["anchor"].numpy().astype(np.int32), np.asarray(info["passes"]), np.asarray(info["events"])
-
-
-def cpu_worker(args):
-    set_id, h, w, chunks, threads = args
-    torch.set_num_threads(threads)
+def variant_anchors(variant, gray, ab, idx, fb, cache={}):
+    """Anchors of one chunk under one evaluation of the reference's arithmetic (module docstring).  A / B: CPU; G / D: torch on the GPU with
+    MIOpen off (ATen's im2col + rocBLAS gemm convolutions: exact fp32 products and sums in yet another order / the same in fp64)."""
     from disentangledcolorization_amd import synth
     from disentangledcolorization_amd.gamut import gamut_points
     from oracle import disco_ref as R
-    sd = synth.synth_state_dict(130)
-    o32 = R.DiscoOracle(sd, gamut_points(), n_clusters=K)
-    o64 = R.DiscoOracle({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, gamut_points(), n_clusters=K)
-    out = {}
-    for c in chunks:
-        gray, ab, idx, fb = chunk_inputs(set_id, c, h, w)
-        with torch.no_grad():
-            a = oracle_anchors(o32, R, gray, ab, idx, fb)
+    if "sd" not in cache:
+        cache["sd"] = synth.synth_state_dict(130)
+    key = variant
+    if key not in cache:
+        sd = cache["sd"]
+        if variant in "CD":
+            sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        if variant in "GD":
+            sd = {k: v.cuda() for k, v in sd.items()}
+        cache[key] = R.DiscoOracle(sd, gamut_points(), n_clusters=K)
+    o = cache[key]
+    if variant in "CD":
+        gray, ab = gray.double(), ab.double()
+    with torch.no_grad():
+        if variant in "GD":
+            with torch.backends.cudnn.flags(enabled=False):
+                aff, feats, src, pos, spix_ab, sizes = o.tokens(gray.cuda(), ab.cuda())
+                enc = R.encoder_stack(o.sd, "wildpath", src, pos.to(src.device))
+            enc, sizes = enc.cpu(), sizes.cpu()
+        elif variant == "B":
             with torch.backends.mkldnn.flags(enabled=False):
-                b = oracle_anchors(o32, R, gray, ab, idx, fb)
-            cc = oracle_anchors(o64, R, gray.double(), ab.double(), idx, fb)
-        out[c] = (a, b, cc)
-    return set_id, out
+                aff, feats, src, pos, spix_ab, sizes = o.tokens(gray, ab)
+                enc = R.encoder_stack(o.sd, "wildpath", src, pos)
+        else:
+            aff, feats, src, pos, spix_ab, sizes = o.tokens(gray, ab)
+            enc = R.encoder_stack(o.sd, "wildpath", src, pos)
+        mask, info = o.anchors(enc.float(), sizes.float(), idx, [list(r) for r in fb])
+    return info["anchor"].numpy().astype(np.int16)
 
 
-def stage_cpu(args):
-    import multiprocessing as mp
-    sets = parse_sets(args.sets)
-    cores = os.cpu_count() or 1
-    workers = args.workers or max(1, cores // 32)
-    threads = max(1, min(32, cores // workers))
-    jobs = []
-    for sid, (h, w, n) in enumerate(sets):
-        nchunks = (n + CHUNK - 1) // CHUNK
-        per = max(1, (nchunks + workers * 2 - 1) // (workers * 2))
-        for c0 in range(0, nchunks, per):
-            jobs.append((sid, h, w, list(range(c0, min(nchunks, c0 + per))), threads))
-    jobs.sort(key=lambda j: -j[1] * j[2] * len(j[3]))
+def hip_anchors(m, gray, ab, idx, fb, l):
+    out, ev = m.forward_once(gray.cuda(), ab.cuda(), True, 0, idx, None, fb.reshape(-1), np.arange(CHUNK, dtype=np.int64) * MF, True)
+    mask = out[5].reshape(CHUNK, l).cpu().numpy()
+    H = np.zeros((CHUNK, K), np.int16)
+    for i in range(CHUNK):                           # the hint mask is the anchors as a multiset: expand it back, sorted
+        toks = np.repeat(np.arange(l), mask[i].astype(np.int64))
+        assert len(toks) == K
+        H[i] = toks
+    return H
+
+
+def stage_run(args):
+    """One worker: the chunks c with c % of == part of every set, the variants asked for, ONE FILE PER (set, chunk, variant) written as soon
+    as it exists - a run that is cut short keeps what it has (the report stage takes what it finds)."""
+    part, of = (int(v) for v in args.part.split("/"))
+    torch.set_num_threads(args.threads)
+    os.makedirs(args.dir, exist_ok=True)
+    m = None
     t0 = time.time()
-    res = {}
-    with mp.get_context("spawn").Pool(workers) as pool:
-        for sid, out in pool.imap_unordered(cpu_worker, jobs):
-            res.setdefault(sid, {}).update(out)
-            print("[cpu] set %d: %d chunks done, %.0f s" % (sid, len(res[sid]), time.time() - t0), flush=True)
-    save = {"sets": np.asarray([(h, w, n) for h, w, n in sets], np.int32)}
-    for sid, chunks in res.items():
-        order = sorted(chunks)
-        for vi, name in enumerate("ABC"):
-            save["s%d_%s" % (sid, name)] = np.concatenate([chunks[c][vi][0] for c in order]).astype(np.int16)
-            save["s%d_%s_passes" % (sid, name)] = np.concatenate([chunks[c][vi][1] for c in order]).astype(np.int16)
-            save["s%d_%s_events" % (sid, name)] = np.concatenate([chunks[c][vi][2] for c in order]).astype(np.int16)
-    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
-    np.savez_compressed(args.out, **save)
-    print("[cpu] wrote %s in %.0f s (%d workers x %d threads of %d cores)" % (args.out, time.time() - t0, workers, threads, cores))
+    for (h, w, n) in parse_sets(args.sets):
+        l = (h // 16) * (w // 16)
+        for c in range(n // CHUNK):
+            if c % of != part:
+                continue
+            inputs = None
+            for v in args.variants:
+                if v in args.limit and c >= args.limit[v]:
+                    continue
+                path = os.path.join(args.dir, "%dx%d_c%04d_%s.npy" % (h, w, c, v))
+                if os.path.exists(path):
+                    continue
+                if inputs is None:
+                    inputs = chunk_inputs(0, c, h, w)
+                if v == "H":
+                    if m is None:
+                        from disentangledcolorization_amd import synth
+                        from disentangledcolorization_amd.model import AnchorColorProb
+                        m = AnchorColorProb(n_clusters=K, enhanced=True, init_weights=False)
+                        m.load_state_dict(synth.synth_state_dict(130))
+                        m = m.cuda().eval()
+                        m.range_checks = 0
+                    a = hip_anchors(m, *inputs, l)
+                else:
+                    a = variant_anchors(v, *inputs)
+                np.save(path + ".tmp.npy", a)
+                os.replace(path + ".tmp.npy", path)
+            if c % (of * 8) == part:
+                print("[%s %d/%d] %dx%d chunk %d, %.0f s" % (args.variants, part, of, h, w, c, time.time() - t0), flush=True)
 
 
 def same_set(a, b):
@@ -122,52 +153,52 @@ def same_set(a, b):
     return np.all(np.sort(a, 1) == np.sort(b, 1), 1)
 
 
-def stage_hip(args):
+NAMES = {"A": "oracle (CPU fp32, oneDNN)", "B": "CPU fp32, oneDNN off (im2col + sgemm)", "C": "CPU fp64", "G": "torch-ROCm fp32 (im2col + rocBLAS)",
+         "D": "torch-ROCm fp64", "H": "HIP path (f16x3 anchor stacks)"}
+
+
+def stage_report(args):
+    import glob
     import bench
-    from disentangledcolorization_amd import synth
-    from disentangledcolorization_amd.model import AnchorColorProb
-    cpu, sets = {}, []
-    for path in args.cpu.split(","):             # one file per set is fine (the cpu stage can be run set by set)
-        d = np.load(path)
-        for sid, r in enumerate(d["sets"]):
-            for v in "ABC":
-                cpu["s%d_%s" % (len(sets), v)] = d["s%d_%s" % (sid, v)]
-            sets.append(tuple(int(x) for x in r))
-    sd = synth.synth_state_dict(130)
-    m = AnchorColorProb(n_clusters=K, enhanced=True, init_weights=False)
-    m.load_state_dict(sd)
-    m = m.cuda().eval()
-    m.range_checks = 0
-    report = {"source_hash": bench.source_hash(), "precision": "default (f16x3 on SpixelNet + ColorProbNet)", "k": K, "sets": {}}
+    report = {"source_hash": bench.source_hash(), "precision": "default (f16x3 on SpixelNet + ColorProbNet)", "k": K, "variants": NAMES, "sets": {}}
     lines = []
-    for sid, (h, w, n) in enumerate(sets):
-        A, B, Cc = (cpu["s%d_%s" % (sid, v)].astype(np.int32) for v in "ABC")
-        n = A.shape[0]
-        H = np.zeros_like(A)
-        l = (h // 16) * (w // 16)
-        for c in range(n // CHUNK):
-            gray, ab, idx, fb = chunk_inputs(sid, c, h, w)
-            stream = fb                                     # image i reads ITS row: bases i * MF into the flattened table
-            out, ev = m.forward_once(gray.cuda(), ab.cuda(), True, 0, idx, None, fb.reshape(-1), np.arange(CHUNK, dtype=np.int64) * MF, True)
-            mask = out[5].reshape(CHUNK, l).cpu().numpy()
-            for i in range(CHUNK):                           # the hint mask is the anchors as a multiset: expand it back, sorted
-                toks = np.repeat(np.arange(l), mask[i].astype(np.int64))
-                assert len(toks) == K
-                H[c * CHUNK + i] = toks
-        hA, bA, cA = ~same_set(H, A), ~same_set(B, A), ~same_set(Cc, A)
-        hC = ~same_set(H, Cc)
-        near = bA | cA                                       # images some exact-arithmetic evaluation decides differently from A
-        rec = {"n": int(n), "hip_vs_oracle": int(hA.sum()), "fp32_other_order_vs_oracle": int(bA.sum()), "fp64_vs_oracle": int(cA.sum()),
-               "hip_vs_fp64": int(hC.sum()), "hip_mismatches_that_fp32_other_order_or_fp64_also_flip": int((hA & near).sum()),
-               "hip_mismatches_only_hip_flips": int((hA & ~near).sum()), "rate_hip_vs_oracle": round(float(hA.mean()), 5),
-               "rate_fp32_other_order_vs_oracle": round(float(bA.mean()), 5), "rate_fp64_vs_oracle": round(float(cA.mean()), 5),
-               "hip_mismatch_images": np.nonzero(hA)[0].tolist()[:32]}
+    for (h, w, n) in parse_sets(args.sets):
+        tab = {}
+        for v in NAMES:
+            for path in sorted(glob.glob(os.path.join(args.dir, "%dx%d_c*_%s.npy" % (h, w, v)))):
+                c = int(os.path.basename(path).split("_c")[1][:4])
+                tab.setdefault(v, {})[c] = np.load(path).astype(np.int32)
+        if "A" not in tab or "H" not in tab:
+            continue
+        rec = {}
+        chunks_ah = sorted(set(tab["A"]) & set(tab["H"]))
+        A = np.concatenate([tab["A"][c] for c in chunks_ah]); H = np.concatenate([tab["H"][c] for c in chunks_ah])
+        hA = ~same_set(H, A)
+        rec["n"] = int(len(A)); rec["hip_vs_oracle"] = int(hA.sum()); rec["rate_hip_vs_oracle"] = round(float(hA.mean()), 5)
+        rec["hip_mismatch_images"] = np.nonzero(hA)[0].tolist()[:64]
+        line = "%4dx%-4d | HIP != oracle: %d of %d (%.3f %%)" % (h, w, hA.sum(), len(A), 100 * hA.mean())
+        near_any = np.zeros(len(A), bool); covered = np.ones(len(A), bool)
+        for v in "BCGD":
+            if v not in tab:
+                continue
+            cs = sorted(set(tab[v]) & set(chunks_ah))
+            sel = np.concatenate([np.arange(chunks_ah.index(c) * CHUNK, chunks_ah.index(c) * CHUNK + CHUNK) for c in cs])
+            V = np.concatenate([tab[v][c] for c in cs])
+            vA = ~same_set(V, A[sel]); vH = ~same_set(V, H[sel])
+            both = vA & hA[sel]
+            rec[v] = {"name": NAMES[v], "n": int(len(V)), "vs_oracle": int(vA.sum()), "rate_vs_oracle": round(float(vA.mean()), 5),
+                      "vs_hip": int(vH.sum()), "hip_mismatches_in_these_images": int(hA[sel].sum()), "of_which_this_variant_also_differs_from_oracle": int(both.sum())}
+            line += " | %s != oracle: %d of %d (%.3f %%), != HIP: %d; of HIP's %d mismatches here it flips %d" % (
+                NAMES[v], vA.sum(), len(V), 100 * vA.mean(), vH.sum(), hA[sel].sum(), both.sum())
+            if v in "GD" and len(V) == len(A):
+                near_any |= vA
+        if all(v in tab and len(tab[v]) == len(chunks_ah) for v in "GD"):
+            rec["hip_mismatches_also_flipped_by_an_exact_evaluation"] = int((hA & near_any).sum())
+            rec["hip_mismatches_flipped_by_hip_alone"] = int((hA & ~near_any).sum())
+            line += " | HIP mismatches that an exact evaluation (fp32 other order or fp64) flips too: %d, HIP alone: %d" % ((hA & near_any).sum(), (hA & ~near_any).sum())
         report["sets"]["%dx%d" % (h, w)] = rec
-        lines.append("%4dx%-4d n=%4d | HIP != oracle(fp32,oneDNN): %3d (%.2f %%) | fp32 other order != oracle: %3d (%.2f %%) | fp64 != oracle: %3d (%.2f %%) | "
-                     "HIP != fp64: %3d | of HIP's mismatches, also flipped by the fp32 control or fp64: %d, by HIP alone: %d"
-                     % (h, w, n, rec["hip_vs_oracle"], 100 * hA.mean(), rec["fp32_other_order_vs_oracle"], 100 * bA.mean(), rec["fp64_vs_oracle"],
-                        100 * cA.mean(), rec["hip_vs_fp64"], rec["hip_mismatches_that_fp32_other_order_or_fp64_also_flip"], rec["hip_mismatches_only_hip_flips"]))
-        print(lines[-1], flush=True)
+        lines.append(line)
+        print(line, flush=True)
     report["table"] = lines
     with open(args.out, "w") as f:
         json.dump(report, f, indent=1)
@@ -176,10 +207,14 @@ def stage_hip(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("stage", choices=["cpu", "hip"])
+    ap.add_argument("stage", choices=["run", "report"])
     ap.add_argument("--sets", default="256x256:2048,512x512:512,768x512:512")
-    ap.add_argument("--workers", type=int, default=0)
-    ap.add_argument("--cpu", default=os.path.join(REPO, "profiles", "r06_anchor_study_cpu.npz"))
-    ap.add_argument("--out", required=True)
+    ap.add_argument("--variants", default="A", help="letters of A B C (CPU) G D (torch on the GPU) H (the HIP path)")
+    ap.add_argument("--limit", default="", help="e.g. B:16,C:4 - at most that many chunks (of %d images) per set for a variant" % CHUNK)
+    ap.add_argument("--part", default="0/1", help="k/n: this worker takes the chunks c with c %% n == k")
+    ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--dir", default=os.path.join(REPO, "gpurun_out", "anchor_study"))
+    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "anchor_study", "anchor_mismatch.json"))
     a = ap.parse_args()
-    (stage_cpu if a.stage == "cpu" else stage_hip)(a)
+    a.limit = {p.split(":")[0]: int(p.split(":")[1]) for p in a.limit.split(",") if p}
+    (stage_run if a.stage == "run" else stage_report)(a)
