@@ -160,6 +160,16 @@ def synth_inputs(n: int, h: int = 256, w: int = 256, seed: int = 5, ab_scale: fl
     return torch.from_numpy(gray), torch.from_numpy(ab)
 
 
+def small_superpixel_variant(sd, slot: int = 0, boost: float = 4.0):
+    """The checkpoint `sd` with SpixelNet's affinity head biased towards neighbour slot `slot` (pred_mask0.bias[slot] += boost): nearly
+    every pixel then votes for that neighbour cell, so the cells along the opposite image border end up with (almost) no pixels of their
+    own - superpixels smaller than 25 pixels, which is what `use_mask` marks (model.py:121-124).  The plain synthetic checkpoint produces
+    none, so a use_mask test on it would compare two identical forwards.  Test data generation."""
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    out["segnet.net.pred_mask0.bias"][slot] += boost
+    return out
+
+
 def student_t_variant(sd, df: float, seed: int = 7, prefixes=("repnet.", "enhanceNet.")):
     """The checkpoint `sd` with the 3x3 conv weights under `prefixes` redrawn from a Student-t(df) distribution at the SAME per-tensor
     standard deviation (heavy tails as trained conv weights have them: a few weights per row far above the rest - what a block-scaled

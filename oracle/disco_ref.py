@@ -265,8 +265,14 @@ def position_encoding(h: int, w: int, n_feats: int = 32, temperature: float = 10
 # --------------------------------------------------------------------------------------
 
 
-def encoder_layer(sd: SD, pre: str, x: Tensor, pos: Tensor, n_head: int = 8) -> Tensor:
-    """x,pos: (N,L,E).  q=k=x+pos, v=x; post-norm; dropouts are identity in eval."""
+def encoder_layer(sd: SD, pre: str, x: Tensor, pos: Tensor, n_head: int = 8, key_bias: Optional[Tensor] = None) -> Tensor:
+    """x,pos: (N,L,E).  q=k=x+pos, v=x; post-norm; dropouts are identity in eval.
+    key_bias (N,L) float: `use_mask` (model.py:122-124,133,186 -> transformer2d.py:53-54 `key_padding_mask=`).  The reference hands
+    nn.MultiheadAttention a FLOAT mask (1.0 at superpixels smaller than 25 pixels, else 0.0); torch >= 1.9 treats a float
+    key_padding_mask as ADDITIVE - F.multi_head_attention_forward merges it into attn_mask and computes
+    baddbmm(attn_mask, q_scaled, k^T) = mask + q k^T before the softmax - so the small superpixels' keys get +1.0 on every score
+    (pinned on the live reference under this container's torch 2.10: tests/golden/fwd_usemask_*.npz).  The reference's own pin,
+    torch 1.8 (environment.yaml:59), rejects a float mask in its masked_fill: there the option cannot run at all."""
     n, l, e = x.shape
     hd = e // n_head
     w_in, b_in = sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"]
@@ -275,7 +281,10 @@ def encoder_layer(sd: SD, pre: str, x: Tensor, pos: Tensor, n_head: int = 8) -> 
     k = F.linear(qk_in, w_in[e:2 * e], b_in[e:2 * e])
     v = F.linear(x, w_in[2 * e:], b_in[2 * e:])
     split = lambda t: t.reshape(n, l, n_head, hd).permute(0, 2, 1, 3)  # (N,heads,L,hd)
-    att = torch.softmax(split(q) @ split(k).transpose(-1, -2), dim=-1)
+    scores = split(q) @ split(k).transpose(-1, -2)
+    if key_bias is not None:
+        scores = key_bias.to(scores.dtype)[:, None, None, :] + scores
+    att = torch.softmax(scores, dim=-1)
     o = (att @ split(v)).permute(0, 2, 1, 3).reshape(n, l, e)
     o = F.linear(o, sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"])
     x = F.layer_norm(x + o, (e,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], LN_EPS)
@@ -284,11 +293,16 @@ def encoder_layer(sd: SD, pre: str, x: Tensor, pos: Tensor, n_head: int = 8) -> 
     return F.layer_norm(x + f, (e,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], LN_EPS)
 
 
-def encoder_stack(sd: SD, path: str, x: Tensor, pos: Tensor, n_layers: int = 6) -> Tensor:
-    """Dense-pos variant (transformer2d.py:18-22): pos is re-added to q,k in every layer."""
+def encoder_stack(sd: SD, path: str, x: Tensor, pos: Tensor, n_layers: int = 6, key_bias: Optional[Tensor] = None) -> Tensor:
+    """Dense-pos variant (transformer2d.py:18-22): pos is re-added to q,k in every layer; key_bias: see encoder_layer."""
     for i in range(n_layers):
-        x = encoder_layer(sd, f"{path}.layers.{i}.", x, pos)
+        x = encoder_layer(sd, f"{path}.layers.{i}.", x, pos, key_bias=key_bias)
     return x
+
+
+def entry_mask(sizes: Tensor, sp: int) -> Tensor:
+    """model.py:121-124,96-101: 1.0 where a superpixel holds fewer than 25 pixels (spixel_sizes < 25 / sp^2), else 0.0; (N,L)."""
+    return (sizes < 25.0 / (sp * sp)).to(sizes.dtype).flatten(1)
 
 
 # --------------------------------------------------------------------------------------
@@ -556,7 +570,7 @@ class DiscoOracle:
     """Holds a checkpoint `state_dict` and replays AnchorColorProb.forward on the CPU."""
 
     def __init__(self, state_dict: SD, q_to_ab: np.ndarray, sp_size: int = 16, n_clusters: int = 8,
-                 random_hint: bool = False, hint2regress: bool = False, spix_pos: bool = False):
+                 random_hint: bool = False, hint2regress: bool = False, spix_pos: bool = False, use_mask: bool = False):
         self.sd = {k: v.detach().clone() for k, v in state_dict.items()}
         self.q_to_ab = torch.as_tensor(np.asarray(q_to_ab), dtype=torch.float32)
         self.sp = sp_size
@@ -564,6 +578,7 @@ class DiscoOracle:
         self.random_hint = random_hint
         self.hint2regress = hint2regress      # model.py:63-64,177-181,188
         self.spix_pos = spix_pos              # model.py:106-112
+        self.use_mask = use_mask              # model.py:38,124
 
     # -- stages ---------------------------------------------------------------------
     def tokens(self, gray: Tensor, ab: Tensor, observer=None, taps=None):
@@ -627,7 +642,8 @@ class DiscoOracle:
         n, l, _ = src.shape
         h, w = gray.shape[2] // self.sp, gray.shape[3] // self.sp
         to_map = lambda t: t.transpose(1, 2).reshape(t.shape[0], -1, h, w)
-        enc = encoder_stack(sd, "wildpath", src, pos)
+        pad = entry_mask(sizes, self.sp) if self.use_mask else None       # the same mask for both stacks (model.py:124-125)
+        enc = encoder_stack(sd, "wildpath", src, pos, key_bias=pad)
         pal_logit = to_map(F.linear(enc, sd["mid_word_prj.weight"]))
         if self.random_hint and hint_mask is None:
             hint_mask = random_anchor_mask(n, h, w, self.k)
@@ -643,12 +659,14 @@ class DiscoOracle:
                 raise RuntimeError("diverse sampling is defined for N=1 only (reference expand() fails for N>1)")
             colors = torch.cat([sample_anchor_colors(prob, self.q_to_ab, t) for t in (0, 1, 2)], 0)
             gray, aff, src, pos, mask = (t.expand(3, *t.shape[1:]) for t in (gray, aff, src, pos, mask))
-            n = 3
+            n = 3       # (the reference does NOT expand src_pad_mask: with use_mask its hint path fails for --diverse; neither is combined here)
+            if pad is not None:
+                raise RuntimeError("use_mask with diverse sampling: the reference's (1,L) key_padding_mask does not match its batch of 3")
         else:
             colors = sample_anchor_colors(prob, self.q_to_ab, 0)
         labels = color_labels(colors, self.q_to_ab).reshape(n, l)
         hint = self.hint_tokens(src, labels, mask, colors)
-        dec = encoder_stack(sd, "hintpath", hint, pos)
+        dec = encoder_stack(sd, "hintpath", hint, pos, key_bias=pad)
         ref_logit = to_map(F.linear(dec, sd["trg_word_prj.weight"]))
         full = upfeat(to_map(dec), aff, self.sp)
         pre = enhance_forward(sd, torch.cat((gray, full), 1), observer)

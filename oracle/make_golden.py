@@ -27,14 +27,14 @@ def npy(t):
 
 
 def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed=5, full=True, sub=1,
-             feat_stride=8, aff_stride=4, test_mode=True, hint2regress=False, spix_pos=False, inputs=None, extra=None):
+             feat_stride=8, aff_stride=4, test_mode=True, hint2regress=False, spix_pos=False, inputs=None, extra=None, use_mask=False):
     ref_harness.install()
     import clusterkit  # reference module
 
     if hint2regress:
         sd = synth.synth_state_dict(SEED, hint2regress=True)
     m = ref_harness.build_reference_model(sd, n_clusters=k, random_hint=random_hint, hint2regress=hint2regress,
-                                          spix_pos=spix_pos)
+                                          spix_pos=spix_pos, use_mask=use_mask)
     gray, ab = inputs if inputs is not None else synth.synth_inputs(n, h, w, seed=input_seed, ab_scale=0.5)
     cap = {}
     orig_km = clusterkit.batch_kmeans_pytorch
@@ -50,6 +50,7 @@ def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed
         m.wildpath.register_forward_hook(lambda mod, i, o: cap.__setitem__("enc", o[0])),
         m.hintpath.register_forward_hook(lambda mod, i, o: cap.__setitem__("dec", o[0])),
         m.hintpath.register_forward_pre_hook(lambda mod, i: cap.__setitem__("hint", i[0])),
+        m.wildpath.register_forward_pre_hook(lambda mod, i: cap.__setitem__("pad_mask", i[2] if len(i) > 2 else None)),
         m.enhanceNet.register_forward_hook(lambda mod, i, o: cap.__setitem__("pre_tanh", o)),
     ]
     # seeding exactly like main/colorizer/inference.py:58-60 (+ python random for random_hint)
@@ -71,6 +72,8 @@ def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed
         strides=np.array([feat_stride, aff_stride], dtype=np.int64),
         pred_absmax=np.array(float(pred.abs().max())),
     )
+    if cap.get("pad_mask") is not None:      # use_mask: the float key_padding_mask both stacks received (model.py:121-125)
+        d["pad_mask"] = npy(cap["pad_mask"])
     if "cluster_mask" in cap:
         d["cluster_ids"] = npy(cap["cluster_mask"].argmax(dim=1).flatten(1)).astype(np.int16)  # (N,L)
     if full:
@@ -255,6 +258,14 @@ def networks_case(sd):
                         spixelnet=npy(outs["segnet.net."]), colorprobnet=npy(outs["repnet."]), hourglass2=npy(outs["enhanceNet."]))
 
 
+def usemask_cases(sd):
+    # use_mask (model.py:38,121-125): on the checkpoint variant that HAS superpixels below 25 pixels (synth.small_superpixel_variant) -
+    # the float key_padding_mask is additive under this container's torch 2.10 (oracle/disco_ref.py encoder_layer)
+    sd_small = synth.small_superpixel_variant(sd)
+    run_case("fwd_usemask_128x192_k8", sd_small, n=2, h=128, w=192, k=8, input_seed=15, use_mask=True)
+    run_case("fwd_usemask_512_k8", sd_small, n=1, h=512, w=512, k=8, input_seed=16, use_mask=True, full=False, sub=8, feat_stride=16, aff_stride=8)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--networks-only" in sys.argv:
@@ -264,6 +275,8 @@ def main():
     sd = synth.synth_state_dict(SEED)
     if "--photo-only" in sys.argv:
         return photo_case(sd)
+    if "--usemask-only" in sys.argv:
+        return usemask_cases(sd)
     photo_case(sd)
     # the forward variants beyond inference.py's default flags: the validation forward
     # (train_colorizer.py:206), --hint2regress, --spix_pos (inference.py:156,158)
@@ -272,6 +285,7 @@ def main():
     run_case("fwd_spixpos_128x192_k8", sd, n=2, h=128, w=192, k=8, input_seed=13, spix_pos=True)
     run_case("fwd_spixpos_h2r_diverse_128_k16", sd, n=1, h=128, w=128, k=16, sampled_T=2, input_seed=14,
              hint2regress=True, spix_pos=True)
+    usemask_cases(sd)
     if "--variants-only" in sys.argv:
         return
     posthoc()

@@ -59,7 +59,7 @@ def install():
     _installed = True
 
 
-def build_reference_model(state_dict, n_clusters=8, random_hint=False, hint2regress=False, spix_pos=False):
+def build_reference_model(state_dict, n_clusters=8, random_hint=False, hint2regress=False, spix_pos=False, use_mask=False):
     """The reference AnchorColorProb exactly as main/colorizer/inference.py:71-74,85,89 builds it
     (--hint2regress / --spix_pos: inference.py:156,158)."""
     install()
@@ -67,7 +67,7 @@ def build_reference_model(state_dict, n_clusters=8, random_hint=False, hint2regr
 
     m = model.AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True,
                               spix_pos=spix_pos, learning_pos=False, n_clusters=n_clusters,
-                              random_hint=random_hint, hint2regress=hint2regress, enhanced=True)
+                              random_hint=random_hint, hint2regress=hint2regress, enhanced=True, use_mask=use_mask)
     m.load_state_dict(state_dict)  # strict
     m.eval()
     return m

@@ -185,7 +185,10 @@ def _run(golden_dir, synth_sd, q_to_ab, name):
     else:
         gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
     sd = synth.synth_state_dict(seed, hint2regress=True) if h2r else synth_sd
-    oracle = R.DiscoOracle(sd, q_to_ab, n_clusters=k, random_hint=bool(rh), hint2regress=h2r, spix_pos=spos)
+    use_mask = "pad_mask" in g.files       # use_mask fixtures: made on the checkpoint variant that has superpixels below 25 pixels
+    if use_mask:
+        sd = synth.small_superpixel_variant(sd)
+    oracle = R.DiscoOracle(sd, q_to_ab, n_clusters=k, random_hint=bool(rh), hint2regress=h2r, spix_pos=spos, use_mask=use_mask)
     np.random.seed(seed); torch.manual_seed(seed); random.seed(seed)
     out, info = oracle.forward(gray, ab, sampled_T=T, return_info=True, test_mode=test_mode)
     return g, out, info
@@ -198,6 +201,9 @@ def _check_forward(g, out, info):
     _close(info["feats"][:, :, ::fs, ::fs], g["feats_sub"], 1e-4)   # features are O(10)
     _close(aff[: g["aff_sub"].shape[0], :, ::as_, ::as_], g["aff_sub"], 1e-5)
     _close(info["enc"], g["enc"], 1e-4)
+    if "pad_mask" in g.files:          # the float key_padding_mask the reference built (model.py:121-125): must be non-trivial and equal
+        pad = R.entry_mask(info["sizes"], 16)
+        assert torch.equal(pad, torch.from_numpy(g["pad_mask"])) and 0 < float(pad.sum()) < pad.numel()
     if "cluster_ids" in g.files:
         assert np.array_equal(info["assign"].numpy(), g["cluster_ids"].astype(np.int64))
     assert torch.equal(mask, torch.from_numpy(g["hint_mask"]))      # anchors bit-exact
@@ -219,10 +225,31 @@ def _check_forward(g, out, info):
                                   "fwd_val_128_k8", "fwd_h2r_128_k8", "fwd_spixpos_128x192_k8",
                                   "fwd_spixpos_h2r_diverse_128_k16",
                                   # two of the photographs the reference ships (data/*.jpg), 256 x 256 (round 4)
-                                  "fwd_photo_256_k8"])
+                                  "fwd_photo_256_k8",
+                                  # use_mask=True (model.py:38,121-125): float key_padding_mask, additive under torch >= 1.9 (round 6)
+                                  "fwd_usemask_128x192_k8", "fwd_usemask_512_k8"])
 def test_forward_matches_reference(golden_dir, synth_sd, q_to_ab, name):
     g, out, info = _run(golden_dir, synth_sd, q_to_ab, name)
     _check_forward(g, out, info)
+
+
+def test_use_mask_changes_the_result_and_is_additive(golden_dir, synth_sd, q_to_ab):
+    """The use_mask fixtures are not vacuous: without the mask the same inputs give another encoder output; and the mask is ADDITIVE
+    (+1.0 on the small superpixels' scores, torch >= 1.9) - a boolean reading (those keys excluded) gives yet another."""
+    from disentangledcolorization_amd import synth
+    g = _load(golden_dir, "fwd_usemask_128x192_k8")
+    n, h, w, k, T, rh, iseed, seed = (int(v) for v in g["recipe"])
+    gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
+    sd = synth.small_superpixel_variant(synth_sd)
+    o = R.DiscoOracle(sd, q_to_ab, n_clusters=k)
+    aff, feats, src, pos, spix_ab, sizes = o.tokens(gray, ab)
+    pad = R.entry_mask(sizes, 16)
+    plain = R.encoder_stack(sd, "wildpath", src, pos)
+    added = R.encoder_stack(sd, "wildpath", src, pos, key_bias=pad)
+    excluded = R.encoder_stack(sd, "wildpath", src, pos, key_bias=pad * -1e30)
+    want = torch.from_numpy(g["enc"])
+    assert (added - want).abs().max() < 1e-4
+    assert (plain - want).abs().max() > 1e-3 and (excluded - want).abs().max() > 1e-3
 
 
 def test_diverse_requires_single_image(synth_sd, q_to_ab):

@@ -109,6 +109,34 @@ def hip_anchors(m, gray, ab, idx, fb, l):
     return H
 
 
+def load_all(dirs, h, w, v):
+    """{chunk: anchors (CHUNK, K)} of one set and variant from loose chunk files (<dir>/HxW_cNNNN_V.npy) and packed stores (<dir>/HxW_V.npz)."""
+    import glob
+    out = {}
+    for d in dirs:
+        pk = os.path.join(d, "%dx%d_%s.npz" % (h, w, v))
+        if os.path.exists(pk):
+            z = np.load(pk)
+            for c, a in zip(z["chunks"], z["anchors"]):
+                out[int(c)] = a.astype(np.int32)
+        for path in glob.glob(os.path.join(d, "%dx%d_c*_%s.npy" % (h, w, v))):
+            out[int(os.path.basename(path).split("_c")[1][:4])] = np.load(path).astype(np.int32)
+    return out
+
+
+def stage_pack(args):
+    """Loose chunk files of --dir (+ what --store already holds) -> one small npz per (set, variant) under --store (tracked: profiles/)."""
+    os.makedirs(args.store, exist_ok=True)
+    for (h, w, n) in parse_sets(args.sets):
+        for v in args.variants:
+            tab = load_all([args.store, args.dir], h, w, v)
+            if tab:
+                cs = sorted(tab)
+                np.savez_compressed(os.path.join(args.store, "%dx%d_%s.npz" % (h, w, v)), chunks=np.asarray(cs, np.int32),
+                                    anchors=np.stack([tab[c] for c in cs]).astype(np.int16))
+                print("%dx%d %s: %d chunks" % (h, w, v, len(cs)))
+
+
 def stage_run(args):
     """One worker: the chunks c with c % of == part of every set, the variants asked for, ONE FILE PER (set, chunk, variant) written as soon
     as it exists - a run that is cut short keeps what it has (the report stage takes what it finds)."""
@@ -119,6 +147,7 @@ def stage_run(args):
     t0 = time.time()
     for (h, w, n) in parse_sets(args.sets):
         l = (h // 16) * (w // 16)
+        have = {v: set(load_all([args.store], h, w, v)) for v in args.variants if v not in args.redo}
         for c in range(n // CHUNK):
             if c % of != part:
                 continue
@@ -127,7 +156,7 @@ def stage_run(args):
                 if v in args.limit and c >= args.limit[v]:
                     continue
                 path = os.path.join(args.dir, "%dx%d_c%04d_%s.npy" % (h, w, c, v))
-                if os.path.exists(path):
+                if os.path.exists(path) or c in have.get(v, ()):
                     continue
                 if inputs is None:
                     inputs = chunk_inputs(0, c, h, w)
@@ -165,9 +194,9 @@ def stage_report(args):
     for (h, w, n) in parse_sets(args.sets):
         tab = {}
         for v in NAMES:
-            for path in sorted(glob.glob(os.path.join(args.dir, "%dx%d_c*_%s.npy" % (h, w, v)))):
-                c = int(os.path.basename(path).split("_c")[1][:4])
-                tab.setdefault(v, {})[c] = np.load(path).astype(np.int32)
+            t = load_all([args.store, args.dir], h, w, v)
+            if t:
+                tab[v] = t
         if "A" not in tab or "H" not in tab:
             continue
         rec = {}
@@ -207,14 +236,16 @@ def stage_report(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("stage", choices=["run", "report"])
+    ap.add_argument("stage", choices=["run", "report", "pack"])
     ap.add_argument("--sets", default="256x256:2048,512x512:512,768x512:512")
     ap.add_argument("--variants", default="A", help="letters of A B C (CPU) G D (torch on the GPU) H (the HIP path)")
     ap.add_argument("--limit", default="", help="e.g. B:16,C:4 - at most that many chunks (of %d images) per set for a variant" % CHUNK)
     ap.add_argument("--part", default="0/1", help="k/n: this worker takes the chunks c with c %% n == k")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--dir", default=os.path.join(REPO, "gpurun_out", "anchor_study"))
+    ap.add_argument("--store", default=os.path.join(REPO, "profiles", "r06_anchor_study"), help="packed results (tracked); `run` skips the chunks it holds")
+    ap.add_argument("--redo", default="", help="variants to compute again although the store has them (H after a kernel change)")
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "anchor_study", "anchor_mismatch.json"))
     a = ap.parse_args()
     a.limit = {p.split(":")[0]: int(p.split(":")[1]) for p in a.limit.split(",") if p}
-    (stage_run if a.stage == "run" else stage_report)(a)
+    {"run": stage_run, "report": stage_report, "pack": stage_pack}[a.stage](a)
