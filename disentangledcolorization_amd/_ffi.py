@@ -23,7 +23,7 @@ class DiscoError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("sp_size", C.c_int32), ("n_clusters", C.c_int32), ("random_hint", C.c_int32),
                 ("precision", C.c_int32), ("network", C.c_int32), ("hint2regress", C.c_int32),
-                ("spix_pos", C.c_int32)]
+                ("spix_pos", C.c_int32), ("use_mask", C.c_int32)]
 
 
 class ForwardArgs(C.Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
     "disco_op_upfeat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_encoder_weight_floats": (_SZ, []),
     "disco_op_encoder_stack": (_I, [_P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
+    "disco_op_encoder_stack_masked": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _SZ, _P]),
     "disco_op_kmeans_anchors": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "disco_op_kmeans_workspace_bytes": (_SZ, [_I, _I]),
     "disco_op_kmeans_anchors_ws": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),

@@ -1091,7 +1091,9 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
             }
         }
     };
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s, P.dbg_row >= 0 ? &enc_dbg : nullptr, c->d_enc_pk[0]);
+    // use_mask (model.py:121-125): both stacks bias the keys of superpixels below 25 pixels; the mask IS a function of `sizes`, read in the kernels
+    const float* key_sizes = c->opt.use_mask ? sizes : nullptr;
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s, P.dbg_row >= 0 ? &enc_dbg : nullptr, c->d_enc_pk[0], key_sizes, 1);
     P.dbg(enc, (size_t)n * L * 64 * 4);
     if (!dry && P.ok()) P.rc = launch_logits(enc, c->d_mid_w, a->d_pal_logit, n, L, s);
     P.dbg(a->d_pal_logit, (size_t)n * N_VOCAB * L * 4);
@@ -1144,7 +1146,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     float* hint = (float*)P.raw((size_t)n2 * L * 64 * 4);
     float* dec = (float*)P.raw((size_t)n2 * L * 64 * 4);
     if (!dry && P.ok()) P.rc = launch_hint_embed(src, rep, h2r ? nullptr : labels, h2r ? a->d_spix_colors : nullptr, a->d_hint_mask, rep, c->d_emb_w, hint, n2, L, s);
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(hint, pos, pos_rep ? rep : 0, c->d_enc[1], dec, n2, L, enc_ws, s, nullptr, c->d_enc_pk[1]);
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(hint, pos, pos_rep ? rep : 0, c->d_enc[1], dec, n2, L, enc_ws, s, nullptr, c->d_enc_pk[1], key_sizes, rep);
     if (!dry && P.ok()) P.rc = launch_logits(dec, c->d_trg_w, a->d_ref_logit, n2, L, s, h2r ? 2 : N_VOCAB);
     P.drop(enc_ws); P.drop(hint); P.drop(labels); P.drop(d_idx); P.drop(d_fb); P.drop(d_assign); P.drop(d_anchor);
     P.drop(enc); P.drop(src); P.drop(spix_ab); P.drop(sizes); if (pos_img) P.drop(pos_img);
@@ -1279,6 +1281,8 @@ int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
     if (a->test_mode & ~1) { set_error("test_mode must be 0 or 1"); return DISCO_EINVAL; }
     // model.py:178 reads the undefined name `spix_color` when hint2regress meets test_mode=False: the reference raises
     if (!a->test_mode && c->opt.hint2regress) { set_error("hint2regress has no validation forward (models/model.py:178 raises NameError)"); return DISCO_EUNSUPPORTED; }
+    // model.py:154-159 expands everything to the batch of 3 EXCEPT src_pad_mask: nn.MultiheadAttention then rejects the (1,L) mask
+    if (c->opt.use_mask && a->test_mode && a->sampled_T > 0) { set_error("use_mask has no diverse forward (the reference's key_padding_mask keeps batch 1: models/model.py:154-159,186)"); return DISCO_EUNSUPPORTED; }
     return DISCO_OK;
 }
 
@@ -2056,6 +2060,11 @@ size_t disco_op_encoder_weight_floats(void) { return ENC_LAYERS * ENC_LAYER_FLOA
 
 int disco_op_encoder_stack(const float* d_x, const float* d_pos, const float* d_weights, float* d_out, int n, int l, void* d_ws,
                            size_t ws_bytes, void* stream) {
+    return disco_op_encoder_stack_masked(d_x, d_pos, d_weights, nullptr, d_out, n, l, d_ws, ws_bytes, stream);
+}
+
+int disco_op_encoder_stack_masked(const float* d_x, const float* d_pos, const float* d_weights, const float* d_key_sizes, float* d_out, int n,
+                                  int l, void* d_ws, size_t ws_bytes, void* stream) {
     if (!positive("encoder_stack", {n, l})) return DISCO_ESHAPE;
     if (!d_x || !d_pos || !d_weights || !d_out || !d_ws) { set_error("null argument"); return DISCO_EINVAL; }
     if (ws_bytes < encoder_ws_bytes(n, l)) { set_error("encoder workspace too small (%zu < %zu)", ws_bytes, encoder_ws_bytes(n, l)); return DISCO_ENOMEM; }
@@ -2065,9 +2074,9 @@ int disco_op_encoder_stack(const float* d_x, const float* d_pos, const float* d_
     if (ws_bytes >= base + pk) {
         float* d_pk = reinterpret_cast<float*>(static_cast<char*>(d_ws) + base);
         if (int rc = launch_encoder_pack(d_weights, d_pk, (hipStream_t)stream)) return rc;
-        return launch_encoder_stack(d_x, d_pos, 0, d_weights, d_out, n, l, d_ws, (hipStream_t)stream, nullptr, d_pk);
+        return launch_encoder_stack(d_x, d_pos, 0, d_weights, d_out, n, l, d_ws, (hipStream_t)stream, nullptr, d_pk, d_key_sizes, 1);
     }
-    return launch_encoder_stack(d_x, d_pos, 0, d_weights, d_out, n, l, d_ws, (hipStream_t)stream);
+    return launch_encoder_stack(d_x, d_pos, 0, d_weights, d_out, n, l, d_ws, (hipStream_t)stream, nullptr, nullptr, d_key_sizes, 1);
 }
 
 int disco_op_kmeans_anchors(const float* d_x, const float* d_sizes, const int32_t* d_init_idx, const int32_t* d_fallback_rows,

@@ -23,13 +23,19 @@ constexpr int KCH = 256;
 constexpr int KP = 16;     // key partitions (lanes) per query group
 // QT: queries per thread (a block covers (256 / KP) QT of them).  4 for throughput; 1 when the grid would not fill the GPU (one image of
 // 256 tokens: 32 workgroups at QT = 4) - a query's arithmetic does not depend on how many neighbours share its thread: same results
-template <int QT>
+// MASK: `use_mask` (model.py:121-125 -> transformer2d.py:53-54): key j of image i gets +1.0 on every score when superpixel j holds fewer than
+// 25 pixels (key_sizes[i / key_rep][j] < 25/256) - the reference's FLOAT key_padding_mask, additive under torch >= 1.9: score = mask + q k^T
+// (one rounding, like baddbmm).  Without MASK the kernel is the machine code it was.
+constexpr float SMALL_SPIXEL = 25.f / 256.f;
+template <int QT, bool MASK>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                        const float* __restrict__ v, float* out, int L) {
+                                                        const float* __restrict__ v, float* out, int L,
+                                                        const float* __restrict__ key_sizes, int key_rep) {
     // halves of a key / value in separate arrays: the 16 partitions of a wave read 16 consecutive float4 (256 contiguous
     // bytes, no bank conflict; interleaved [key][2] rows put partitions p and p+8 on the same banks)
     __shared__ float4 sk[2][KCH];
     __shared__ float4 sv[2][KCH];
+    __shared__ float sbias[MASK ? KCH : 1];
     const int qb = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
     constexpr int QPB = (256 / KP) * QT;
     const int part = threadIdx.x & (KP - 1);
@@ -58,6 +64,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             const int key = u >> 1, half = u & 1;
             sk[half][key] = *reinterpret_cast<const float4*>(k + base + (size_t)(c0 + key) * 64 + half * 4);
             sv[half][key] = *reinterpret_cast<const float4*>(v + base + (size_t)(c0 + key) * 64 + half * 4);
+            if constexpr (MASK) { if (half == 0) sbias[key] = key_sizes[(size_t)(img / key_rep) * L + c0 + key] < SMALL_SPIXEL ? 1.f : 0.f; }
         }
         __syncthreads();
         float sc[KCH / KP][QT];
@@ -76,7 +83,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                     d = __builtin_elementwise_fma(qv[t][1], k1, d);
                     d = __builtin_elementwise_fma(qv[t][2], k2, d);
                     d = __builtin_elementwise_fma(qv[t][3], k3, d);
-                    sc[i][t] = d.x + d.y;
+                    sc[i][t] = add_rn(d.x, d.y);
+                    if constexpr (MASK) sc[i][t] = add_rn(sbias[j], sc[i][t]);
                     cm[t] = fmaxf(cm[t], sc[i][t]);
                 }
             } else {
@@ -89,9 +97,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int t = 0; t < QT; ++t) {
             const float mn = fmaxf(m[t], cm[t]);
             const float alpha = __expf(m[t] - mn);    // 0 on the lane's first chunk (m = -inf)
-            l[t] *= alpha;
+            l[t] = mul_rn(l[t], alpha);            // (every rounding step spelled out: QT = 1 and QT = 4 must be the same arithmetic)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[t][j] *= alpha;
+            for (int j = 0; j < 4; ++j) o[t][j] = mul_rn2(o[t][j], pair_of(alpha));
             m[t] = mn;
         }
 #pragma unroll
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     const float p = __expf(sc[i][t] - m[t]);
-                    l[t] += p;
+                    l[t] = add_rn(l[t], p);
                     const f32x2 pp{p, p};
                     o[t][0] = __builtin_elementwise_fma(pp, v0, o[t][0]);
                     o[t][1] = __builtin_elementwise_fma(pp, v1, o[t][1]);
@@ -120,17 +128,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
         for (int sft = 1; sft < KP; sft <<= 1) mm = fmaxf(mm, __shfl_xor(mm, sft));
         const float scl = m[t] == -INFINITY ? 0.f : __expf(m[t] - mm);
-        float ls = l[t] * scl;
+        float ls = mul_rn(l[t], scl);
 #pragma unroll
-        for (int sft = 1; sft < KP; sft <<= 1) ls += __shfl_xor(ls, sft);
+        for (int sft = 1; sft < KP; sft <<= 1) ls = add_rn(ls, __shfl_xor(ls, sft));
         const float inv = 1.f / ls;
         f32x2 mine{0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float x = o[t][j].x * scl, y = o[t][j].y * scl;
+            float x = mul_rn(o[t][j].x, scl), y = mul_rn(o[t][j].y, scl);
 #pragma unroll
-            for (int sft = 1; sft < KP; sft <<= 1) { x += __shfl_xor(x, sft); y += __shfl_xor(y, sft); }
-            if (part == j) mine = f32x2{x * inv, y * inv};
+            for (int sft = 1; sft < KP; sft <<= 1) { x = add_rn(x, __shfl_xor(x, sft)); y = add_rn(y, __shfl_xor(y, sft)); }
+            if (part == j) mine = f32x2{mul_rn(x, inv), mul_rn(y, inv)};
         }
         const int qi = q0i + t;
         if (qi < L && part < 4) *reinterpret_cast<f32x2*>(out + base + (size_t)qi * 64 + 2 * part) = mine;
@@ -143,12 +151,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // The form is chosen by the grid the launch would have: QT = 1 when QT = 4 could not give every CU a workgroup.  A query's arithmetic does not
 // depend on how many neighbours share its thread (every rounding step of the softmax is spelled out: mul_rn / add_rn / fmaf), so an
 // image's result does not depend on the batch it is part of (tests/test_gpu_ops.py::test_encoder_stack_result_does_not_depend_on_the_batch).
-int launch_attention_valu(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s) {
+int launch_attention_valu(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes, int key_rep) {
     // (beyond one workgroup per CU the two forms run the same: n = 2 ... 16 images measured with the threshold at 1x, 2x, 5x, 9x the CU count)
-    if ((long)cdiv(l, 64) * N_HEAD * n < num_cus_current())
-        hipLaunchKernelGGL(attention_kernel<1>, dim3(cdiv(l, 16), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l);
+    const bool small = (long)cdiv(l, 64) * N_HEAD * n < num_cus_current();
+    const dim3 grid(cdiv(l, small ? 16 : 64), N_HEAD, n);
+    if (key_sizes) {
+        if (key_rep < 1) { set_error("attention: key_rep %d", key_rep); return DISCO_EINVAL; }
+        if (small) hipLaunchKernelGGL((attention_kernel<1, true>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep);
+        else hipLaunchKernelGGL((attention_kernel<4, true>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep);
+    } else if (small)
+        hipLaunchKernelGGL((attention_kernel<1, false>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, 1);
     else
-        hipLaunchKernelGGL(attention_kernel<4>, dim3(cdiv(l, 64), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l);
+        hipLaunchKernelGGL((attention_kernel<4, false>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, 1);
     DISCO_LAUNCH_CHECK("attention_kernel");
     return DISCO_OK;
 }

@@ -56,13 +56,17 @@ __device__ __forceinline__ float quad_bcast(float x) {     // lane (l & ~3) + SE
 // occupancy: 126 VGPRs, four waves per SIMD (851 us), which this form keeps because a tile's scores die into the P V operands in place.
 // KS: the waves of a workgroup split the KEYS of 32 QW queries (wave u takes the key tiles u, u + NW, ... of every chunk) and merge their partial
 // (maximum, sum, O) through LDS at the end: NW times the waves per query where the plain form cannot fill the GPU (one image)
-template <int QW, int NW, bool KS>
+template <int QW, int NW, bool KS, bool MASK>
 __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                             const float* __restrict__ v, float* out, int L) {
+                                                             const float* __restrict__ v, float* out, int L,
+                                                             const float* __restrict__ key_sizes, int key_rep) {
     constexpr int NTHR = 64 * NW, KPT = AM_KPT, KCH = NTHR * KPT;  // keys per thread and chunk; keys per staged chunk
     constexpr int VTS = KCH + 8;                              // floats per row of the transposed V chunk (rows 32 bytes apart in bank phase)
     __shared__ float4 sK[2][KCH];
     __shared__ __attribute__((aligned(16))) float sVT[8][VTS];
+    // MASK (`use_mask`, see attention.hip): the keys' additive biases of the staged chunk, log2 domain - they START the S^T accumulator of a
+    // tile (row = key), so the matrix pipe adds them for free; same mathematics as attention_kernel's mask + q k^T in another rounding order
+    __shared__ float sBias[MASK ? KCH : 1];
     const int head = blockIdx.y, img = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
     // (a scalar: the tile addresses of the key-split form stay in SGPRs - 166 -> 126 VGPRs, four waves per SIMD there as well: eight images of
@@ -93,13 +97,16 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
     }
     // the chunk in flight: thread t carries keys c0 + t + i NTHR (zeros beyond L: a masked key's p = 0 must not meet a NaN)
     float4 pk0[KPT], pk1[KPT], pv0[KPT], pv1[KPT];
+    float pbias[KPT];
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int key = c0 + tid + i * NTHR;
             const float4 z = {0.f, 0.f, 0.f, 0.f};
             pk0[i] = pk1[i] = pv0[i] = pv1[i] = z;
+            pbias[i] = 0.f;
             if (key < L) {
+                if constexpr (MASK) pbias[i] = key_sizes[(size_t)(img / key_rep) * L + key] < (25.f / 256.f) ? LOG2E : 0.f;
                 pk0[i] = *reinterpret_cast<const float4*>(k + base + (size_t)key * 64);
                 pk1[i] = *reinterpret_cast<const float4*>(k + base + (size_t)key * 64 + 4);
                 pv0[i] = *reinterpret_cast<const float4*>(v + base + (size_t)key * 64);
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
     auto qk_tile = [&](f32x16& s, int w, int t0) __attribute__((always_inline)) {
         const float4 kf = sK[hk][t0 + qn];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        for (int e = 0; e < 16; ++e) s[e] = MASK ? sBias[t0 + 8 * (e >> 2) + 4 * hk + (e & 3)] : 0.f;
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qb[w][0], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qb[w][1], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qb[w][2], s, 0, 0, 0);
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
             const float kq[4] = {kfn.x, kfn.y, kfn.z, kfn.w};
             if constexpr (HAS_NEXT) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) nxt[w][e] = 0.f;
+                for (int e = 0; e < 16; ++e) nxt[w][e] = MASK ? sBias[t0 + TS + 8 * (e >> 2) + 4 * hk + (e & 3)] : 0.f;
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
             sK[1][kk] = float4{pk0[i].y, pk0[i].w, pk1[i].y, pk1[i].w};
             sVT[0][kk] = pv0[i].x; sVT[1][kk] = pv0[i].y; sVT[2][kk] = pv0[i].z; sVT[3][kk] = pv0[i].w;
             sVT[4][kk] = pv1[i].x; sVT[5][kk] = pv1[i].y; sVT[6][kk] = pv1[i].z; sVT[7][kk] = pv1[i].w;
+            if constexpr (MASK) sBias[kk] = pbias[i];
         }
         __syncthreads();
         if (c0 + KCH < L) fetch(c0 + KCH);
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
 }  // namespace
 
 // softmax(q k^T) v per (image, head); q, k, v, out: (n, l, 64) fp32, head h in columns 8 h .. 8 h + 7; q pre-scaled by 1 / sqrt(8)
-int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s) {
+int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes, int key_rep) {
     // One 32-query tile per wave (126 VGPRs: four waves per SIMD; the QW = 2 form - 216 VGPRs, two waves per SIMD - measured 5-25 % slower at every
     // size, profiles/r05_attn_mfma_ab.txt "forms").  Two forms: (2) workgroups of four query tiles sharing the staged chunks; (3) the four waves of
     // a workgroup split the KEYS of one query tile (four times the waves per query: what one image of up to 2 048 tokens needs to fill the GPU).
@@ -300,10 +308,14 @@ int launch_attention_mfma(const float* q, const float* k, const float* v, float*
     // against 97 - still under attention_kernel's 138), beyond it form 2.  DISCO_ATTN_FORM = 2 / 3 forces a form (measurements only).
     static const int forced = [] { const char* e = std::getenv("DISCO_ATTN_FORM"); return e ? atoi(e) : 0; }();
     const int form = forced ? forced : (l > 2048 ? 2 : 3);
-    if (form == 2)
-        hipLaunchKernelGGL((attention_mfma_kernel<1, 4, false>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l);
-    else
-        hipLaunchKernelGGL((attention_mfma_kernel<1, 4, true>), dim3(cdiv(l, 32), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l);
+    if (key_sizes && key_rep < 1) { set_error("attention: key_rep %d", key_rep); return DISCO_EINVAL; }
+    if (form == 2) {
+        if (key_sizes) hipLaunchKernelGGL((attention_mfma_kernel<1, 4, false, true>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep);
+        else hipLaunchKernelGGL((attention_mfma_kernel<1, 4, false, false>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, 1);
+    } else {
+        if (key_sizes) hipLaunchKernelGGL((attention_mfma_kernel<1, 4, true, true>), dim3(cdiv(l, 32), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep);
+        else hipLaunchKernelGGL((attention_mfma_kernel<1, 4, true, false>), dim3(cdiv(l, 32), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, 1);
+    }
     DISCO_LAUNCH_CHECK("attention_mfma_kernel");
     return DISCO_OK;
 }

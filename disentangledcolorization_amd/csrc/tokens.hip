@@ -580,14 +580,21 @@ static int attention_mfma_min_tokens() {
 }
 
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
-                         void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg, const float* packed) {
+                         void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg, const float* packed,
+                         const float* key_sizes, int key_rep) {
     const int T = n * l;
     const bool tail = packed != nullptr && T <= encoder_tail_max_rows();
     float* qkv = reinterpret_cast<float*>(ws);
     float* att = qkv + (size_t)3 * T * 64;
     float* pp[2] = {att + (size_t)T * 64, att + (size_t)2 * T * 64};
     const float* cur = x;
-    static const int dbg_layers = [] { const char* e = std::getenv("DISCO_ENC_DEBUG_LAYERS"); return e ? atoi(e) : ENC_LAYERS; }();
+    // bisecting aid: run only the first k layers.  Clamped to [1, ENC_LAYERS] (0 never wrote `out`, more indexed past the weights: advisor, round 5)
+    static const int dbg_layers = [] {
+        const char* e = std::getenv("DISCO_ENC_DEBUG_LAYERS");
+        const int v = e ? std::min(std::max(atoi(e), 1), (int)ENC_LAYERS) : ENC_LAYERS;
+        if (v != ENC_LAYERS) fprintf(stderr, "[disco] DISCO_ENC_DEBUG_LAYERS=%d: the encoder stacks run %d of %d layers - results are NOT the model's\n", v, v, (int)ENC_LAYERS);
+        return v;
+    }();
     for (int layer = 0; layer < dbg_layers; ++layer) {
         const float* w = weights + (size_t)layer * ENC_LAYER_FLOATS;
         const float* in_w = w;                 const float* in_b = in_w + 192 * 64;
@@ -601,7 +608,11 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         // q,k,v
         g.A = cur; g.pos = pos; g.pos_rep = pos_rep; g.W = in_w; g.ldw = 64; g.bias = in_b; g.K = 64; g.O = 192; g.out = qkv;
         g.q_scale = (float)std::sqrt(1.0 / 8.0);
-        static const bool dbg_noqkv = std::getenv("DISCO_TAIL_NOQKV") != nullptr;      // bisecting aid: the tail kernel without its fused in-projection
+        static const bool dbg_noqkv = [] {      // bisecting aid: the tail kernel without its fused in-projection (same results, one more launch per layer)
+            const bool on = std::getenv("DISCO_TAIL_NOQKV") != nullptr;
+            if (on) fprintf(stderr, "[disco] DISCO_TAIL_NOQKV is set: every encoder layer runs its own q/k/v GEMM\n");
+            return on;
+        }();
         if (!tail || layer == 0 || dbg_noqkv) {           // (the tail path: layers 1.. get their q, k, v from the previous layer's tail kernel)
             int rc = launch_gemm<EPI_QKV>(g, s);
             if (rc) return rc;
@@ -609,10 +620,10 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         if (dbg) (*dbg)(qkv, (size_t)3 * T * 64 * 4);
         // from attention_mfma_min_tokens() tokens on: both contractions on the matrix cores.  The choice depends on the token count alone.
         if (l >= attention_mfma_min_tokens()) {
-            const int rc = launch_attention_mfma(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s);
+            const int rc = launch_attention_mfma(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s, key_sizes, key_rep);
             if (rc) return rc;
         } else {
-            const int rc = launch_attention_valu(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s);
+            const int rc = launch_attention_valu(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s, key_sizes, key_rep);
             if (rc) return rc;
         }
         if (dbg) (*dbg)(att, (size_t)T * 64 * 4);

@@ -10,9 +10,11 @@ All arithmetic runs in hand-written HIP kernels; without the library this module
 Supported: every configuration main/colorizer/inference.py can produce (inference.py:71-74,156-165) -
 enhanced=True, use_dense_pos=True, sp_size=16, d_model=64, clustering or random hints, --diverse, --spix_pos,
 --hint2regress - plus the validation forward of train_colorizer.py:206 (model.eval(), test_mode=False).
-Not supported (NotImplementedError): use_mask=True (never enabled by any caller; the float key_padding_mask it
-builds, model.py:122-124, is rejected by the pinned torch 1.8 `masked_fill`), test_mode=False together with
-hint2regress (model.py:178 reads an undefined name there), training (set_train / gradients).
+use_mask=True (model.py:38,121-125; no caller of the reference enables it) is supported with the semantics of torch >= 1.9, where the
+float key_padding_mask the reference builds is ADDED to the attention scores (+1.0 at superpixels below 25 pixels; the pinned torch 1.8
+rejects a float mask) - pinned on the live reference, tests/golden/fwd_usemask_*.npz; not with sampled_T > 0 (the reference fails there).
+Not supported (NotImplementedError): test_mode=False together with hint2regress (model.py:178 reads an undefined name there),
+training (set_train / gradients).
 """
 import ctypes as C
 import os
@@ -167,12 +169,11 @@ class AnchorColorProb(nn.Module):
         if d_model != 64: unsupported.append("d_model=%r" % d_model)
         if not use_dense_pos: unsupported.append("use_dense_pos=False")
         if not enhanced: unsupported.append("enhanced=False")
-        if use_mask: unsupported.append("use_mask=True")
         if unsupported:
             raise NotImplementedError("outside the MI355X hot path (SURVEY §8b): " + ", ".join(unsupported))
         # learning_pos is accepted and ignored exactly like the reference (model.py:59 hard-codes is_learned=False)
         self.sp_size, self.hint_num, self.random_hint = sp_size, int(n_clusters), bool(random_hint)
-        self.enhanced, self.hint2regress, self.spix_pos, self.use_token_mask = True, bool(hint2regress), bool(spix_pos), False
+        self.enhanced, self.hint2regress, self.spix_pos, self.use_token_mask = True, bool(hint2regress), bool(spix_pos), bool(use_mask)
         self.n_vocab = 313
         self.rank = rank
         self.precision = _PRECISIONS[precision or default_precision()]
@@ -241,7 +242,7 @@ class AnchorColorProb(nn.Module):
         self._drop_ctx()
         L = _ffi.lib()
         opt = _ffi.Options(self.sp_size, self.hint_num, int(self.random_hint), self.precision, 0, int(self.hint2regress),
-                           int(self.spix_pos))
+                           int(self.spix_pos), int(self.use_token_mask))
         ctx = C.c_void_p()
         _ffi.check(L.disco_create(device.index if device.index is not None else torch.cuda.current_device(),
                                   C.byref(opt), C.byref(ctx)))
@@ -426,10 +427,12 @@ class AnchorColorProb(nn.Module):
                 "works under DataParallel as it is." % (like.device, home))
         return origin
 
-    def _check_inputs(self, input_grays, input_colors, test_mode):
+    def _check_inputs(self, input_grays, input_colors, test_mode, sampled_T=0):
         test_mode = bool(test_mode)
         if not test_mode and self.hint2regress:
             raise NotImplementedError("hint2regress has no test_mode=False forward: models/model.py:178 raises NameError")
+        if self.use_token_mask and test_mode and int(sampled_T) > 0:
+            raise NotImplementedError("use_mask has no --diverse forward: the reference's key_padding_mask keeps batch 1 (models/model.py:154-159,186)")
         if not input_grays.is_cuda:
             raise _ffi.DiscoError("AnchorColorProb needs CUDA/HIP tensors: the HIP path has no CPU fallback")
         dev = input_grays.device
@@ -473,7 +476,7 @@ class AnchorColorProb(nn.Module):
         if origin is not None:
             return origin.forward_once(input_grays, input_colors, test_mode, sampled_T, init_idx, hint_pos, fallback_stream, fallback_bases,
                                        want_events, out, range_check)
-        test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
+        test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode, sampled_T)
         dev = gray.device
         n, _, H, W = gray.shape
         sp = self.sp_size
@@ -591,7 +594,7 @@ class AnchorColorProb(nn.Module):
         origin = self._replica_origin(input_grays)
         if origin is not None:
             return origin.forward_with_draws(input_grays, input_colors, test_mode, sampled_T, init_idx, hint_pos)
-        test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode)
+        test_mode, gray, ab = self._check_inputs(input_grays, input_colors, test_mode, sampled_T)
         n, _, H, W = gray.shape
         l = (H // self.sp_size) * (W // self.sp_size)
         if self.random_hint:

@@ -114,6 +114,10 @@ typedef struct disco_options {
     int32_t spix_pos;     /* 1: --spix_pos (inference.py:156): the sine position encoding is evaluated per PIXEL and
                              pooled into the superpixels together with the features, so every image has its own
                              position sequence (model.py:106-112) */
+    int32_t use_mask;     /* (ABI 11) 1: use_mask=True (model.py:38,121-125,133,186): both encoder stacks receive the reference's
+                             FLOAT key_padding_mask - 1.0 at superpixels of fewer than 25 pixels (get_spixel_size < 25/256) - which
+                             nn.MultiheadAttention ADDS to the scores under torch >= 1.9 (the pinned torch 1.8 rejects a float mask;
+                             oracle/disco_ref.py encoder_layer).  Not combinable with sampled_T > 0 (the reference fails there) */
 } disco_options;
 
 int disco_create(int device, const disco_options *opt, disco_ctx **out);
@@ -352,6 +356,10 @@ int disco_op_upfeat(const float *d_tok, const float *d_prob, float *d_out, int n
 size_t disco_op_encoder_weight_floats(void);
 int disco_op_encoder_stack(const float *d_x, const float *d_pos, const float *d_weights, float *d_out, int n,
                            int l, void *d_ws, size_t ws_bytes, void *stream);
+/* ... with use_mask's key bias (ABI 11): d_key_sizes (n,l) = get_spixel_size of every token; keys below 25/256 get +1.0 on
+ * every attention score of every layer (transformer2d.py:53-54 with the float key_padding_mask of model.py:121-125) */
+int disco_op_encoder_stack_masked(const float *d_x, const float *d_pos, const float *d_weights, const float *d_key_sizes,
+                                  float *d_out, int n, int l, void *d_ws, size_t ws_bytes, void *stream);
 
 /* k-means (clusterkit.py:112-208) + anchors (anchor_gen.py:96-101) on n point sets of l points with d <= 64
  * features: d_x is (n,l,d) row-major, or (n,d,l) when channel_major (NCHW maps such as the pooled colours that the

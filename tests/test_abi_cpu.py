@@ -71,8 +71,7 @@ def test_dropin_state_dict_contract(synth_sd):
     m.eval()
     with pytest.raises(NotImplementedError):
         AnchorColorProb(enhanced=False)
-    with pytest.raises(NotImplementedError):
-        AnchorColorProb(enhanced=True, use_mask=True)
+    assert AnchorColorProb(enhanced=True, use_mask=True, init_weights=False).use_token_mask is True      # (round 6: supported, model.py:38)
     # --hint2regress checkpoints carry differently shaped head tensors (model.py:63-64); strict both ways
     h = AnchorColorProb(enhanced=True, hint2regress=True, spix_pos=True, init_weights=False)
     assert tuple(h.state_dict()["trg_word_emb.weight"].shape) == (64, 67)

@@ -25,14 +25,16 @@ def _err(a, b):
 _models = {}
 
 
-def _model(sd, k, random_hint=False, hint2regress=False, spix_pos=False):
-    key = (k, random_hint, hint2regress, spix_pos)
+def _model(sd, k, random_hint=False, hint2regress=False, spix_pos=False, use_mask=False):
+    key = (k, random_hint, hint2regress, spix_pos, use_mask)
     if key not in _models:
         m = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=spix_pos,
                             learning_pos=False, n_clusters=k, random_hint=random_hint, hint2regress=hint2regress,
-                            enhanced=True, init_weights=False)
+                            enhanced=True, use_mask=use_mask, init_weights=False)
         if hint2regress:               # the two head tensors take their --hint2regress shapes; the rest is the same
             sd = synth.synth_state_dict(130, hint2regress=True)
+        if use_mask:                   # the use_mask fixtures: the checkpoint variant that has superpixels below 25 pixels
+            sd = synth.small_superpixel_variant(sd)
         m.load_state_dict(sd)          # strict
         _models[key] = m.cuda().eval()
     return _models[key]
@@ -45,7 +47,9 @@ def _seed(seed):
 CASES = ["fwd_n2_256_k8", "fwd_diverse_256_k16", "fwd_n1_128x192_k8", "fwd_randhint_128_k16", "fwd_gt_128_k8",
          "fwd_n1_512x768_k8",
          # validation forward (test_mode=False), --hint2regress, --spix_pos, and all of them with --diverse
-         "fwd_val_128_k8", "fwd_h2r_128_k8", "fwd_spixpos_128x192_k8", "fwd_spixpos_h2r_diverse_128_k16"]
+         "fwd_val_128_k8", "fwd_h2r_128_k8", "fwd_spixpos_128x192_k8", "fwd_spixpos_h2r_diverse_128_k16",
+         # use_mask=True (model.py:38,121-125), 96 tokens (VALU attention) and 1 024 tokens (MFMA attention); round 6
+         "fwd_usemask_128x192_k8", "fwd_usemask_512_k8"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -54,7 +58,7 @@ def test_forward_matches_reference_golden(golden_dir, synth_sd, name):
     n, h, w, k, T, rh, iseed, seed = (int(v) for v in g["recipe"])
     test_mode, h2r, spos = (bool(v) for v in g["flags"]) if "flags" in g.files else (True, False, False)
     gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
-    m = _model(synth_sd, k, bool(rh), h2r, spos)
+    m = _model(synth_sd, k, bool(rh), h2r, spos, "pad_mask" in g.files)
     _seed(seed)
     pal, ref, pred, aff, spix, mask = m(gray.cuda(), ab.cuda(), test_mode, T)
     torch.cuda.synchronize()
@@ -1042,3 +1046,27 @@ def test_forward_survives_a_kmeans_that_cannot_be_co_resident(synth_sd, monkeypa
     again = m(gray, ab, True, 0)
     torch.cuda.synchronize()
     assert m.kmeans_fallback_count() == 0 and torch.equal(again[2], want[2]) and torch.equal(again[5], want[5])
+
+
+def test_use_mask_forward_against_oracle_and_its_refusals(synth_sd, q_to_ab):
+    """use_mask on a batch the goldens do not hold (3 x 256 x 256 on the small-superpixel checkpoint variant), HIP against the oracle: anchors
+    exact, ab within the bar; the masked forward differs from the unmasked one; --diverse is refused like the reference fails."""
+    sd = synth.small_superpixel_variant(synth_sd)
+    m = _model(synth_sd, 8, use_mask=True)
+    gray, ab = synth.synth_inputs(3, 256, 256, seed=91, ab_scale=0.3)
+    _seed(7)
+    got = m(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    _seed(7)
+    want = R.DiscoOracle(sd, q_to_ab, n_clusters=8, use_mask=True).forward(gray, ab)
+    assert torch.equal(got[5].cpu(), want[5]) and torch.equal(got[4].cpu(), want[4])
+    assert _err(got[0], want[0]) < LOGIT_TOL and _err(got[1], want[1]) < LOGIT_TOL and _err(got[2], want[2]) <= AB_TOL
+    plain = AnchorColorProb(n_clusters=8, enhanced=True, init_weights=False)
+    plain.load_state_dict(sd)
+    plain = plain.cuda().eval()
+    _seed(7)
+    other = plain(gray.cuda(), ab.cuda(), True, 0)
+    torch.cuda.synchronize()
+    assert _err(other[0], got[0]) > 1e-3, "the mask changed nothing"
+    with pytest.raises(NotImplementedError, match="diverse"):
+        m(gray[:1].cuda(), ab[:1].cuda(), True, 2)

@@ -247,6 +247,41 @@ def test_encoder_stack_matches_oracle(H, synth_sd, n, hw):
     assert H.max_err(out, want) < 2e-5
 
 
+@pytest.mark.parametrize("n,hw", [(3, (16, 16)), (40, (16, 16)), (1, (8, 12)), (1, (32, 32)), (2, (32, 48)), (1, (48, 48))])
+def test_encoder_stack_with_key_padding_mask_matches_oracle(H, synth_sd, n, hw):
+    """use_mask (model.py:121-125 -> transformer2d.py:53-54): the reference's float key_padding_mask adds 1.0 to the scores of the keys whose
+    superpixel holds fewer than 25 pixels, in every layer.  Every attention form: attention_kernel<1> (few workgroups), <4> (40 images),
+    the key-split MFMA form (1 024 / 1 536 tokens) and the four-query-tile MFMA form (2 304 tokens) against the oracle's stack with the
+    same bias; and the mask must matter (the unmasked stack gives another result)."""
+    h, w = hw
+    l = h * w
+    x = torch.randn(n, l, 64, generator=g(l + n))
+    pos = R.position_encoding(h, w).flatten(1).t().contiguous()
+    sizes = torch.randint(0, 512, (n, l), generator=g(3 * l + n)).float() / 256.0
+    sizes[:, ::5] = torch.randint(0, 25, sizes[:, ::5].shape, generator=g(l)).float() / 256.0      # a fifth of the superpixels below 25 pixels
+    sizes[0, 1] = 25.0 / 256.0                                                                      # the boundary itself is NOT small (<)
+    bias = R.entry_mask(sizes, 16)
+    assert 0.1 < float(bias.mean()) < 0.4 and bias[0, 1] == 0
+    want = R.encoder_stack(synth_sd, "hintpath", x[:4], pos[None].expand(min(n, 4), -1, -1), key_bias=bias[:4])
+    plain = R.encoder_stack(synth_sd, "hintpath", x[:1], pos[None], key_bias=None)
+    wts = _encoder_weights(synth_sd, "hintpath").to(H.DEV)
+    xd, pd, sz = x.to(H.DEV), pos.to(H.DEV), sizes.to(H.DEV)
+    out = torch.empty_like(xd)
+    ws = torch.empty(n * l * 704 * 4, device=H.DEV, dtype=torch.uint8)
+    _ffi.check(_ffi.lib().disco_op_encoder_stack_masked(_ffi.ptr(xd), _ffi.ptr(pd), _ffi.ptr(wts), _ffi.ptr(sz), _ffi.ptr(out), n, l,
+                                                        _ffi.ptr(ws), ws.numel(), H.stream()))
+    torch.cuda.synchronize()
+    assert H.max_err(out[:4], want) < 2e-5
+    assert H.max_err(out[:1], plain) > 1e-3, "the mask did not change anything"
+    # an image's result does not depend on the batch it is part of, with the mask as without
+    if n > 1:
+        one = torch.empty_like(xd[:1])
+        _ffi.check(_ffi.lib().disco_op_encoder_stack_masked(_ffi.ptr(xd[:1].contiguous()), _ffi.ptr(pd), _ffi.ptr(wts), _ffi.ptr(sz[:1].contiguous()),
+                                                            _ffi.ptr(one), 1, l, _ffi.ptr(ws), ws.numel(), H.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(one[0], out[0])
+
+
 @pytest.mark.parametrize("n,hw", [(1, (16, 16)), (3, (16, 16)), (2, (9, 11)), (1, (32, 48)), (5, (7, 3))])
 def test_encoder_tail_path_equals_the_tiled_one(H, synth_sd, n, hw):
     """The two ways the stack runs a layer's second half: 64-row tiles (post_attention_kernel + a q/k/v launch per layer) and 16-row tiles on
