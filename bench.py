@@ -40,8 +40,10 @@ sys.path.insert(0, REPO)
 
 GFLOP_PER_IMAGE = 255.470          # algorithmic work of one 256x256 image
 FP16_MFMA_PEAK = 2.5e15            # dense, MI355X_MICROARCH.md
-FP32_MFMA_PEAK = 157.3e12
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"
+ANCHOR_STUDY_FILE = "r06_anchor_mismatch.json"
+SOCKET_POWER_CAP_W = 1400.0        # MI355X board power limit (rocm-smi; profiles/r04_power_per_kernel.txt sits on it)
+MAX_SCLK_MHZ = 2400.0
 
 
 def cpu_baseline(sd, seconds_budget=30.0, all_cores=False):
@@ -90,16 +92,84 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic():
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE x2 gfx950 correction
-    + WRITE_SIZE).  PMC counters cannot be read from inside a timed run, so the file carries the hash of the kernel sources it
-    was measured on; a stale file is reported as null rather than as a number."""
+def pmc_record(key):
+    """A number from the committed rocprofv3 PMC passes (tools/pmc_traffic.py): `hbm_bytes_per_launch` (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE) or `mfma_busy` (SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over the conv launches).  PMC counters cannot be read
+    from inside a timed run, so the file carries the hash of the kernel sources it was measured on; a stale file is reported as null
+    rather than as a number."""
     try:
         with open(os.path.join(REPO, "profiles", PMC_TRAFFIC_FILE)) as f:
             d = json.load(f)
-        return d["hbm_bytes_per_launch"] if d.get("source_hash") == source_hash() else None
+        return d.get(key) if d.get("source_hash") == source_hash() else None
     except Exception:
         return None
+
+
+def pmc_traffic():
+    return pmc_record("hbm_bytes_per_launch")
+
+
+def anchor_mismatch():
+    """Anchor exactness as a rate (tools/anchor_study.py -> profiles/r06_anchor_mismatch.json, keyed by the kernel sources): per image size,
+    how many images the HIP path decides differently from the fp32 CPU oracle, next to the same count for an exact-fp32 evaluation of
+    the reference in ANOTHER summation order (torch-ROCm im2col + rocBLAS) and for an fp64 evaluation.  null when the file is stale."""
+    try:
+        with open(os.path.join(REPO, "profiles", ANCHOR_STUDY_FILE)) as f:
+            d = json.load(f)
+        if d.get("source_hash") != source_hash():
+            return None
+        out = {}
+        for size, r in d["sets"].items():
+            e = {"n": r["n"], "hip_vs_oracle": r["hip_vs_oracle"], "rate": r["rate_hip_vs_oracle"]}
+            for v, name in (("G", "fp32_other_order_vs_oracle"), ("D", "fp64_vs_oracle"), ("B", "cpu_fp32_no_onednn_vs_oracle")):
+                if v in r:
+                    e[name] = {"n": r[v]["n"], "count": r[v]["vs_oracle"], "rate": r[v]["rate_vs_oracle"]}
+            for k in ("hip_mismatches_also_flipped_by_an_exact_evaluation", "hip_mismatches_flipped_by_hip_alone"):
+                if k in r:
+                    e[k] = r[k]
+            out[size] = e
+        return out
+    except Exception:
+        return None
+
+
+class PowerProbe:
+    """Socket power and shader clock DURING the timed loop: tools/power_sampler.py (a separate process reading librocm_smi64 at 100 Hz; it
+    touches neither the HIP runtime nor the GPU's queues) is started before the warm-up and stopped after the timed region; the mean over
+    the samples inside [t0, t1] goes into the roofline block - the reason the matrix pipe runs below its datasheet clock is on the line."""
+
+    def __init__(self):
+        import subprocess
+        import tempfile
+        self.path = os.path.join(tempfile.gettempdir(), "disco_bench_power_%d.csv" % os.getpid())
+        try:
+            self.proc = subprocess.Popen([sys.executable, os.path.join(REPO, "tools", "power_sampler.py"), "--out", self.path, "--hz", "100",
+                                          "--dev", str(int(os.environ.get("LOCAL_RANK", "0")))], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+
+    def read(self, t0, t1):
+        import signal
+        if self.proc is None:
+            return None
+        try:
+            self.proc.send_signal(signal.SIGTERM)
+            self.proc.wait(timeout=10)
+            w, c, src = [], [], ""
+            with open(self.path) as f:
+                for line in f:
+                    if line.startswith("#"):
+                        src += line[1:].strip() + " "
+                        continue
+                    t, p, k = line.strip().split(",")
+                    if t0 <= float(t) <= t1:
+                        w.append(float(p)); c.append(float(k))
+            os.unlink(self.path)
+            if not w:
+                return None
+            return {"socket_w": round(sum(w) / len(w), 1), "sclk_mhz": round(sum(c) / len(c), 0), "samples": len(w), "source": src.strip()}
+        except Exception:
+            return None
 
 
 def fake_forward(gray, ab, T, idx, pos, fstream, fbases, want, out=None):
@@ -405,12 +475,14 @@ def main():
         step()
     runner.wait()
     sync()
+    probe = PowerProbe() if (model is not None and rank == 0) else None
     for _ in range(args.warmup):
         step()
     runner.wait()
     if use_dist:
         dist.barrier()
     sync()
+    wall0 = time.time()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
@@ -420,6 +492,7 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    power = probe.read(wall0, time.time()) if probe is not None else None
     checksum = zlib.crc32(last[1].cpu().numpy().tobytes(), zlib.crc32(last[0].cpu().numpy().tobytes()))
     conv_ms = conv_fl = conv_bytes = 0.0
     conv_launches = 0
@@ -495,6 +568,9 @@ def main():
             "kmeans_events": events, "fp8_saturated_elements": sat, "result_checksum": "%08x" % checksum,
         }
         if model is not None:
+            out["anchor_mismatch_rate"] = anchor_mismatch()
+            out["kmeans_fallback_images"] = model.kmeans_fallback_count()
+        if model is not None:
             # what the HourGlass2 really ran on: the channel-disparity guard of disco_finalize may have moved it from fp6 to fp8 corrections
             ar, disp = model.enhance_arithmetic()
             out["hourglass2_arithmetic"] = ar
@@ -512,7 +588,15 @@ def main():
                 "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_fl / max(conv_launches, 1) / 1e9, 3),
                 "algorithmic_hbm_bytes_per_launch": int(conv_bytes),
-                "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK, 4),
+                # why the fraction is what it is, on the line itself: every algorithmic MAC costs THREE matrix-pipe products in both arithmetics
+                # (f16x3: w_lo a_hi + w_hi a_lo + w_hi a_hi; f16+fp6x2: one fp16 product + two fp6 corrections in one K=64 MFMA), the pipe is busy
+                # most of the time, and the socket sits on its power cap with the shader clock pulled below its 2.4 GHz maximum
+                "products_per_mac": 3, "executed_tflops": round(3 * achieved / 1e12, 1),
+                "executed_frac_of_peak": round(3 * achieved / FP16_MFMA_PEAK, 4),
+                "mfma_busy": pmc_record("mfma_busy"),
+                "socket_w": power and power["socket_w"], "socket_cap_w": SOCKET_POWER_CAP_W,
+                "sclk_mhz": power and power["sclk_mhz"], "sclk_max_mhz": MAX_SCLK_MHZ,
+                "power_samples_in_timed_loop": power and power["samples"],
                 "end_to_end_frac_of_fp16_conv_roofline": round(ips * GFLOP_PER_IMAGE * 1e9 / world / FP16_MFMA_PEAK, 4),
             }
             out["stage_ms_per_step"] = {k: round(v / prof_steps, 3) for k, v in stage_ms.items()}        # of the profiled single-stream forwards

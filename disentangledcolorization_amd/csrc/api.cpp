@@ -1663,7 +1663,11 @@ int disco_calibration_entry(disco_ctx* c, int i, const char** key, float* amax, 
     if (i < 0 || i >= (int)c->amax.size()) { set_error("bad calibration index"); return DISCO_EINVAL; }
     auto it = c->amax.begin();
     std::advance(it, i);
-    *key = it->first.c_str(); *amax = it->second;
+    // the key is COPIED into storage of the calling thread: a pointer into c->amax would dangle as soon as the lock is released and another
+    // thread's disco_calibrate (or the HourGlass2 rebuild) reinserts the entries (advisor, round 5).  Valid until this thread's next call.
+    static thread_local std::string key_copy;
+    key_copy = it->first;
+    *key = key_copy.c_str(); *amax = it->second;
     auto sx = c->sexp.find(it->first);
     *sexp = sx == c->sexp.end() ? 0 : sx->second;
     return DISCO_OK;

@@ -197,6 +197,7 @@ int disco_calibration_count(disco_ctx *ctx);
  * rebuild the HourGlass2 on fp8 corrections (e4m3: 4 exponent bits; same accuracy as DISCO_PREC_MX8, 2-3 % slower): *precision then reports
  * DISCO_PREC_MX8 although the context was created with DISCO_PREC_MX6.  The synthetic checkpoint reads 9 and is left alone. */
 int disco_enhance_arithmetic(disco_ctx *ctx, int *precision, float *channel_disparity, float *disparity_before_equalisation);
+/* i-th entry of the calibration record; *key points at a copy owned by the calling thread, valid until that thread's next call */
 int disco_calibration_entry(disco_ctx *ctx, int i, const char **key, float *amax, int *sexp);
 /* One network of the colorizer on its own (the reference's models/network.py classes as modules of their own), on a full context or on
  * the stand-alone context of that network (disco_options.network = 1 / 2 / 3); workspace as reported by

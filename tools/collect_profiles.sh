@@ -3,16 +3,16 @@
 # Counters are collected in their own passes (--kernel-trace only), as the guide prescribes.
 set -x
 R=$PWD
-O=$R/gpurun_out/r05
+O=$R/gpurun_out/r06
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 20 --warmup 5 > $O/final_bench.json 2> $O/final_bench.err
 rocprofv3 --kernel-trace --stats -d $O/ks -o ks --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-other-configs --pipeline 0 --micro 1 > $O/ks_bench.json 2> $O/ks.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-other-configs --pipeline 0 --micro 1 > /dev/null 2> $O/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-other-configs --pipeline 0 --micro 1 > /dev/null 2> $O/write.err
-python $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU -d $O/pmc_sq1 -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-other-configs --pipeline 0 --micro 1 > /dev/null 2> $O/sq1.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE -d $O/pmc_sq2 -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-other-configs --pipeline 0 --micro 1 > /dev/null 2> $O/sq2.err
+python $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc_sq1
 python $R/tools/pmc_sum.py $O/pmc_sq1 conv3x3 > $O/conv_pmc.txt; python $R/tools/pmc_sum.py $O/pmc_sq2 conv3x3 >> $O/conv_pmc.txt
 python $R/tools/profile_layers.py > $O/final_layers.txt 2>&1
 python $R/tools/operating_points.py > $O/operating_points.txt 2>&1

@@ -48,8 +48,25 @@ def total(dirname, counter):
     return sum(v for _, v in rows), len(rows), per_layer
 
 
+def mfma_busy(sq_dir):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES) over every conv3x3_mx_kernel launch of an SQ pass (four SIMDs per CU): the share of
+    the CUs' busy time in which a matrix pipe was executing."""
+    busy = cu = 0.0
+    for f in glob.glob(os.path.join(sq_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "conv3x3_mx_kernel" not in row.get("Kernel_Name", ""):
+                    continue
+                if row["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    busy += float(row["Counter_Value"])
+                elif row["Counter_Name"] == "SQ_BUSY_CU_CYCLES":
+                    cu += float(row["Counter_Value"])
+    return round(busy / (4.0 * cu), 4) if cu else None
+
+
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    sq_dir = sys.argv[4] if len(sys.argv) > 4 else None
     fetch, nf, fetch_l = total(fetch_dir, "FETCH_SIZE")
     write, nw, write_l = total(write_dir, "WRITE_SIZE")
     with open(os.path.splitext(out)[0] + "_layers.txt", "w") as fh:
@@ -71,7 +88,10 @@ def main():
                      "wide coalesced streaming reads, so reads are doubled below; WRITE_SIZE is uncalibrated and taken as is",
         "conv_launches (conv3x3_mx_kernel, all arithmetics; 64-image forwards only: the calibration pass is dropped)": nf, "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
         "hbm_read_bytes_per_launch_corrected": int(rd), "hbm_write_bytes_per_launch": int(wr),
-        "hbm_bytes_per_launch": int(rd + wr)}, open(out, "w"), indent=1)
+        "hbm_bytes_per_launch": int(rd + wr),
+        "mfma_busy": mfma_busy(sq_dir) if sq_dir else None,
+        "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) summed over the conv3x3_mx_kernel launches of a third pass "
+                          "(--pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES ...)"}, open(out, "w"), indent=1)
     print(open(out).read())
 
 
