@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdisco_hip.so")
-SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.hip", "conv_mx_ar1.hip", "conv_mx_ar2.hip", "conv_mx_ar3.hip", "conv_direct.hip", "color.hip", "spixel.hip", "pool.hip", "tokens.hip", "attention.hip", "kmeans.hip", "anchor_colors.hip", "attention_mfma.hip", "diag.hip"]
+SOURCES = ["util.cpp", "api_load.cpp", "api_plan.cpp", "api_calib.cpp", "api_diag.cpp", "api_ops.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.hip", "conv_mx_ar1.hip", "conv_mx_ar2.hip", "conv_mx_ar3.hip", "conv_direct.hip", "color.hip", "spixel.hip", "pool.hip", "tokens.hip", "attention.hip", "kmeans.hip", "anchor_colors.hip", "attention_mfma.hip", "diag.hip"]
 # per-file extra flags
 # -fno-slp-vectorize: the SLP vectoriser forms v_pk_*_f32 with op_sel (the low result half takes the HIGH dword of a source), and on this part
 # that form returns a wrong low half while other waves of the CU issue MFMAs (tools/pk_fault_repro.hip, profiles/r03_pk_fma_op_sel_fault.txt;
@@ -21,7 +21,7 @@ SOURCES = ["util.cpp", "api.cpp", "conv_pack.cpp", "conv_mx.hip", "conv_mx_ar0.h
 # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (attention_mfma.hip: the softmax reads every score; no v_accvgpr_read per element)
 EXTRA_FLAGS = {"pool.hip": ["-fno-slp-vectorize"], "spixel.hip": ["-fno-slp-vectorize"], "color.hip": ["-fno-slp-vectorize"],
                "attention_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-HEADERS = ["common.h", "conv_mx_kernel.h", os.path.join("..", "..", "include", "disco_hip.h")]
+HEADERS = ["common.h", "ctx.h", "plan.h", "conv_mx_kernel.h", os.path.join("..", "..", "include", "disco_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wno-unused-result"]
 

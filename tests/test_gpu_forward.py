@@ -610,7 +610,7 @@ def test_checkpoints_with_activations_far_from_one(synth_sd, q_to_ab, which):
 
 def test_fused_first_layer_is_bit_identical_to_the_two_launch_form():
     """Round 4: repnet.conv1_2.0 (Cin = 1) is computed inside conv1_2.2's LDS staging when that layer runs on the 32 x 16 x 64 tile with
-    enough tiles to fill the GPU (csrc/conv_mx_kernel.h GENC1; api.cpp run_plan) - the stand-alone kernel's fmaf chain, bias, LeakyReLU,
+    enough tiles to fill the GPU (csrc/conv_mx_kernel.h GENC1; api_plan.cpp run_plan) - the stand-alone kernel's fmaf chain, bias, LeakyReLU,
     scale and hi/lo split, so every output of the forward must be BIT-identical with the fusion on and off (DISCO_FUSE_C1, read once per
     process: two subprocesses).  Shapes: full tiles, a partial last tile column (W = 176), one tall image, a batch too small to fuse."""
     import subprocess, sys
@@ -962,7 +962,7 @@ def test_two_host_threads_share_one_context(synth_sd):
 
 def test_small_batches_fork_spixelnet_onto_a_side_stream(synth_sd):
     """Up to 8 x 256^2 pixels per forward, disco_forward runs SpixelNet on a side stream of the context next to ColorProbNet (neither fills the
-    GPU at that size; csrc/api.cpp run_plan).  Same kernels, same results: the two images of a forked forward equal, bit for bit, their rows
+    GPU at that size; csrc/api_plan.cpp run_plan).  Same kernels, same results: the two images of a forked forward equal, bit for bit, their rows
     in a 40-image forward (above the threshold: single stream), also when the small forwards are issued back to back."""
     m = _model(synth_sd, 8)
     saved, m.range_checks = m.range_checks, 0
