@@ -309,6 +309,9 @@ CONFIGS = {
     "3": dict(per_gpu=0, global_batch=512, k=8, T=0, random_hint=False, scaling="strong",
               workload="BASELINE config 3: global batch=512 synthetic 256x256 L-channel sharded over the GPUs (64 per GPU on 8), K=8 clustering anchors, "
                        "synthetic checkpoint of the DISCO layout (the real one is not available offline), packed all-gather inside the timed region"),
+    "4": dict(per_gpu=0, global_batch=16, k=8, T=0, random_hint=False, scaling="strong", mixed=True,
+              workload="BASELINE config 4: --no_resize, a mixed list of eight 512x512 and eight 768x512 (H x W) L images on ONE GPU, K=8 clustering anchors, "
+                       "grouped by shape (two forwards per step: 1 024 and 1 536 tokens per image); `value` counts IMAGES of these sizes, not 256x256 ones"),
     "5a": dict(per_gpu=0, global_batch=256, k=16, T=1, random_hint=False, scaling="strong",
                workload="BASELINE config 5 (a): global batch=256 synthetic 256x256 sharded over the GPUs, --diverse (three colorizations per image = 768 outputs), "
                         "K=16 clustering anchors"),
@@ -364,6 +367,83 @@ def self_launch(n, fake):
     return rc
 
 
+def bench_mixed(args, cfg):
+    """--config 4: one step = runner.colorize_mixed over BASELINE's mixed --no_resize list (inputs resident in HBM), W warm-up steps, K timed
+    steps closed by one synchronize; afterwards one more pass with the k-means bookkeeping on must report no empty-cluster event and the same
+    result.  One JSON line; `roofline` from hipEvent pairs around the conv launches of a profiled pass, like the headline's."""
+    from disentangledcolorization_amd import synth
+    from disentangledcolorization_amd.model import AnchorColorProb
+    from disentangledcolorization_amd.runner import colorize_mixed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+    torch.cuda.set_device(0)
+    sd = synth.synth_state_dict(130)
+    model = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, n_clusters=cfg["k"], enhanced=True,
+                            precision=args.precision, init_weights=False)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    model.set_profiling(0)
+    grays = [synth.synth_inputs(1, 512, 512, seed=40 + i)[0].cuda() for i in range(8)] + [synth.synth_inputs(1, 768, 512, seed=60 + i)[0].cuda() for i in range(8)]
+    px = sum(g.shape[2] * g.shape[3] for g in grays)
+
+    def step():
+        np.random.seed(130); torch.manual_seed(130)
+        return colorize_mixed(model, grays)
+    model.sync_kmeans_events = False
+    for _ in range(2 + args.warmup):
+        step()
+    torch.cuda.synchronize()
+    probe = PowerProbe()
+    time.sleep(0.05)
+    wall0 = time.time()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    power = probe.read(wall0, time.time())
+    model.sync_kmeans_events = True
+    exact = step()
+    torch.cuda.synchronize()
+    ev = model.last_kmeans_events()
+    events = 0 if ev is None else int(np.asarray(ev).sum())
+    same = all(torch.equal(a[2], b[2]) and torch.equal(a[5], b[5]) for a, b in zip(last, exact))
+    if events != 0 or not same:
+        raise SystemExit("bench: the timed (unsynchronised) forwards are not the reference-exact ones: kmeans_events=%d, identical: %s" % (events, same))
+    checksum = 0
+    for o in last:
+        checksum = zlib.crc32(o[5].cpu().numpy().tobytes(), zlib.crc32(o[2].cpu().numpy().tobytes(), checksum))
+    model.set_profiling(2)
+    model.sync_kmeans_events = False
+    conv_ms = conv_fl = 0.0
+    conv_n = 0
+    for shape_group in (grays[:8], grays[8:]):                 # one forward per shape: the profile of each
+        np.random.seed(130)
+        colorize_mixed(model, shape_group)
+        torch.cuda.synchronize()
+        nl, ms, fl = model.conv_profile()
+        conv_n += nl; conv_ms += ms; conv_fl += fl
+    model.set_profiling(0)
+    achieved = conv_fl / (conv_ms * 1e-3) if conv_ms > 0 else 0.0
+    out = {"metric": "colorized images/sec (--no_resize sizes)", "value": round(len(grays) * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": 1,
+           "world_size_seen_by_backend": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16x3 / f16+fp6x2 conv stacks, fp32 token path (as the headline)",
+           "data": "synthetic",
+           "config": {"workload": cfg["workload"], "name": args.config, "global_batch": len(grays), "n_clusters": cfg["k"], "pixels_per_step": px,
+                      "ns_per_pixel": round(elapsed / args.steps * 1e9 / px, 3), "equivalent_256x256_images_per_s": round(px / 65536.0 * args.steps / elapsed, 1)},
+           "kmeans_events": events, "kmeans_fallback_images": model.kmeans_fallback_count(), "result_checksum": "%08x" % checksum,
+           "roofline": {"bound": "mfma", "kernel": "conv3x3_mx_kernel", "achieved": round(achieved / 1e12, 2), "peak": FP16_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                        "frac": round(achieved / FP16_MFMA_PEAK, 4), "traffic": None, "conv_launches_per_step": conv_n,
+                        "products_per_mac": 3, "executed_tflops": round(3 * achieved / 1e12, 1),
+                        "socket_w": power and power["socket_w"], "sclk_mhz": power and power["sclk_mhz"],
+                        "end_to_end_frac_of_fp16_conv_roofline": round(px / 65536.0 * args.steps / elapsed * GFLOP_PER_IMAGE * 1e9 / FP16_MFMA_PEAK, 4)}}
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS), help="the BASELINE.json configuration to time (default 2: the one the metric is quoted on); "
@@ -395,6 +475,10 @@ def main():
         args.precision = default_precision()
     fake = os.environ.get("DISCO_BENCH_FAKE") == "1"
     cfg = CONFIGS[args.config]
+    if cfg.get("mixed"):
+        if args.gpus != 1 or fake:
+            raise SystemExit("bench: --config 4 is BASELINE's single-GPU --no_resize configuration (--gpus 1, real device)")
+        return bench_mixed(args, cfg)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, fake))
 

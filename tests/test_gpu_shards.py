@@ -143,3 +143,25 @@ def test_virtual_rank_refuses_collectives(synth_sd):
         ShardedColorizer.from_model(m, exact_fallback=True, virtual_rank=(8, 7)).colorize(g.cuda(), a.cuda(), 8, 0, gather=False)
     with pytest.raises(ValueError):
         ShardedColorizer.from_model(m, virtual_rank=(8, 8))
+
+
+def test_config4_full_mixed_batch_matches_the_oracle(synth_sd, q_to_ab):
+    """BASELINE config 4 at its full size - eight 512x512 and eight 768x512 L images (bench.py's list: synth seeds 40.. / 60..) through
+    runner.colorize_mixed (grouped by shape: two forwards) - against the CPU oracle run the reference's way, one file at a time with the
+    draws in file order (inference.py:93-109): anchors exact for all sixteen, ab within the bar.  (bench.py times exactly this list.)"""
+    from disentangledcolorization_amd.runner import colorize_mixed
+    m = _model(synth_sd, 8)
+    grays = [synth.synth_inputs(1, 512, 512, seed=40 + i)[0] for i in range(8)] + [synth.synth_inputs(1, 768, 512, seed=60 + i)[0] for i in range(8)]
+    _seed()
+    got = colorize_mixed(m, [g.cuda() for g in grays])
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    oracle = R.DiscoOracle(synth_sd, q_to_ab, n_clusters=8)
+    _seed()
+    worst = 0.0
+    for i, g in enumerate(grays):
+        want = oracle.forward(g, torch.zeros(1, 2, g.shape[2], g.shape[3]))          # draws from NumPy's global state, file order
+        assert torch.equal(got[i][5].cpu(), want[5]), "anchors of file %d (%dx%d) differ from the oracle" % (i, g.shape[2], g.shape[3])
+        worst = max(worst, _err(got[i][2], want[2]))
+    print("config 4, 8 x 512x512 + 8 x 768x512: max|ab - oracle| = %.3e" % worst)
+    assert worst <= AB_TOL
