@@ -126,6 +126,7 @@ SIGNATURES = {
     "disco_op_mark_color_hints": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
 }
 
+ABI_VERSION = 11      # include/disco_hip.h DISCO_ABI_VERSION this binding matches (struct layouts, entry points)
 _lib = None
 
 
@@ -142,6 +143,10 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        got = handle.disco_abi_version()
+        if got != ABI_VERSION:          # a stale build next to newer Python sources (struct layouts differ between versions): refuse it
+            raise DiscoError("libdisco_hip.so reports ABI version %d, this binding was written for %d: rebuild it "
+                             "(python -m disentangledcolorization_amd.build --force)" % (got, ABI_VERSION))
         _lib = handle
     return _lib
 
