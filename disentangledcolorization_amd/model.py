@@ -495,10 +495,12 @@ class AnchorColorProb(nn.Module):
             init_idx = np.ascontiguousarray(init_idx, dtype=np.int32)
         max_imgs = max(1, MAX_ACT_BYTES // (64 * H * W * 4 * rep))
         if n > max_imgs:
-            # images are independent: run the batch in slices and concatenate
+            # images are independent: run the batch in slices and concatenate.  BALANCED slices (512 images -> 171 + 171 + 170, not
+            # 255 + 255 + 2): a two-image tail forward would run on the small-batch paths at a fraction of the throughput
             parts, evs = [], []
-            for i in range(0, n, max_imgs):
-                j = min(n, i + max_imgs)
+            n_slices = -(-n // max_imgs)
+            bounds = [(k * n) // n_slices for k in range(n_slices + 1)]
+            for i, j in zip(bounds[:-1], bounds[1:]):
                 o, e = self.forward_once(gray[i:j], ab[i:j], test_mode, sampled_T, None if init_idx is None else init_idx[i:j],
                                          None if hint_pos is None else hint_pos[i:j], fallback_stream,
                                          None if fallback_bases is None else fallback_bases[i:j], want_events,
