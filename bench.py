@@ -342,6 +342,13 @@ def self_launch(n, fake):
             return 2
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()), WORLD_SIZE=str(n),
                LOCAL_WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # N ranks share the host: without a cap every rank's NumPy / torch would start one thread per core for the host-side set-up (the synthetic
+    # checkpoint's power iterations, the inputs), and N x cores threads thrash for minutes on a box whose container owns a fraction of the cores
+    # it shows (seen in round 6: eight 28-thread workers needed 15 minutes for work that takes one of them 30 s).  torch.distributed.run does the
+    # same for its children (OMP_NUM_THREADS=1); the GPU work does not depend on it.
+    threads = str(max(1, min(8, (os.cpu_count() or 8) // (4 * n))))
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env.setdefault(var, threads)
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
