@@ -65,3 +65,19 @@ def test_named_configs_on_two_ranks_equal_one_rank(config, batch):
     assert two["world_size_seen_by_backend"] == 2 and two["config"]["name"] == config and two["kmeans_events"] == 0
     assert two["config"]["colorizations_per_step"] == batch * (3 if config == "5a" else 1)
     assert one["result_checksum"] == two["result_checksum"]
+
+
+@pytest.mark.parametrize("config", ["3", "5a"])
+def test_eight_ranks_sharing_one_gpu_equal_the_single_process_run(config):
+    """BASELINE's 8-GPU configurations at their FULL global batch and their real world size, on the one GPU a test box has: `python bench.py
+    --gpus 8 --config 3` (512 images, 64 per rank) / `--config 5a` (256 images --diverse K = 16, 32 per rank = 96 colorizations each) with the
+    eight self-launched ranks sharing cuda:0 (collectives on gloo, staged through pinned host buffers; RCCL wants a device per rank).  Everything
+    an 8 x MI355X run does except the xGMI transport: the launch, the thread caps, shard bounds, the global draws sliced at eight offsets, the
+    collective range check of the first batches, pipelined forwards with the packed gather behind each, the exactness check, max-over-ranks
+    timing.  The result checksum must equal the single-process run's: the gathered 512 (768) results are bit for bit the one-GPU ones."""
+    args = ("--config", config, "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    one = _bench({}, [sys.executable], ("--gpus", "1") + args)
+    eight = _bench({"DISCO_DIST_BACKEND": "gloo"}, [sys.executable], ("--gpus", "8") + args)
+    assert eight["n_gpus"] == 8 and eight["world_size_seen_by_backend"] == 8 and eight["kmeans_events"] == 0
+    assert eight["config"]["global_batch"] == (512 if config == "3" else 256) and eight["config"]["images_per_gpu"] == (64 if config == "3" else 32)
+    assert eight["result_checksum"] == one["result_checksum"]

@@ -1070,3 +1070,23 @@ def test_use_mask_forward_against_oracle_and_its_refusals(synth_sd, q_to_ab):
     assert _err(other[0], got[0]) > 1e-3, "the mask changed nothing"
     with pytest.raises(NotImplementedError, match="diverse"):
         m(gray[:1].cuda(), ab[:1].cuda(), True, 2)
+
+
+def test_spixelseg_under_dataparallel(synth_sd):
+    """main/spixelseg/inference.py:50-51,89 unmodified on a multi-GPU host: DataParallel(SpixelSeg) with batch 1 - the replica forwards on its
+    origin's context; bit for bit the plain call."""
+    from disentangledcolorization_amd.model import SpixelSeg
+    m = SpixelSeg(inChannel=1, outChannel=9, batchNorm=True)
+    dp = torch.nn.DataParallel(m).cuda()
+    m.load_state_dict({k[len("segnet."):]: v for k, v in synth_sd.items() if k.startswith("segnet.")})
+    dp.eval()
+    gray, _ = synth.synth_inputs(1, 96, 160, seed=12)
+    gray = gray.cuda()
+    want = m(gray)
+    torch.cuda.synchronize()
+    dp.device_ids = [0, 0]
+    for _ in range(2):
+        got = dp(gray)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    assert m._ctx is not None
