@@ -1090,3 +1090,36 @@ def test_spixelseg_under_dataparallel(synth_sd):
         torch.cuda.synchronize()
         assert torch.equal(got, want)
     assert m._ctx is not None
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_randomised_use_mask_configurations_match_oracle(synth_sd, q_to_ab, case):
+    """use_mask over a seeded sweep of sizes (multiples of 16 from 64 to 320, non-square; one case at 512x512 = the MFMA attention), batch,
+    K and the plain / ground-truth-colour / validation forwards, on the checkpoint variant that has superpixels below 25 pixels (a second
+    variant biases another neighbour slot, so other cells are the small ones): HIP against the oracle, anchors exact."""
+    rs = np.random.RandomState(5000 + case)
+    h, w = (512, 512) if case == 5 else tuple(int(rs.randint(4, 21)) * 16 for _ in range(2))
+    mode = ["plain", "gt", "val"][case % 3]
+    n = int(rs.randint(1, 4))
+    k = int(rs.randint(2, min(17, (h // 16) * (w // 16) + 1)))
+    slot = [0, 8, 2][case % 3]
+    sd = synth.small_superpixel_variant(synth_sd, slot=slot, boost=float(rs.uniform(3.0, 5.0)))
+    m = AnchorColorProb(n_clusters=k, enhanced=True, use_mask=True, init_weights=False)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    gray, ab = synth.synth_inputs(n, h, w, seed=6000 + case, ab_scale=float(rs.uniform(0.05, 0.8)))
+    T = {"plain": 0, "gt": -1, "val": 0}[mode]
+    test_mode = mode != "val"
+    _seed(case)
+    got = m(gray.cuda(), ab.cuda(), test_mode, T)
+    torch.cuda.synchronize()
+    _seed(case)
+    oracle = R.DiscoOracle(sd, q_to_ab, n_clusters=k, use_mask=True)
+    want, info = oracle.forward(gray, ab, sampled_T=T, test_mode=test_mode, return_info=True)
+    small = R.entry_mask(info["sizes"], 16)
+    assert 0 < float(small.sum()) < small.numel(), "the case must have small superpixels (and not only small ones)"
+    assert torch.equal(got[5].cpu(), want[5]), "anchors differ (%s %dx%d n=%d K=%d)" % (mode, h, w, n, k)
+    assert _err(got[0], want[0]) < LOGIT_TOL and _err(got[1], want[1]) < LOGIT_TOL
+    e = _err(got[2], want[2])
+    print(f"use_mask case {case}: {mode} {h}x{w} n={n} K={k} slot {slot}: {int(small.sum())} small superpixels, max|ab - oracle| = {e:.2e}")
+    assert e <= AB_TOL
