@@ -234,3 +234,24 @@ def test_network_dropins_without_a_gpu(synth_sd):
                 lambda: network.HourGlass2(inChannel=3, outChannel=1), lambda: network.HourGlass2(normLayer=nn.InstanceNorm2d)):
         with pytest.raises(NotImplementedError):
             bad()
+
+
+def test_reference_side_change_script(tmp_path):
+    """integration/apply_to_reference.py: the one-hunk reference-side change of INTEGRATION.md section 2 on a stand-in checkout (two files
+    with the import line the reference has, CRLF line endings like the real checkout): patched, idempotent, revertible byte for byte."""
+    import subprocess
+    import sys
+    script = os.path.join(REPO, "integration", "apply_to_reference.py")
+    body = "import os\r\nfrom utils_train import load_checkpoint\r\nimport model, basic\r\nimport util\r\n"
+    for sub in ("colorizer", "spixelseg"):
+        d = tmp_path / "main" / sub
+        d.mkdir(parents=True)
+        (d / "inference.py").write_bytes(body.encode())
+    run = lambda *a: subprocess.run([sys.executable, script, str(tmp_path)] + list(a), capture_output=True, text=True, check=True).stdout
+    assert run().count("patched") == 2 and run().count("already done") == 2
+    col = (tmp_path / "main" / "colorizer" / "inference.py").read_bytes()
+    assert b"import basic\r\nfrom disentangledcolorization_amd import model\r\nimport util\r\n" in col and b"import model, basic" not in col
+    seg = (tmp_path / "main" / "spixelseg" / "inference.py").read_bytes()
+    assert b"from disentangledcolorization_amd import model, basic\r\n" in seg
+    assert run("--revert").count("reverted") == 2
+    assert (tmp_path / "main" / "colorizer" / "inference.py").read_bytes() == body.encode()
