@@ -481,7 +481,9 @@ int disco_expected_tensor_ctx(disco_ctx* c, int i, const char** key, int64_t sha
 
 int disco_create(int device, const disco_options* opt, disco_ctx** out) {
     if (!opt || !out) { set_error("null argument"); return DISCO_EINVAL; }
-    if (opt->sp_size != 16) { set_error("sp_size %d unsupported (16 only, inference.py:146)", opt->sp_size); return DISCO_EUNSUPPORTED; }
+    // --psize (inference.py:147): the superpixel CELL of the pooling / un-pooling / size count (model.py:109-121,191); SpixelNet's affinity is
+    // the same nine-neighbour map whatever the cell.  16 has the dedicated kernels; 8 and 32 run the general ones (ABI 11)
+    if (opt->sp_size != 8 && opt->sp_size != 16 && opt->sp_size != 32) { set_error("sp_size %d unsupported (8, 16 or 32; inference.py:147)", opt->sp_size); return DISCO_EUNSUPPORTED; }
     if (opt->n_clusters < 1 || opt->n_clusters > 32) { set_error("n_clusters %d outside [1,32]", opt->n_clusters); return DISCO_EUNSUPPORTED; }
     if (opt->precision != DISCO_PREC_F16X3 && opt->precision != DISCO_PREC_MX8 && opt->precision != DISCO_PREC_MX8_ALL && opt->precision != DISCO_PREC_X2Q && opt->precision != DISCO_PREC_MX6) { set_error("precision %d", opt->precision); return DISCO_EINVAL; }
     if ((opt->hint2regress | opt->spix_pos) & ~1) { set_error("hint2regress / spix_pos must be 0 or 1"); return DISCO_EINVAL; }

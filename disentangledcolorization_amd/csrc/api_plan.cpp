@@ -291,7 +291,8 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     };
     // use_mask (model.py:121-125): both stacks bias the keys of superpixels below 25 pixels; the mask IS a function of `sizes`, read in the kernels
     const float* key_sizes = c->opt.use_mask ? sizes : nullptr;
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s, P.dbg_row >= 0 ? &enc_dbg : nullptr, c->d_enc_pk[0], key_sizes, 1);
+    const float key_thr = 25.f / (float)(sp * sp);         // "fewer than 25 pixels" as a share of the cell (model.py:122)
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(src, pos, pos_rep, c->d_enc[0], enc, n, L, enc_ws, s, P.dbg_row >= 0 ? &enc_dbg : nullptr, c->d_enc_pk[0], key_sizes, 1, key_thr);
     P.dbg(enc, (size_t)n * L * 64 * 4);
     if (!dry && P.ok()) P.rc = launch_logits(enc, c->d_mid_w, a->d_pal_logit, n, L, s);
     P.dbg(a->d_pal_logit, (size_t)n * N_VOCAB * L * 4);
@@ -344,7 +345,7 @@ int run_plan(disco_ctx* c, const disco_forward_args* a, size_t cap, bool dry, si
     float* hint = (float*)P.raw((size_t)n2 * L * 64 * 4);
     float* dec = (float*)P.raw((size_t)n2 * L * 64 * 4);
     if (!dry && P.ok()) P.rc = launch_hint_embed(src, rep, h2r ? nullptr : labels, h2r ? a->d_spix_colors : nullptr, a->d_hint_mask, rep, c->d_emb_w, hint, n2, L, s);
-    if (!dry && P.ok()) P.rc = launch_encoder_stack(hint, pos, pos_rep ? rep : 0, c->d_enc[1], dec, n2, L, enc_ws, s, nullptr, c->d_enc_pk[1], key_sizes, rep);
+    if (!dry && P.ok()) P.rc = launch_encoder_stack(hint, pos, pos_rep ? rep : 0, c->d_enc[1], dec, n2, L, enc_ws, s, nullptr, c->d_enc_pk[1], key_sizes, rep, key_thr);
     if (!dry && P.ok()) P.rc = launch_logits(dec, c->d_trg_w, a->d_ref_logit, n2, L, s, h2r ? 2 : N_VOCAB);
     P.drop(enc_ws); P.drop(hint); P.drop(labels); P.drop(d_idx); P.drop(d_fb); P.drop(d_assign); P.drop(d_anchor);
     P.drop(enc); P.drop(src); P.drop(spix_ab); P.drop(sizes); if (pos_img) P.drop(pos_img);
@@ -388,7 +389,8 @@ int check_forward_args(disco_ctx* c, const disco_forward_args* a) {
     if (!c || !a) { set_error("null argument"); return DISCO_EINVAL; }
     if (!c->finalized) { set_error("disco_forward before disco_finalize"); return DISCO_ESTATE; }
     const int sp = c->opt.sp_size;
-    if (a->n < 1 || a->h < sp || a->w < sp || a->h % sp || a->w % sp) { set_error("bad input size %dx%dx%d (multiples of %d)", a->n, a->h, a->w, sp); return DISCO_ESHAPE; }
+    const int mult = sp > 16 ? sp : 16;              // whole superpixel cells AND the conv stacks' four stride-2 stages
+    if (a->n < 1 || a->h < mult || a->w < mult || a->h % mult || a->w % mult) { set_error("bad input size %dx%dx%d (multiples of %d)", a->n, a->h, a->w, mult); return DISCO_ESHAPE; }
     if (!c->opt.network && (a->h / sp) * (a->w / sp) < c->opt.n_clusters) { set_error("fewer tokens than clusters"); return DISCO_ESHAPE; }
     if (a->max_fallback < 0) { set_error("max_fallback %d", a->max_fallback); return DISCO_EINVAL; }
     if (a->max_fallback > c->opt.n_clusters * 20) { set_error("max_fallback %d > K*20", a->max_fallback); return DISCO_EINVAL; }

@@ -24,13 +24,12 @@ constexpr int KP = 16;     // key partitions (lanes) per query group
 // QT: queries per thread (a block covers (256 / KP) QT of them).  4 for throughput; 1 when the grid would not fill the GPU (one image of
 // 256 tokens: 32 workgroups at QT = 4) - a query's arithmetic does not depend on how many neighbours share its thread: same results
 // MASK: `use_mask` (model.py:121-125 -> transformer2d.py:53-54): key j of image i gets +1.0 on every score when superpixel j holds fewer than
-// 25 pixels (key_sizes[i / key_rep][j] < 25/256) - the reference's FLOAT key_padding_mask, additive under torch >= 1.9: score = mask + q k^T
+// 25 pixels (key_sizes[i / key_rep][j] < key_thr = 25 / cell area) - the reference's FLOAT key_padding_mask, additive under torch >= 1.9: score = mask + q k^T
 // (one rounding, like baddbmm).  Without MASK the kernel is the machine code it was.
-constexpr float SMALL_SPIXEL = 25.f / 256.f;
 template <int QT, bool MASK>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, float* out, int L,
-                                                        const float* __restrict__ key_sizes, int key_rep) {
+                                                        const float* __restrict__ key_sizes, int key_rep, float key_thr) {
     // halves of a key / value in separate arrays: the 16 partitions of a wave read 16 consecutive float4 (256 contiguous
     // bytes, no bank conflict; interleaved [key][2] rows put partitions p and p+8 on the same banks)
     __shared__ float4 sk[2][KCH];
@@ -64,7 +63,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             const int key = u >> 1, half = u & 1;
             sk[half][key] = *reinterpret_cast<const float4*>(k + base + (size_t)(c0 + key) * 64 + half * 4);
             sv[half][key] = *reinterpret_cast<const float4*>(v + base + (size_t)(c0 + key) * 64 + half * 4);
-            if constexpr (MASK) { if (half == 0) sbias[key] = key_sizes[(size_t)(img / key_rep) * L + c0 + key] < SMALL_SPIXEL ? 1.f : 0.f; }
+            if constexpr (MASK) { if (half == 0) sbias[key] = key_sizes[(size_t)(img / key_rep) * L + c0 + key] < key_thr ? 1.f : 0.f; }
         }
         __syncthreads();
         float sc[KCH / KP][QT];
@@ -151,18 +150,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // The form is chosen by the grid the launch would have: QT = 1 when QT = 4 could not give every CU a workgroup.  A query's arithmetic does not
 // depend on how many neighbours share its thread (every rounding step of the softmax is spelled out: mul_rn / add_rn / fmaf), so an
 // image's result does not depend on the batch it is part of (tests/test_gpu_ops.py::test_encoder_stack_result_does_not_depend_on_the_batch).
-int launch_attention_valu(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes, int key_rep) {
+int launch_attention_valu(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes, int key_rep, float key_thr) {
     // (beyond one workgroup per CU the two forms run the same: n = 2 ... 16 images measured with the threshold at 1x, 2x, 5x, 9x the CU count)
     const bool small = (long)cdiv(l, 64) * N_HEAD * n < num_cus_current();
     const dim3 grid(cdiv(l, small ? 16 : 64), N_HEAD, n);
     if (key_sizes) {
         if (key_rep < 1) { set_error("attention: key_rep %d", key_rep); return DISCO_EINVAL; }
-        if (small) hipLaunchKernelGGL((attention_kernel<1, true>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep);
-        else hipLaunchKernelGGL((attention_kernel<4, true>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep);
+        if (small) hipLaunchKernelGGL((attention_kernel<1, true>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep, key_thr);
+        else hipLaunchKernelGGL((attention_kernel<4, true>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep, key_thr);
     } else if (small)
-        hipLaunchKernelGGL((attention_kernel<1, false>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, 1);
+        hipLaunchKernelGGL((attention_kernel<1, false>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, 1, key_thr);
     else
-        hipLaunchKernelGGL((attention_kernel<4, false>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, 1);
+        hipLaunchKernelGGL((attention_kernel<4, false>), grid, dim3(256), 0, s, q, k, v, out, l, key_sizes, 1, key_thr);
     DISCO_LAUNCH_CHECK("attention_kernel");
     return DISCO_OK;
 }

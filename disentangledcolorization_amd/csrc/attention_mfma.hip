@@ -59,7 +59,7 @@ __device__ __forceinline__ float quad_bcast(float x) {     // lane (l & ~3) + SE
 template <int QW, int NW, bool KS, bool MASK>
 __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, float* out, int L,
-                                                             const float* __restrict__ key_sizes, int key_rep) {
+                                                             const float* __restrict__ key_sizes, int key_rep, float key_thr) {
     constexpr int NTHR = 64 * NW, KPT = AM_KPT, KCH = NTHR * KPT;  // keys per thread and chunk; keys per staged chunk
     constexpr int VTS = KCH + 8;                              // floats per row of the transposed V chunk (rows 32 bytes apart in bank phase)
     __shared__ float4 sK[2][KCH];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
             pk0[i] = pk1[i] = pv0[i] = pv1[i] = z;
             pbias[i] = 0.f;
             if (key < L) {
-                if constexpr (MASK) pbias[i] = key_sizes[(size_t)(img / key_rep) * L + key] < (25.f / 256.f) ? LOG2E : 0.f;
+                if constexpr (MASK) pbias[i] = key_sizes[(size_t)(img / key_rep) * L + key] < key_thr ? LOG2E : 0.f;
                 pk0[i] = *reinterpret_cast<const float4*>(k + base + (size_t)key * 64);
                 pk1[i] = *reinterpret_cast<const float4*>(k + base + (size_t)key * 64 + 4);
                 pv0[i] = *reinterpret_cast<const float4*>(v + base + (size_t)key * 64);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * NW) void attention_mfma_kernel(const float* __
 }  // namespace
 
 // softmax(q k^T) v per (image, head); q, k, v, out: (n, l, 64) fp32, head h in columns 8 h .. 8 h + 7; q pre-scaled by 1 / sqrt(8)
-int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes, int key_rep) {
+int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes, int key_rep, float key_thr) {
     // One 32-query tile per wave (126 VGPRs: four waves per SIMD; the QW = 2 form - 216 VGPRs, two waves per SIMD - measured 5-25 % slower at every
     // size, profiles/r05_attn_mfma_ab.txt "forms").  Two forms: (2) workgroups of four query tiles sharing the staged chunks; (3) the four waves of
     // a workgroup split the KEYS of one query tile (four times the waves per query: what one image of up to 2 048 tokens needs to fill the GPU).
@@ -310,11 +310,11 @@ int launch_attention_mfma(const float* q, const float* k, const float* v, float*
     const int form = forced ? forced : (l > 2048 ? 2 : 3);
     if (key_sizes && key_rep < 1) { set_error("attention: key_rep %d", key_rep); return DISCO_EINVAL; }
     if (form == 2) {
-        if (key_sizes) hipLaunchKernelGGL((attention_mfma_kernel<1, 4, false, true>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep);
-        else hipLaunchKernelGGL((attention_mfma_kernel<1, 4, false, false>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, 1);
+        if (key_sizes) hipLaunchKernelGGL((attention_mfma_kernel<1, 4, false, true>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep, key_thr);
+        else hipLaunchKernelGGL((attention_mfma_kernel<1, 4, false, false>), dim3(cdiv(l, 128), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, 1, key_thr);
     } else {
-        if (key_sizes) hipLaunchKernelGGL((attention_mfma_kernel<1, 4, true, true>), dim3(cdiv(l, 32), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep);
-        else hipLaunchKernelGGL((attention_mfma_kernel<1, 4, true, false>), dim3(cdiv(l, 32), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, 1);
+        if (key_sizes) hipLaunchKernelGGL((attention_mfma_kernel<1, 4, true, true>), dim3(cdiv(l, 32), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, key_rep, key_thr);
+        else hipLaunchKernelGGL((attention_mfma_kernel<1, 4, true, false>), dim3(cdiv(l, 32), N_HEAD, n), dim3(256), 0, s, q, k, v, out, l, key_sizes, 1, key_thr);
     }
     DISCO_LAUNCH_CHECK("attention_mfma_kernel");
     return DISCO_OK;

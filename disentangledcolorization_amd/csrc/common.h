@@ -374,11 +374,11 @@ size_t encoder_ws_bytes(int n, int l);
 // packed: the weights' B-fragment image for the 16-row tail kernel (launch_encoder_pack of the same `weights`), or null: 64-row tiles at every size
 // attention_mfma.hip: softmax(q k^T) v on the fp32 matrix cores (long token sequences; launch_encoder_stack picks it by the token count alone)
 // key_sizes (n / key_rep, l) or null: `use_mask` - keys of superpixels below 25 pixels (size < 25/256) get +1.0 on every score (model.py:121-125)
-int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes = nullptr, int key_rep = 1);
-int launch_attention_valu(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes = nullptr, int key_rep = 1);      // attention.hip
+int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes = nullptr, int key_rep = 1, float key_thr = 25.f / 256.f);
+int launch_attention_valu(const float* q, const float* k, const float* v, float* out, int n, int l, hipStream_t s, const float* key_sizes = nullptr, int key_rep = 1, float key_thr = 25.f / 256.f);      // attention.hip
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
                          void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg = nullptr, const float* packed = nullptr,
-                         const float* key_sizes = nullptr, int key_rep = 1);      // use_mask: the superpixel sizes of image i / key_rep bias image i's keys
+                         const float* key_sizes = nullptr, int key_rep = 1, float key_thr = 25.f / 256.f);      // use_mask: the superpixel sizes of image i / key_rep bias image i's keys (those below key_thr)
 size_t encoder_packed_floats();
 int launch_encoder_pack(const float* raw, float* packed, hipStream_t s);
 void position_encoding_host(float* h_pos /*(h*w,64)*/, int h, int w);

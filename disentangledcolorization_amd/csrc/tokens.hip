@@ -581,7 +581,7 @@ static int attention_mfma_min_tokens() {
 
 int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const float* weights, float* out, int n, int l,
                          void* ws, hipStream_t s, const std::function<void(const void*, size_t)>* dbg, const float* packed,
-                         const float* key_sizes, int key_rep) {
+                         const float* key_sizes, int key_rep, float key_thr) {
     const int T = n * l;
     const bool tail = packed != nullptr && T <= encoder_tail_max_rows();
     float* qkv = reinterpret_cast<float*>(ws);
@@ -620,10 +620,10 @@ int launch_encoder_stack(const float* x, const float* pos, int pos_rep, const fl
         if (dbg) (*dbg)(qkv, (size_t)3 * T * 64 * 4);
         // from attention_mfma_min_tokens() tokens on: both contractions on the matrix cores.  The choice depends on the token count alone.
         if (l >= attention_mfma_min_tokens()) {
-            const int rc = launch_attention_mfma(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s, key_sizes, key_rep);
+            const int rc = launch_attention_mfma(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s, key_sizes, key_rep, key_thr);
             if (rc) return rc;
         } else {
-            const int rc = launch_attention_valu(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s, key_sizes, key_rep);
+            const int rc = launch_attention_valu(qkv, qkv + (size_t)T * 64, qkv + (size_t)2 * T * 64, att, n, l, s, key_sizes, key_rep, key_thr);
             if (rc) return rc;
         }
         if (dbg) (*dbg)(att, (size_t)T * 64 * 4);

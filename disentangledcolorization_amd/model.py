@@ -8,7 +8,7 @@ the reference makes (NumPy k-means initialisation, Python `random` hints, torch 
 All arithmetic runs in hand-written HIP kernels; without the library this module raises.
 
 Supported: every configuration main/colorizer/inference.py can produce (inference.py:71-74,156-165) -
-enhanced=True, use_dense_pos=True, sp_size=16, d_model=64, clustering or random hints, --diverse, --spix_pos,
+enhanced=True, use_dense_pos=True, sp_size=16 (--psize; 8 and 32 run too, on the general pooling kernels), d_model=64, clustering or random hints, --diverse, --spix_pos,
 --hint2regress - plus the validation forward of train_colorizer.py:206 (model.eval(), test_mode=False).
 use_mask=True (model.py:38,121-125; no caller of the reference enables it) is supported with the semantics of torch >= 1.9, where the
 float key_padding_mask the reference builds is ADDED to the attention scores (+1.0 at superpixels below 25 pixels; the pinned torch 1.8
@@ -165,7 +165,7 @@ class AnchorColorProb(nn.Module):
         unsupported = []
         if inChannel != 1: unsupported.append("inChannel=%r" % inChannel)
         if outChannel != 313: unsupported.append("outChannel=%r" % outChannel)
-        if sp_size != 16: unsupported.append("sp_size=%r" % sp_size)
+        if sp_size not in (8, 16, 32): unsupported.append("sp_size=%r (8, 16 or 32)" % sp_size)
         if d_model != 64: unsupported.append("d_model=%r" % d_model)
         if not use_dense_pos: unsupported.append("use_dense_pos=False")
         if not enhanced: unsupported.append("enhanced=False")
@@ -441,8 +441,9 @@ class AnchorColorProb(nn.Module):
         n, _, H, W = gray.shape
         if gray.shape[1] != 1 or ab.shape != (n, 2, H, W):
             raise ValueError("expected gray (N,1,H,W) and ab (N,2,H,W)")
-        if H % self.sp_size or W % self.sp_size:
-            raise ValueError("H and W must be multiples of %d" % self.sp_size)
+        mult = max(16, self.sp_size)       # whole superpixel cells (--psize) and the conv stacks' four stride-2 stages
+        if H % mult or W % mult:
+            raise ValueError("H and W must be multiples of %d" % mult)
         return test_mode, gray, ab
 
     def set_progress_event(self, event, after_conv_launches):

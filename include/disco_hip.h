@@ -97,7 +97,9 @@ const char *disco_last_error(void);
 /* ---- context ------------------------------------------------------------------------- */
 
 typedef struct disco_options {
-    int32_t sp_size;     /* superpixel size, 16 (inference.py:146) */
+    int32_t sp_size;     /* superpixel size: --psize (inference.py:147), the cell of poolfeat / get_spixel_size / upfeat (model.py:109-121,
+                            191).  16 (the default, dedicated kernels), 8 or 32 (ABI 11: the general pooling kernels); H and W must be
+                            multiples of max(16, sp_size) */
     int32_t n_clusters;  /* K anchors (inference.py:156) */
     int32_t random_hint; /* 1: anchors come from h_hint_pos instead of k-means (model.py:69) */
     int32_t precision;   /* DISCO_PREC_* for the conv stacks */

@@ -27,14 +27,14 @@ def npy(t):
 
 
 def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed=5, full=True, sub=1,
-             feat_stride=8, aff_stride=4, test_mode=True, hint2regress=False, spix_pos=False, inputs=None, extra=None, use_mask=False):
+             feat_stride=8, aff_stride=4, test_mode=True, hint2regress=False, spix_pos=False, inputs=None, extra=None, use_mask=False, psize=16):
     ref_harness.install()
     import clusterkit  # reference module
 
     if hint2regress:
         sd = synth.synth_state_dict(SEED, hint2regress=True)
     m = ref_harness.build_reference_model(sd, n_clusters=k, random_hint=random_hint, hint2regress=hint2regress,
-                                          spix_pos=spix_pos, use_mask=use_mask)
+                                          spix_pos=spix_pos, use_mask=use_mask, sp_size=psize)
     gray, ab = inputs if inputs is not None else synth.synth_inputs(n, h, w, seed=input_seed, ab_scale=0.5)
     cap = {}
     orig_km = clusterkit.batch_kmeans_pytorch
@@ -72,6 +72,8 @@ def run_case(name, sd, *, n, h, w, k, sampled_T=0, random_hint=False, input_seed
         strides=np.array([feat_stride, aff_stride], dtype=np.int64),
         pred_absmax=np.array(float(pred.abs().max())),
     )
+    if psize != 16:
+        d["psize"] = np.array(psize, dtype=np.int64)
     if cap.get("pad_mask") is not None:      # use_mask: the float key_padding_mask both stacks received (model.py:121-125)
         d["pad_mask"] = npy(cap["pad_mask"])
     if "cluster_mask" in cap:
@@ -258,6 +260,14 @@ def networks_case(sd):
                         spixelnet=npy(outs["segnet.net."]), colorprobnet=npy(outs["repnet."]), hourglass2=npy(outs["enhanceNet."]))
 
 
+def psize_cases(sd):
+    # --psize 8 / 32 (inference.py:147): the superpixel cell of pooling, sizes and un-pooling; the networks are the same
+    run_case("fwd_psize8_128x192_k8", sd, n=1, h=128, w=192, k=8, input_seed=17, psize=8)
+    run_case("fwd_psize32_256_k8", sd, n=2, h=256, w=256, k=8, input_seed=18, psize=32, feat_stride=16, aff_stride=8)
+    # ... and with use_mask (threshold 25 / psize^2 of the cell, model.py:122) on the checkpoint variant with small superpixels
+    run_case("fwd_psize8_usemask_128_k8", synth.small_superpixel_variant(sd), n=1, h=128, w=128, k=8, input_seed=19, psize=8, use_mask=True, feat_stride=16, aff_stride=8)
+
+
 def usemask_cases(sd):
     # use_mask (model.py:38,121-125): on the checkpoint variant that HAS superpixels below 25 pixels (synth.small_superpixel_variant) -
     # the float key_padding_mask is additive under this container's torch 2.10 (oracle/disco_ref.py encoder_layer)
@@ -277,6 +287,8 @@ def main():
         return photo_case(sd)
     if "--usemask-only" in sys.argv:
         return usemask_cases(sd)
+    if "--psize-only" in sys.argv:
+        return psize_cases(sd)
     photo_case(sd)
     # the forward variants beyond inference.py's default flags: the validation forward
     # (train_colorizer.py:206), --hint2regress, --spix_pos (inference.py:156,158)
@@ -286,6 +298,7 @@ def main():
     run_case("fwd_spixpos_h2r_diverse_128_k16", sd, n=1, h=128, w=128, k=16, sampled_T=2, input_seed=14,
              hint2regress=True, spix_pos=True)
     usemask_cases(sd)
+    psize_cases(sd)
     if "--variants-only" in sys.argv:
         return
     posthoc()

@@ -59,13 +59,13 @@ def install():
     _installed = True
 
 
-def build_reference_model(state_dict, n_clusters=8, random_hint=False, hint2regress=False, spix_pos=False, use_mask=False):
+def build_reference_model(state_dict, n_clusters=8, random_hint=False, hint2regress=False, spix_pos=False, use_mask=False, sp_size=16):
     """The reference AnchorColorProb exactly as main/colorizer/inference.py:71-74,85,89 builds it
     (--hint2regress / --spix_pos: inference.py:156,158)."""
     install()
     import model  # the reference's models/model.py
 
-    m = model.AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True,
+    m = model.AnchorColorProb(inChannel=1, outChannel=313, sp_size=sp_size, d_model=64, use_dense_pos=True,
                               spix_pos=spix_pos, learning_pos=False, n_clusters=n_clusters,
                               random_hint=random_hint, hint2regress=hint2regress, enhanced=True, use_mask=use_mask)
     m.load_state_dict(state_dict)  # strict

@@ -25,10 +25,10 @@ def _err(a, b):
 _models = {}
 
 
-def _model(sd, k, random_hint=False, hint2regress=False, spix_pos=False, use_mask=False):
-    key = (k, random_hint, hint2regress, spix_pos, use_mask)
+def _model(sd, k, random_hint=False, hint2regress=False, spix_pos=False, use_mask=False, psize=16):
+    key = (k, random_hint, hint2regress, spix_pos, use_mask, psize)
     if key not in _models:
-        m = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=spix_pos,
+        m = AnchorColorProb(inChannel=1, outChannel=313, sp_size=psize, d_model=64, use_dense_pos=True, spix_pos=spix_pos,
                             learning_pos=False, n_clusters=k, random_hint=random_hint, hint2regress=hint2regress,
                             enhanced=True, use_mask=use_mask, init_weights=False)
         if hint2regress:               # the two head tensors take their --hint2regress shapes; the rest is the same
@@ -49,7 +49,9 @@ CASES = ["fwd_n2_256_k8", "fwd_diverse_256_k16", "fwd_n1_128x192_k8", "fwd_randh
          # validation forward (test_mode=False), --hint2regress, --spix_pos, and all of them with --diverse
          "fwd_val_128_k8", "fwd_h2r_128_k8", "fwd_spixpos_128x192_k8", "fwd_spixpos_h2r_diverse_128_k16",
          # use_mask=True (model.py:38,121-125), 96 tokens (VALU attention) and 1 024 tokens (MFMA attention); round 6
-         "fwd_usemask_128x192_k8", "fwd_usemask_512_k8"]
+         "fwd_usemask_128x192_k8", "fwd_usemask_512_k8",
+         # --psize 8 / 32 (inference.py:147): the general pooling / un-pooling kernels; round 6
+         "fwd_psize8_128x192_k8", "fwd_psize32_256_k8", "fwd_psize8_usemask_128_k8"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -58,7 +60,7 @@ def test_forward_matches_reference_golden(golden_dir, synth_sd, name):
     n, h, w, k, T, rh, iseed, seed = (int(v) for v in g["recipe"])
     test_mode, h2r, spos = (bool(v) for v in g["flags"]) if "flags" in g.files else (True, False, False)
     gray, ab = synth.synth_inputs(n, h, w, seed=iseed, ab_scale=0.5)
-    m = _model(synth_sd, k, bool(rh), h2r, spos, "pad_mask" in g.files)
+    m = _model(synth_sd, k, bool(rh), h2r, spos, "pad_mask" in g.files, int(g["psize"]) if "psize" in g.files else 16)
     _seed(seed)
     pal, ref, pred, aff, spix, mask = m(gray.cuda(), ab.cuda(), test_mode, T)
     torch.cuda.synchronize()
@@ -1123,3 +1125,31 @@ def test_randomised_use_mask_configurations_match_oracle(synth_sd, q_to_ab, case
     e = _err(got[2], want[2])
     print(f"use_mask case {case}: {mode} {h}x{w} n={n} K={k} slot {slot}: {int(small.sum())} small superpixels, max|ab - oracle| = {e:.2e}")
     assert e <= AB_TOL
+
+
+@pytest.mark.parametrize("psize,shape,mode", [(8, (2, 128, 160), "plain"), (8, (1, 512, 512), "plain"), (8, (1, 96, 96), "diverse"), (32, (3, 256, 320), "plain"),
+                                              (32, (1, 512, 768), "gt"), (32, (2, 256, 256), "val"), (8, (2, 144, 112), "randhint")])
+def test_other_superpixel_sizes_match_oracle(synth_sd, q_to_ab, psize, shape, mode):
+    """--psize 8 / 32 (inference.py:147: the cell of pooling, size count and un-pooling; goldens of the live reference: fwd_psize*.npz) on
+    further sizes and modes against the oracle - 8 on a 512x512 image is 4 096 tokens (the several-workgroup k-means, the MFMA attention),
+    32 on 256x256 is 64.  Anchors exact, ab within the bar."""
+    n, h, w = shape
+    k = 8
+    rh = mode == "randhint"
+    m = _model(synth_sd, k, random_hint=rh, psize=psize)
+    gray, ab = synth.synth_inputs(n, h, w, seed=700 + psize + h + w, ab_scale=0.4)
+    T = {"plain": 0, "diverse": 2, "gt": -1, "val": 0, "randhint": 0}[mode]
+    test_mode = mode != "val"
+    _seed(21)
+    got = m(gray.cuda(), ab.cuda(), test_mode, T)
+    torch.cuda.synchronize()
+    assert got[0].shape == (n, 313, h // psize, w // psize) and got[5].shape[2:] == (h // psize, w // psize)
+    _seed(21)
+    want = R.DiscoOracle(synth_sd, q_to_ab, sp_size=psize, n_clusters=k, random_hint=rh).forward(gray, ab, sampled_T=T, test_mode=test_mode)
+    assert torch.equal(got[5].cpu(), want[5]), "anchors differ (psize %d %s %dx%d)" % (psize, mode, h, w)
+    assert _err(got[3], want[3]) < 1e-4 and _err(got[0], want[0]) < LOGIT_TOL and _err(got[1], want[1]) < LOGIT_TOL
+    e = _err(got[2], want[2])
+    print(f"psize {psize} {mode} {n}x{h}x{w}: max|ab - oracle| = {e:.2e}")
+    assert e <= AB_TOL
+    with pytest.raises(ValueError):                      # whole cells AND multiples of 16
+        m(gray[:, :, : h - 16 if psize == 32 else h - 8].cuda(), ab[:, :, : h - 16 if psize == 32 else h - 8].cuda(), True, 0)

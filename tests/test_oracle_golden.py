@@ -188,7 +188,8 @@ def _run(golden_dir, synth_sd, q_to_ab, name):
     use_mask = "pad_mask" in g.files       # use_mask fixtures: made on the checkpoint variant that has superpixels below 25 pixels
     if use_mask:
         sd = synth.small_superpixel_variant(sd)
-    oracle = R.DiscoOracle(sd, q_to_ab, n_clusters=k, random_hint=bool(rh), hint2regress=h2r, spix_pos=spos, use_mask=use_mask)
+    psize = int(g["psize"]) if "psize" in g.files else 16          # --psize (inference.py:147)
+    oracle = R.DiscoOracle(sd, q_to_ab, sp_size=psize, n_clusters=k, random_hint=bool(rh), hint2regress=h2r, spix_pos=spos, use_mask=use_mask)
     np.random.seed(seed); torch.manual_seed(seed); random.seed(seed)
     out, info = oracle.forward(gray, ab, sampled_T=T, return_info=True, test_mode=test_mode)
     return g, out, info
@@ -202,7 +203,7 @@ def _check_forward(g, out, info):
     _close(aff[: g["aff_sub"].shape[0], :, ::as_, ::as_], g["aff_sub"], 1e-5)
     _close(info["enc"], g["enc"], 1e-4)
     if "pad_mask" in g.files:          # the float key_padding_mask the reference built (model.py:121-125): must be non-trivial and equal
-        pad = R.entry_mask(info["sizes"], 16)
+        pad = R.entry_mask(info["sizes"], int(g["psize"]) if "psize" in g.files else 16)
         assert torch.equal(pad, torch.from_numpy(g["pad_mask"])) and 0 < float(pad.sum()) < pad.numel()
     if "cluster_ids" in g.files:
         assert np.array_equal(info["assign"].numpy(), g["cluster_ids"].astype(np.int64))
@@ -227,7 +228,9 @@ def _check_forward(g, out, info):
                                   # two of the photographs the reference ships (data/*.jpg), 256 x 256 (round 4)
                                   "fwd_photo_256_k8",
                                   # use_mask=True (model.py:38,121-125): float key_padding_mask, additive under torch >= 1.9 (round 6)
-                                  "fwd_usemask_128x192_k8", "fwd_usemask_512_k8"])
+                                  "fwd_usemask_128x192_k8", "fwd_usemask_512_k8",
+                                  # --psize 8 / 32 (inference.py:147), and 8 with use_mask (threshold 25 / psize^2); round 6
+                                  "fwd_psize8_128x192_k8", "fwd_psize32_256_k8", "fwd_psize8_usemask_128_k8"])
 def test_forward_matches_reference(golden_dir, synth_sd, q_to_ab, name):
     g, out, info = _run(golden_dir, synth_sd, q_to_ab, name)
     _check_forward(g, out, info)

@@ -36,12 +36,13 @@ def main():
     ap.add_argument("--anchors", action="store_true", help="also save the anchor overlay")
     ap.add_argument("--no_resize", action="store_true", help="keep the original size (padded to multiples of 16), inference.py:148")
     ap.add_argument("--resize_to", type=int, default=256, help="side of the resized input (the reference hard-codes 256, inference.py:33; its --psize is the superpixel size)")
+    ap.add_argument("--psize", type=int, default=16, choices=[8, 16, 32], help="superpixel size (inference.py:147; inputs are padded / resized to multiples of 16, so 32 needs sizes that are multiples of 32)")
     ap.add_argument("--seed", type=int, default=130)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     # inference.py:58-60
     np.random.seed(args.seed); torch.manual_seed(args.seed); random.seed(args.seed)
-    model = AnchorColorProb(inChannel=1, outChannel=313, sp_size=16, d_model=64, use_dense_pos=True, spix_pos=args.spix_pos,
+    model = AnchorColorProb(inChannel=1, outChannel=313, sp_size=args.psize, d_model=64, use_dense_pos=True, spix_pos=args.spix_pos,
                             learning_pos=False, n_clusters=args.n_clusters, random_hint=args.random_hint,
                             hint2regress=args.hint2regress, enhanced=True, init_weights=args.checkpt is None)
     if args.checkpt:
@@ -59,7 +60,7 @@ def main():
             out8 = basic.normLabs_to_rgb8(lab, H, W)[0].cpu().numpy()
             Image.fromarray(out8).save(os.path.join(args.out, stem + ("-c%d" % i if args.diverse else "") + ".png"))
         if args.anchors and not args.diverse:
-            gates = basic.upfeat(hint_mask, affinity, 16, 16)
+            gates = basic.upfeat(hint_mask, affinity, args.psize, args.psize)
             marked = basic.mark_color_hints(gray, pred_ab, gates, base_ABs=pred_ab)
             Image.fromarray(basic.normLabs_to_rgb8(marked, H, W)[0].cpu().numpy()).save(os.path.join(args.out, stem + "-anchors.png"))
         print("colorized", path, "(%dx%d)" % (W, H))
