@@ -20,7 +20,9 @@ int calibrate_ctx(disco_ctx* c, const float* d_user_gray, int un, int uh, int uw
     return rc;
 }
 int calibrate_ctx_impl(disco_ctx* c, const float* d_user_gray, int un, int uh, int uw) {
-    const int n = d_user_gray ? un : 2, H = d_user_gray ? uh : 256, W = d_user_gray ? uw : 256, K = c->opt.n_clusters, L = (H / 16) * (W / 16);
+    const int n = d_user_gray ? un : 2, H = d_user_gray ? uh : 256, W = d_user_gray ? uw : 256, K = c->opt.n_clusters;
+    const int sp = c->opt.sp_size > 0 ? c->opt.sp_size : 16;          // (--psize: the token grid, hence the sizes of the token outputs below)
+    const int L = (H / sp) * (W / sp);
     std::vector<float> g(d_user_gray ? 0 : (size_t)n * H * W);
     if (!d_user_gray) {
     unsigned st = 20240607u;
@@ -84,7 +86,8 @@ extern "C" {
 
 int disco_calibrate(disco_ctx* c, const float* d_gray, int n, int h, int w) {
     if (!c || !c->finalized || !d_gray) { set_error("disco_calibrate: bad argument / context not finalized"); return DISCO_EINVAL; }
-    if (n < 1 || n > 64 || h < 16 || w < 16 || h % 16 || w % 16 || (!c->opt.network && (h / 16) * (w / 16) < c->opt.n_clusters)) { set_error("disco_calibrate: bad size %dx%dx%d", n, h, w); return DISCO_ESHAPE; }
+    const int sp = c->opt.sp_size > 16 ? c->opt.sp_size : 16, cell = c->opt.sp_size > 0 ? c->opt.sp_size : 16;
+    if (n < 1 || n > 64 || h < sp || w < sp || h % sp || w % sp || (!c->opt.network && (h / cell) * (w / cell) < c->opt.n_clusters)) { set_error("disco_calibrate: bad size %dx%dx%d", n, h, w); return DISCO_ESHAPE; }
     DISCO_HIP_CHECK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mu);
     ProgressDisarm disarm{c, nullptr};
