@@ -29,6 +29,6 @@ for n, h, w in [(1, 512, 768), (4, 512, 768), (2, 1024, 1024), (3, 768, 512)]:
         outs.append((p, hm))
     r2.wait(); torch.cuda.synchronize()
     bad = sum(1 for p, hm in outs if not (torch.equal(p, ref_p) and torch.equal(hm, ref_m)))
-    print("%d x %dx%d: %d pipelined forwards, %d differ from the one-stream result" % (n, h, w, iters, bad), flush=True)
+    print("%d x %dx%d: %d pipelined forwards, %d differ from the one-stream result; %d images went to the one-workgroup k-means" % (n, h, w, iters, bad, m.kmeans_fallback_count()), flush=True)
     assert bad == 0
 print("ok")
