@@ -255,3 +255,38 @@ def test_reference_side_change_script(tmp_path):
     assert b"from disentangledcolorization_amd import model, basic\r\n" in seg
     assert run("--revert").count("reverted") == 2
     assert (tmp_path / "main" / "colorizer" / "inference.py").read_bytes() == body.encode()
+
+
+def test_ctypes_structs_mirror_the_header():
+    """The binding's structs (disentangledcolorization_amd/_ffi.py) against include/disco_hip.h, field by field and in order: a field appended
+    to the header (ABI 11: disco_options.use_mask) and forgotten in the binding would shift nothing and silently read as zero - or worse.  Also:
+    disco_create refuses superpixel sizes other than 8 / 16 / 32 and the library and the binding agree on the ABI version."""
+    from disentangledcolorization_amd import _ffi
+    text = open(os.path.join(REPO, "include", "disco_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+    def header_fields(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):                       # "int32_t n, h, w" and "float *a, *b" declare several
+                out.append(re.sub(r"\[.*?\]", "", part.strip().split()[-1].lstrip("*")))
+        return out
+
+    for cname, pyname in (("disco_options", "Options"), ("disco_forward_args", "ForwardArgs"), ("disco_conv_desc", "ConvDesc"), ("disco_conv_mx_desc", "ConvMxDesc")):
+        want = header_fields(cname)
+        got = [f[0] for f in getattr(_ffi, pyname)._fields_]
+        assert got == want, "%s: binding %s, header %s" % (cname, got, want)
+    assert re.search(r"#define DISCO_ABI_VERSION (\d+)", text).group(1) == str(_ffi.ABI_VERSION)
+    lib = _ffi.lib()
+    import ctypes as C
+    for sp, ok in ((8, True), (16, True), (32, True), (4, False), (24, False), (64, False)):
+        ctx = C.c_void_p()
+        rc = lib.disco_create(0, C.byref(_ffi.Options(sp, 8, 0, _ffi.PREC_MX6, 0, 0, 0, 0)), C.byref(ctx))
+        # (no GPU here: an accepted size gets as far as the device and fails there with DISCO_EHIP; a refused one never does)
+        assert (rc != -3) == ok and (ok or b"sp_size" in lib.disco_last_error()), (sp, rc)
+        if rc == 0:
+            lib.disco_destroy(ctx)
