@@ -121,7 +121,7 @@ def anchor_mismatch():
         out = {}
         for size, r in d["sets"].items():
             e = {"n": r["n"], "hip_vs_oracle": r["hip_vs_oracle"], "rate": r["rate_hip_vs_oracle"]}
-            for v, name in (("G", "fp32_other_order_vs_oracle"), ("D", "fp64_vs_oracle"), ("B", "cpu_fp32_no_onednn_vs_oracle")):
+            for v, name in (("G", "fp32_other_order_vs_oracle"), ("D", "fp64_vs_oracle"), ("B", "cpu_fp32_no_onednn_vs_oracle"), ("X", "oracle_on_another_host_vs_oracle")):
                 if v in r:
                     e[name] = {"n": r[v]["n"], "count": r[v]["vs_oracle"], "rate": r[v]["rate_vs_oracle"]}
             for k in ("hip_mismatches_also_flipped_by_an_exact_evaluation", "hip_mismatches_flipped_by_hip_alone"):

@@ -16,6 +16,7 @@ how many does the fp32 control B or the fp64 evaluation C ALSO decide differentl
 
     G  the oracle's code on torch-ROCm tensors, MIOpen off (im2col + rocBLAS gemm convolutions): exact fp32 in a third order, on the GPU
     D  the same in fp64
+    X  the oracle itself (A's code and settings) on another host CPU: oneDNN picks its kernels and its reduction split by ISA and thread count
 
 Workers write one small file per (set, chunk of 16 images, variant) as they go (tools/anchor_study.sh starts eight CPU workers and one GPU
 worker side by side); `report` merges what exists:
@@ -183,7 +184,8 @@ def same_set(a, b):
 
 
 NAMES = {"A": "oracle (CPU fp32, oneDNN)", "B": "CPU fp32, oneDNN off (im2col + sgemm)", "C": "CPU fp64", "G": "torch-ROCm fp32 (im2col + rocBLAS)",
-         "D": "torch-ROCm fp64", "H": "HIP path (f16x3 anchor stacks)"}
+         "D": "torch-ROCm fp64", "H": "HIP path (f16x3 anchor stacks)",
+         "X": "the oracle ITSELF on another host (the GPU box's CPU, 32 threads, instead of the build container's 8)"}
 
 
 def stage_report(args):
@@ -207,7 +209,7 @@ def stage_report(args):
         rec["hip_mismatch_images"] = np.nonzero(hA)[0].tolist()[:64]
         line = "%4dx%-4d | HIP != oracle: %d of %d (%.3f %%)" % (h, w, hA.sum(), len(A), 100 * hA.mean())
         near_any = np.zeros(len(A), bool); covered = np.ones(len(A), bool)
-        for v in "BCGD":
+        for v in "XBCGD":
             if v not in tab:
                 continue
             cs = sorted(set(tab[v]) & set(chunks_ah))
